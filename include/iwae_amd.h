@@ -1,0 +1,145 @@
+/* iwae_amd -- C ABI of the MI355X-native IWAE train / eval step.
+ *
+ * Drop-in boundary for the hot path of nbip/IWAE (a pure-Python TF2 repo with no FFI of its
+ * own): each entry point replaces the Python-level call named next to it (file:line under
+ * /root/reference).  Plain C types only; every function returns IWAE_OK (0) or a negative
+ * iwae_status, the message is available from iwae_last_error().  No C++ exceptions cross
+ * this boundary.  A handle is bound to one GPU and one HIP stream; calls on one handle are
+ * stream-ordered and not thread-safe, different handles are independent.
+ *
+ * Pointers named `x`, `eps`, `flat`, `out` may be host OR device pointers (the copy uses
+ * hipMemcpyDefault); host results are valid when the call returns.
+ * Tensor order at this boundary is the reference's: sample axis first, [k, B, ...]
+ * (src/iwae1.py:59,107-125), C-contiguous float32.
+ */
+#ifndef IWAE_AMD_H
+#define IWAE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iwae_model* iwae_handle;
+
+typedef enum {
+    IWAE_OK = 0,
+    IWAE_ERR_ARG = -1,      /* bad argument (the Python shim maps it to ValueError / KeyError) */
+    IWAE_ERR_HIP = -2,      /* HIP runtime error */
+    IWAE_ERR_NOMEM = -3,    /* device allocation failed */
+    IWAE_ERR_STATE = -4     /* call order (e.g. backward without forward) */
+} iwae_status;
+
+/* --objective choices of main.py:23, plus the DReG estimator of tasks/task02.py:87-101 */
+typedef enum {
+    IWAE_OBJ_VAE_ELBO = 0,     /* src/iwae1.py:120 */
+    IWAE_OBJ_IWAE_ELBO = 1,    /* src/iwae1.py:125 */
+    IWAE_OBJ_IWAE_EQ14 = 2,    /* src/iwae1.py:128-134 */
+    IWAE_OBJ_VAE_ELBO_KL = 3,  /* src/iwae1.py:121 (1-layer only; a KeyError for the 2-layer model, src/iwae2.py:154-167) */
+    IWAE_OBJ_DREG = 4          /* tasks/task02.py:61-101 (1-layer only) */
+} iwae_objective;
+
+/* iwae1.IWAE(n_hidden, n_latent) src/iwae1.py:89-96 / iwae2.IWAE(n_hidden[2], n_latent[2]) src/iwae2.py:100-107 */
+typedef struct {
+    int32_t n_layers;          /* 1 or 2 stochastic layers (main.py:17) */
+    int32_t n_hidden[2];       /* main.py:86,90 : {200} / {200,100}; each <= 256 */
+    int32_t n_latent[2];       /* main.py:85,89 : {100} / {100,50};  each <= 128 */
+    int32_t x_dim;             /* 784 */
+    int32_t device;            /* HIP device ordinal */
+    uint64_t seed;             /* Philox key for the reparameterisation noise (main.py:40-41 seeds TF) */
+    int32_t world_size;        /* data-parallel ranks (1 = single GPU) */
+    int32_t rank;
+} iwae_config;
+
+/* scalar entries of the result dict (src/iwae1.py:141-144, tasks/task02.py:78-79) and the
+ * means that IWAE.write_to_tensorboard logs (src/iwae1.py:228-232) */
+typedef struct {
+    float vae_elbo;
+    float vae_elbo_kl;
+    float iwae_elbo;
+    float iwae_eq14;
+    float inference_loss;      /* DReG only */
+    float mean_lpxz;           /* mean over [k,B] of lpxz (lpxz1) */
+    float mean_lpz;            /* 1-layer: lpz ; 2-layer: lpz1z2 */
+    float mean_lqzx;           /* 1-layer: lqzx ; 2-layer: lpz2 */
+    float mean_kl;
+    float reserved[7];
+} iwae_scalars;
+
+/* optional tensor outputs (NULL = not wanted, then never materialised).  1-layer names;
+ * for the 2-layer model z=z1, z2=z2, lpz=lpz1z2, lpz2=lpz2, lqzx=lqz1x, lqzx2=lqz2z1 */
+typedef struct {
+    float* z;        /* [k,B,D1]  src/iwae1.py:145 */
+    float* z2;       /* [k,B,D2]  src/iwae2.py:158 */
+    float* snis_z;   /* [B,D1]    src/iwae1.py:146 */
+    float* snis_z2;  /* [B,D2]    src/iwae2.py:160 */
+    float* al;       /* [k,B]     src/iwae1.py:147 */
+    float* logits;   /* [k,B,X]   src/iwae1.py:148 */
+    float* lpxz;     /* [k,B]     src/iwae1.py:149 */
+    float* lpz;      /* [k,B]     src/iwae1.py:150 */
+    float* lqzx;     /* [k,B]     src/iwae1.py:151 */
+    float* lpz2;     /* [k,B]     src/iwae2.py:165 */
+    float* lqzx2;    /* [k,B]     src/iwae2.py:167 */
+    float* log_w;    /* [k,B]     src/iwae1.py:113 */
+} iwae_tensors;
+
+const char* iwae_last_error(void);
+int iwae_version(void);
+
+/* model construction: iwae1.IWAE(...) / iwae2.IWAE(...) ; weights glorot-uniform / zero-bias
+ * (Keras Dense defaults, src/iwae1.py:31-34,72-75) drawn from `seed`; set the data-mean output
+ * bias (src/utils.py:11-23) with iwae_set_params or iwae_set_output_bias. */
+int iwae_create(const iwae_config* cfg, iwae_handle* out);
+void iwae_destroy(iwae_handle h);
+int iwae_set_stream(iwae_handle h, void* hip_stream);        /* run on the caller's stream (e.g. torch's) */
+int iwae_sync(iwae_handle h);
+
+/* model.trainable_weights (Keras creation order, kernel [in,out] then bias [out] per Dense) */
+int iwae_param_count(iwae_handle h, size_t* n);
+int iwae_num_tensors(iwae_handle h, int32_t* n);
+int iwae_tensor_info(iwae_handle h, int32_t idx, char* name, size_t name_cap, int32_t* rows, int32_t* cols, size_t* offset);
+int iwae_set_params(iwae_handle h, const float* flat, size_t n);   /* model.load_weights / set_weights */
+int iwae_get_params(iwae_handle h, float* flat, size_t n);         /* model.save_weights (main.py:165) */
+int iwae_set_output_bias(iwae_handle h, const float* bias, size_t n);  /* utils.get_bias(), src/utils.py:11-23 */
+int iwae_get_grads(iwae_handle h, float* flat, size_t n);          /* tape.gradient result, src/iwae1.py:159 */
+int iwae_get_adam_state(iwae_handle h, float* m, float* v, size_t n, int64_t* step);
+int iwae_set_adam_state(iwae_handle h, const float* m, const float* v, size_t n, int64_t step);
+
+/* model(x, n_samples, beta) / val_step : src/iwae1.py:98-151,164-166 (main.py:152,176).
+ * x [B, x_dim] in {0,1}; eps NULL (device Philox) or the N(0,1) draws of qzx.sample:
+ * 1-layer [k,B,D1]; 2-layer eps = [k,B,D1] followed by [k,B,D2]. */
+int iwae_forward(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, const float* eps,
+                 iwae_scalars* scalars, const iwae_tensors* want);
+
+/* model.train_step(x, n_samples, beta, optimizer, objective) : src/iwae1.py:153-162 (main.py:143),
+ * tasks/task02.py:87-101 for IWAE_OBJ_DREG.  lr = optimizer.learning_rate (main.py:93,128-133). */
+int iwae_train_step(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, float lr, int32_t objective,
+                    const float* eps, iwae_scalars* scalars, const iwae_tensors* want);
+
+/* the two halves of train_step, for data-parallel training: forward+backward leaves the flat fp32
+ * gradient of THIS rank's shard (mean over its B images) on the device; the caller all-reduces
+ * iwae_grad_devptr() (RCCL) and applies Adam with grad_scale = 1/world_size. */
+int iwae_forward_backward(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, int32_t objective,
+                          const float* eps, iwae_scalars* scalars, const iwae_tensors* want);
+int iwae_grad_devptr(iwae_handle h, void** dev_ptr, size_t* n);
+int iwae_adam_step(iwae_handle h, float lr, float grad_scale);      /* keras Adam(lr, epsilon=1e-4), main.py:93 */
+int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /* Philox counter words */
+
+/* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
+ * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
+int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);
+
+/* IWAE.sample(z): decoder only, src/iwae1.py:168-178 (z [n,D_last]) -> probs [n, x_dim] */
+int iwae_decode(iwae_handle h, const float* z, int32_t n, float* probs);
+
+/* debugging: fetch an internal activation / gradient as float32 [rows, feat] (names in DESIGN.md) */
+int iwae_debug_tensor(iwae_handle h, const char* name, float* out, size_t cap, int32_t* rows, int32_t* cols);
+/* the N(0,1) draws the device generator produces for (B,k): [k,B,D] */
+int iwae_debug_eps(iwae_handle h, int32_t B, int32_t k, int32_t layer, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

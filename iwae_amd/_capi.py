@@ -1,0 +1,94 @@
+"""ctypes binding of libiwae_amd.so (include/iwae_amd.h).  There is no CPU fallback: if the
+library is missing or no AMD GPU is present, construction raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libiwae_amd.so")
+
+OBJECTIVES = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "dreg": 4}
+
+
+class Config(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_hidden", C.c_int32 * 2), ("n_latent", C.c_int32 * 2),
+                ("x_dim", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
+                ("world_size", C.c_int32), ("rank", C.c_int32)]
+
+
+class Scalars(C.Structure):
+    _fields_ = [("vae_elbo", C.c_float), ("vae_elbo_kl", C.c_float), ("iwae_elbo", C.c_float),
+                ("iwae_eq14", C.c_float), ("inference_loss", C.c_float), ("mean_lpxz", C.c_float),
+                ("mean_lpz", C.c_float), ("mean_lqzx", C.c_float), ("mean_kl", C.c_float),
+                ("reserved", C.c_float * 7)]
+
+
+TENSOR_FIELDS = ("z", "z2", "snis_z", "snis_z2", "al", "logits", "lpxz", "lpz", "lqzx", "lpz2", "lqzx2", "log_w")
+
+
+class Tensors(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TENSOR_FIELDS]
+
+
+# every symbol include/iwae_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "iwae_last_error": (C.c_char_p, []),
+    "iwae_version": (C.c_int, []),
+    "iwae_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "iwae_destroy": (None, [_P]),
+    "iwae_set_stream": (C.c_int, [_P, _P]),
+    "iwae_sync": (C.c_int, [_P]),
+    "iwae_param_count": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "iwae_num_tensors": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "iwae_tensor_info": (C.c_int, [_P, C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
+    "iwae_set_params": (C.c_int, [_P, _P, C.c_size_t]),
+    "iwae_get_params": (C.c_int, [_P, _P, C.c_size_t]),
+    "iwae_set_output_bias": (C.c_int, [_P, _P, C.c_size_t]),
+    "iwae_get_grads": (C.c_int, [_P, _P, C.c_size_t]),
+    "iwae_get_adam_state": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_int64)]),
+    "iwae_set_adam_state": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int64]),
+    "iwae_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
+    "iwae_train_step": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
+    "iwae_forward_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
+    "iwae_grad_devptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "iwae_adam_step": (C.c_int, [_P, C.c_float, C.c_float]),
+    "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "iwae_eval_llh": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), _P]),
+    "iwae_decode": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "iwae_debug_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "iwae_debug_eps": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libiwae_amd.so (built in-tree by __graft_entry__.build() / csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("iwae_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the IWAE hot path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class IwaeError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = load().iwae_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -3:
+        raise MemoryError(msg)
+    raise IwaeError("iwae_amd error %d: %s" % (rc, msg))

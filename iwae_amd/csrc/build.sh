@@ -1,0 +1,10 @@
+#!/bin/bash
+# Builds libiwae_amd.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+$HIPCC $FLAGS -c kernels.hip -o kernels.o
+$HIPCC $FLAGS -c model.hip -o model.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libiwae_amd.so kernels.o model.o
+echo "built $(cd .. && pwd)/libiwae_amd.so"

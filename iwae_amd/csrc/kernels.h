@@ -1,0 +1,136 @@
+// Argument blocks and launch wrappers for kernels.hip (internal; the public ABI is include/iwae_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace iwae {
+
+enum { EPI_TANH = 0, EPI_HEAD = 1, EPI_DX = 2, EPI_F32 = 3, EPI_BERN = 4, EPI_SIGMOID = 5 };
+enum { OBJ_VAE_ELBO = 0, OBJ_IWAE_ELBO = 1, OBJ_IWAE_EQ14 = 2, OBJ_VAE_ELBO_KL = 3, OBJ_DREG = 4 };
+// per-image reductions written by lse_kernel
+enum { PB_LME = 0, PB_MEAN, PB_EQ14, PB_KL, PB_PX, PB_T1, PB_T2, PB_DREG, PB_COUNT };
+// scalar outputs (device float[16]); must match iwae_scalars in include/iwae_amd.h
+enum { SC_VAE_ELBO = 0, SC_VAE_ELBO_KL, SC_IWAE_ELBO, SC_IWAE_EQ14, SC_INFERENCE_LOSS, SC_MEAN_LPXZ, SC_MEAN_T1, SC_MEAN_T2, SC_KL, SC_COUNT = 16 };
+
+struct EpsSrc {
+    const float* user;     // [k][B][D] host-supplied draws (reference order) or null -> Philox
+    int B;
+    uint64_t seed;
+    uint64_t row_offset;   // global index of this rank's first data row (batch_offset * k)
+    uint32_t step;
+    uint32_t stream;       // 0: first latent layer, 1: second
+};
+
+struct DenseArgs {
+    const uint16_t* X; int ldX;       // P-layout rows [M][ldX], ldX = 32*KT
+    const char* img;                  // MG-major A-image of the weight
+    const float* b0; int n0;          // bias of out-features [0, n0)
+    const float* b1; int n1; int split;   // bias of out-features [split, split+n1) (second head)
+    int M, KT, MG, mg_per_block;
+    int Np32;                         // out-features that are stored (multiple of 32)
+    uint16_t* YP; int ldYP;           // bf16 P-layout out
+    uint16_t* YT; int ldT;            // bf16 T-layout out [Np32][ldT] (optional)
+    float* YF; int ldYF;              // fp32 natural out
+    const uint16_t* ACT; int ldACT;   // EPI_DX: stored activation of the out-features (P-layout)
+    // EPI_BERN
+    const uint16_t* XB; int ldXB; int k; int B; int Xdim;
+    float* lpxz; float* logits_out;
+};
+
+struct OutBwdArgs {
+    const uint16_t* G2; int ldG;      // last hidden activation, P-layout [M][32*KT]
+    const char* img1;                 // MG-major image of W^T (out = pixels, k = hidden)
+    const char* img2;                 // K-major image of W   (out = hidden, k = pixels)
+    const float* bias; int Xdim; int Xp32;
+    const float* gx;                  // [M] dLoss/dlpxz
+    const uint16_t* XB; int ldXB; int k;
+    int M, KT, NG;
+    uint16_t* DLT; int ldT;           // dlogits, T-layout [Xp32][ldT]
+    uint16_t* DPP; uint16_t* DPT;     // dpre of the last hidden layer, P [M][32*KT] and T [32*KT][ldT]
+};
+
+struct WgradArgs {
+    const uint16_t* AT; int IT;       // layer input, T-layout [IT*16][Mp]
+    const uint16_t* GT; int JT;       // dpre of layer output, T-layout [JT*16][Mp]
+    int Mp, rows_per_split;
+    float* slabW;                     // [nsplit][IT*16][JT*16]
+    float* slabB;                     // [nsplit][JT*16]
+};
+
+struct SampleArgs {
+    const float* head; int ldH; int Dp; int D; int head_per_row;
+    int M, Mp, k, B;
+    EpsSrc eps;
+    uint16_t* ZP; uint16_t* ZT; int ldT;
+    float* lp_prior; float* lq; float* lq_dreg;
+};
+
+struct GaussLpArgs {
+    const float* zhead; int ldZH; int Dzp;   // head that generated z (per image)
+    const float* phead; int ldPH; int Dpp;   // head that scores z (per row)
+    int D, M, k;
+    EpsSrc eps;
+    float* out;
+};
+
+struct LseArgs {
+    const float* term[5]; float coef[5];
+    const float* lq_dreg;
+    int B, k; float beta; int objective;
+    float cz_on;                         // 1: prior term -z reaches dz (1-layer); 0: 2-layer (handled per row)
+    const float* head; int ldH, D, Dp;   // for KL (1-layer) or null
+    float* logw; float* wn; float* gx; float4* cf; float* per_b;
+};
+
+struct LatentBwdArgs {
+    const float* dz; int ldDZ;
+    const float* head; int ldH; int D, Dp;
+    const float4* cf;
+    EpsSrc eps;
+    int B, Bp, k;
+    float kmu, ksig;
+    uint16_t* DHP; uint16_t* DHT;     // dhead bf16: P [B][2Dp], T [2Dp][Bp]
+};
+
+struct GaussBwdArgs {
+    int mode;
+    const float* G;
+    const float* head; int ldH; int D, Dp;       // per-row head
+    const float* zhead; int ldZH; int Dzp;       // mode 0: head generating z1 (per image)
+    const float* dz_in; float* dz_direct; int ldDZ;
+    EpsSrc eps;
+    int M, Mp, k;
+    uint16_t* DHP; uint16_t* DHT; int ldT;
+};
+
+struct LayerDesc {
+    int Kin, Nout, joff;
+    size_t offW, offb;                // offsets into the flat parameter / gradient buffers
+    char* imgF; int KT_F;             // forward image (rows = out-features)
+    char* imgB; int KT_B; int MT_B; int imgB_kmajor;   // backward image (rows = in-features) or null
+    const float* slabW; const float* slabB; int nsplit; int slab_ld; size_t slab_stride;
+    int block_begin;                  // first block of this layer in the flat elementwise grids
+};
+
+void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
+void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
+void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st);
+void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st);
+void launch_sample(const SampleArgs& a, hipStream_t st);
+void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
+void launch_lse(const LseArgs& a, hipStream_t st);
+void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
+void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st);
+void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
+void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st);
+void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, hipStream_t st);
+void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
+                 float alpha, float gscale, float eps, int do_update, hipStream_t st);
+void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st);
+void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st);
+void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st);
+void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hipStream_t st);
+void launch_unpack_t(const uint16_t* T, int rows, int F, int ldT, float* out, hipStream_t st);
+void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st);
+
+}  // namespace iwae

@@ -1,0 +1,1009 @@
+// Hand-written gfx950 (CDNA4, MI355X) kernels for the IWAE train / eval step.
+// Layout rules: layout.h.  Kernel -> reference mapping (file:line in /root/reference):
+//   dense_kernel<EPI_TANH|EPI_HEAD>  BasicBlock.call          src/iwae1.py:36-44 (iwae2.py:37-45)
+//   sample_kernel                    qzx.sample + log-probs   src/iwae1.py:59, :107-109
+//   dense_kernel<EPI_BERN>           decoder out + Bernoulli  src/iwae1.py:74-75, :83, :111
+//   lse_kernel                       log_w, logmeanexp, eq14  src/iwae1.py:113-139, src/utils.py:6-8
+//   out_bwd_kernel / dense<EPI_DX> / wgrad_kernel / latent_bwd_kernel
+//                                    tape.gradient(loss, w)   src/iwae1.py:155-159
+//   adam_kernel                      Adam(eps=1e-4)           main.py:93, src/iwae1.py:160
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+#include "layout.h"
+
+namespace iwae {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LOG2PI_F 1.8378770664093453f
+
+// ---------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2_t v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;   // hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-safe)
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf_at(const uint4& u, int j) {
+    const uint32_t w = (j < 2) ? u.x : (j < 4) ? u.y : (j < 6) ? u.z : u.w;
+    return (j & 1) ? bfhi(w) : bflo(w);
+}
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7 (the result is rounded to bf16 anyway)
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * rcp_fast(e + 1.0f);
+}
+__device__ __forceinline__ float softplus_fast(float l) { return fmaxf(l, 0.0f) + __logf(1.0f + __expf(-fabsf(l))); }
+__device__ __forceinline__ float sigmoid_fast(float l) { return rcp_fast(1.0f + __expf(-l)); }
+
+// async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// stream `bytes` (multiple of 1 KiB) of an A-image into LDS with the whole workgroup
+template <int NWAVES>
+__device__ __forceinline__ void stage_image(const char* src, char* lds, int bytes, int wave, int lane) {
+    for (int off = wave * 1024; off < bytes; off += NWAVES * 1024) glds16(src + off + lane * 16, lds + off);
+}
+
+__device__ __forceinline__ float bias_at(const float* b0, int n0, const float* b1, int n1, int split, int f) {
+    if (f < split) return (f < n0) ? b0[f] : 0.0f;
+    const int f1 = f - split;
+    return (f1 < n1) ? b1[f1] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller.  counter = (row_lo, row_hi, (stream<<24)|d4, step), key = seed
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void normal4(uint64_t grow, uint32_t d4, uint32_t stream, uint32_t step, uint64_t seed, float n[4]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (stream << 24) | d4, step, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float s24 = 5.9604644775390625e-08f;   // 2^-24
+    const float u0 = ((float)(r[0] >> 8) + 0.5f) * s24, u1 = ((float)(r[1] >> 8) + 0.5f) * s24;
+    const float u2 = ((float)(r[2] >> 8) + 0.5f) * s24, u3 = ((float)(r[3] >> 8) + 0.5f) * s24;
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincosf(6.283185307179586f * u1, &sa, &ca);
+    sincosf(6.283185307179586f * u3, &sb, &cb);
+    n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+}
+// 4 consecutive eps values for features 4*d4 .. 4*d4+3 of data row (b,s)
+__device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int d4, int D, float n[4]) {
+    if (e.user) {
+        const float* p = e.user + ((size_t)s * e.B + b) * D + 4 * d4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n[i] = (4 * d4 + i < D) ? p[i] : 0.0f;
+    } else {
+        normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dense_kernel: Y^T[out][rows] = W^T-image x X^T, one wave = 32 data rows (2 column groups of
+// 16, rows interleaved r0+2*rho+g so a T-layout store packs two adjacent rows per lane).
+// Weights stream through LDS one 64-out-feature group (x <=8 k-steps) at a time, double
+// buffered with global_load_lds; the data operand lives in registers for K <= 256.
+// ---------------------------------------------------------------------------------
+#define DENSE_UNIT 32768
+
+template <int EPI>
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    int row[2];
+    bool valid[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; }
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    const int KT = a.KT;
+    const int nkw = (KT + 7) >> 3;
+    const int mg0 = blockIdx.y * a.mg_per_block;
+    const int mg1 = min(a.MG, mg0 + a.mg_per_block);
+    const int nunits = (mg1 - mg0) * nkw;
+
+    uint4 bfr[8][2];
+    auto load_b = [&](int kw) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kw * 8 + ks < KT && valid[g]) v = *(const uint4*)(a.X + (size_t)row[g] * a.ldX + (kw * 8 + ks) * 32 + q * 8);
+                bfr[ks][g] = v;
+            }
+        }
+    };
+    auto stage = [&](int unit, int buf) {
+        const int mg = mg0 + unit / nkw, kw = unit % nkw;
+        const int nks = min(8, KT - kw * 8);
+        stage_image<4>(a.img + ((size_t)(mg * KT + kw * 8)) * 4096, smem + buf * DENSE_UNIT, nks * 4096, wave, lane);
+    };
+
+    if (nunits > 0) stage(0, 0);
+    if (nkw == 1) load_b(0);
+
+    // EPI_BERN state
+    float rowacc[2] = {0.0f, 0.0f};
+    int bidx[2] = {0, 0}, sidx[2] = {0, 0};
+    if (EPI == EPI_BERN) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { bidx[g] = valid[g] ? row[g] / a.k : 0; sidx[g] = valid[g] ? row[g] - bidx[g] * a.k : 0; }
+    }
+
+    for (int mg = mg0; mg < mg1; ++mg) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+        for (int kw = 0; kw < nkw; ++kw) {
+            const int unit = (mg - mg0) * nkw + kw, buf = unit & 1;
+            if (nkw > 1) load_b(kw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (unit + 1 < nunits) stage(unit + 1, buf ^ 1);
+            const int nks = min(8, KT - kw * 8);
+            const char* lb = smem + buf * DENSE_UNIT + a_off;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks < nks) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4 av = *(const uint4*)(lb + (ks * 4 + t) * 1024);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                    }
+                }
+            }
+        }
+
+        // ---------------- epilogue for out-features 64*mg .. 64*mg+63 ----------------
+        if (EPI == EPI_TANH || EPI == EPI_DX) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int fbase = 64 * mg + 32 * p;
+                if (fbase < a.Np32) {
+                    float v[2][8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint4 act = make_uint4(0, 0, 0, 0);
+                        if (EPI == EPI_DX && valid[g]) act = *(const uint4*)(a.ACT + (size_t)row[g] * a.ldACT + fbase + 8 * q);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = acc[2 * p + (j >> 2)][g][j & 3];
+                            if (EPI == EPI_TANH) {
+                                const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
+                                v[g][j] = tanh_fast(x + bias_at(a.b0, a.n0, a.b1, a.n1, a.split, f));
+                            } else {
+                                const float y = bf_at(act, j);
+                                v[g][j] = x * (1.0f - y * y);
+                            }
+                        }
+                        if (valid[g])
+                            *(uint4*)(a.YP + (size_t)row[g] * a.ldYP + fbase + 8 * q) =
+                                make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
+                    }
+                    if (a.YT) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
+                            *(uint32_t*)(a.YT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
+                        }
+                    }
+                }
+            }
+        } else if (EPI == EPI_HEAD || EPI == EPI_F32 || EPI == EPI_SIGMOID) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f0 = 64 * mg + 16 * t + 4 * q;
+                if (f0 < a.ldYF) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        float op[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x = acc[t][g][i];
+                            if (EPI != EPI_F32) x += bias_at(a.b0, a.n0, a.b1, a.n1, a.split, f0 + i);
+                            if (EPI == EPI_HEAD && f0 + i >= a.split) x = __expf(x) + 1e-6f;   // iwae1.py:34,42
+                            if (EPI == EPI_SIGMOID) x = sigmoid_fast(x);
+                            op[i] = x;
+                        }
+                        if (valid[g]) *(float4*)(a.YF + (size_t)row[g] * a.ldYF + f0) = make_float4(op[0], op[1], op[2], op[3]);
+                    }
+                }
+            }
+        } else if (EPI == EPI_BERN) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int fbase = 64 * mg + 32 * p;
+                if (fbase < a.Xdim) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        uint4 xv = make_uint4(0, 0, 0, 0);
+                        if (valid[g]) xv = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
+                            if (f < a.Xdim) {
+                                const float l = acc[2 * p + (j >> 2)][g][j & 3] + a.b0[f];
+                                rowacc[g] += bf_at(xv, j) * l - softplus_fast(l);    // x*l - softplus(l), iwae1.py:111
+                                if (a.logits_out && valid[g]) a.logits_out[((size_t)sidx[g] * a.B + bidx[g]) * a.Xdim + f] = l;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI == EPI_BERN) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float v = rowacc[g];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0 && valid[g]) a.lpxz[row[g]] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// out_bwd_kernel: backward of the Bernoulli output layer for one block of rows, logits
+// recomputed on the fly (never stored): per 64-pixel group
+//   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also written T-layout for dV3)
+//   dg2 += dl V3^T   (the dl accumulator IS the B operand, no LDS round trip)
+// then dpre2 = dg2 * (1 - g2^2) written P- and T-layout.   (iwae1.py:74-75,111,159)
+// One wave per SIMD (4 waves, 32 rows each): 16x2 f32x4 accumulators for dg2 stay resident.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    const int KT = a.KT, MT2 = 2 * a.KT;
+    const int unit = KT * 8192;   // KT*4 KiB (W^T group) + 2*MT2 KiB (W k-group)
+    int row[2], bidx[2];
+    bool valid[2];
+    float gx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        row[g] = r0 + 2 * rho + g;
+        valid[g] = row[g] < a.M;
+        bidx[g] = valid[g] ? row[g] / a.k : 0;
+        gx[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+    }
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+
+    auto stage = [&](int ng, int buf) {
+        char* d = smem + buf * unit;
+        stage_image<4>(a.img1 + (size_t)ng * KT * 4096, d, KT * 4096, wave, lane);
+        stage_image<4>(a.img2 + (size_t)ng * 2 * MT2 * 1024, d + KT * 4096, 2 * MT2 * 1024, wave, lane);
+    };
+    stage(0, 0);
+
+    uint4 bfr[8][2];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ks < KT && valid[g]) v = *(const uint4*)(a.G2 + (size_t)row[g] * a.ldG + ks * 32 + q * 8);
+            bfr[ks][g] = v;
+        }
+
+    f32x4 acc2[16][2];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int ng = 0; ng < a.NG; ++ng) {
+        const int buf = ng & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ng + 1 < a.NG) stage(ng + 1, buf ^ 1);
+        const char* l1 = smem + buf * unit + a_off;
+        const char* l2 = l1 + KT * 4096;
+
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks < KT) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint4 av = *(const uint4*)(l1 + (ks * 4 + t) * 1024);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                }
+            }
+        }
+
+        uint4 bf2[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int fbase = 64 * ng + 32 * p;
+            float v[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint4 xv = make_uint4(0, 0, 0, 0);
+                if (valid[g] && fbase < a.Xp32) xv = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
+                    float d = 0.0f;
+                    if (f < a.Xdim) {
+                        const float l = acc[2 * p + (j >> 2)][g][j & 3] + a.bias[f];
+                        d = gx[g] * (bf_at(xv, j) - sigmoid_fast(l));
+                    }
+                    v[g][j] = d;
+                }
+                bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
+            }
+            if (fbase < a.Xp32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
+                    *(uint32_t*)(a.DLT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(v[0][j], v[1][j]);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int mt = 0; mt < 16; ++mt) {
+                if (mt < MT2) {
+                    const uint4 av = *(const uint4*)(l2 + (kk * MT2 + mt) * 1024);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc2[mt][g] = mfma16(av, bf2[kk][g], acc2[mt][g]);
+                }
+            }
+        }
+    }
+
+    // dpre2 = dg2 * (1 - g2^2); the g2 B-operand registers hold exactly the lane's own features
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks < KT) {
+            float v[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = bf_at(bfr[ks][g], j);
+                    v[g][j] = acc2[2 * ks + (j >> 2)][g][j & 3] * (1.0f - y * y);
+                }
+                if (valid[g])
+                    *(uint4*)(a.DPP + (size_t)row[g] * a.ldG + ks * 32 + 8 * q) =
+                        make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = ks * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
+                *(uint32_t*)(a.DPT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// wgrad_kernel: dW[i][j] (+db[j]) partial sums over a range of data rows.
+//   out[i][j] = sum_r AT[i][r] * GT[j][r]      (both operands T-layout, r contiguous)
+// grid = (j-blocks of 128, i-blocks of 256, row splits); 4 waves, each all <=16 i-tiles x 2
+// j-tiles.  The shared A operand goes through LDS in fragment order; each wave loads its own
+// G fragments straight from global.  Partials go to fp32 slabs (deterministic, no atomics).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [rs 4][it 16][1 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rho = lane & 15, q = lane >> 4;
+    const int it0 = blockIdx.y * 16;
+    const int nit = min(16, a.IT - it0);
+    const int jt0 = blockIdx.x * 8 + wave * 2;
+    const int split = blockIdx.z;
+    const int rbeg = split * a.rows_per_split;
+    const int rend = min(a.Mp, rbeg + a.rows_per_split);
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[t][jj] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum[2] = {0.0f, 0.0f};
+    bool jvalid[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) jvalid[jj] = (jt0 + jj) < a.JT;
+
+    for (int r = rbeg; r < rend; r += 128) {
+        __syncthreads();
+        // stage A: chunk c = ((it*16 + i)*4 + rs)*4 + qq ; 256 B contiguous per (it,i)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = u * 256 + tid;
+            const int qq = c & 3, rs = (c >> 2) & 3, i = (c >> 4) & 15, it = c >> 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (it < nit) v = *(const uint4*)(a.AT + (size_t)((it0 + it) * 16 + i) * a.Mp + r + rs * 32 + qq * 8);
+            *(uint4*)(smem + (rs * 16 + it) * 1024 + i * 64 + ((qq ^ hperm(i >> 2)) * 16)) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs) {
+            uint4 gf[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                gf[jj] = make_uint4(0, 0, 0, 0);
+                if (jvalid[jj]) gf[jj] = *(const uint4*)(a.GT + (size_t)((jt0 + jj) * 16 + rho) * a.Mp + r + rs * 32 + q * 8);
+                bsum[jj] += bflo(gf[jj].x) + bfhi(gf[jj].x) + bflo(gf[jj].y) + bfhi(gf[jj].y) + bflo(gf[jj].z) + bfhi(gf[jj].z) + bflo(gf[jj].w) + bfhi(gf[jj].w);
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                if (it < nit) {
+                    const uint4 av = *(const uint4*)(smem + (rs * 16 + it) * 1024 + a_off);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acc[it][jj] = mfma16(av, gf[jj], acc[it][jj]);
+                }
+            }
+        }
+    }
+
+    // D: lane(col j = rho, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
+    float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        if (it < nit) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                if (jvalid[jj]) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + (jt0 + jj) * 16 + rho] = acc[it][jj][ii];
+                }
+            }
+        }
+    }
+    if (blockIdx.y == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            float v = bsum[jj];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0 && jvalid[jj]) a.slabB[(size_t)split * a.JT * 16 + (jt0 + jj) * 16 + rho] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// elementwise / reduction kernels
+// ---------------------------------------------------------------------------------
+// x fp32 [B][X] -> bf16 P-layout [B][Xp] and T-layout [Xp][Bp] (pads written as zero)
+__global__ void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = idx % Xp, b = idx / Xp;
+    if (b >= Bp) return;
+    const float v = (b < B && f < X) ? x[(size_t)b * X + f] : 0.0f;
+    const uint16_t h = (uint16_t)(pack2(v, 0.0f) & 0xffffu);
+    if (b < B) XP[(size_t)b * Xp + p_pos(f)] = h;
+    if (XT) XT[(size_t)f * Bp + b] = h;
+}
+
+// thread per data row: z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T)
+__global__ void sample_kernel(SampleArgs a) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.Mp) return;
+    const bool valid = row < a.M;
+    const int b = valid ? row / a.k : 0, s = valid ? row - b * a.k : 0;
+    const float* hd = a.head + (size_t)(a.head_per_row ? (valid ? row : 0) : b) * a.ldH;
+    float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
+    for (int c = 0; c < a.Dp / 8; ++c) {
+        const int t = c >> 2, qq = c & 3;
+        float z8[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f0 = 32 * t + 16 * h + 4 * qq;
+            float e[4];
+            eps4(a.eps, b, s, row, f0 >> 2, a.D, e);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i;
+                float z = 0.0f;
+                if (valid && f < a.D) {
+                    const float mu = hd[f], sg = hd[a.Dp + f];
+                    z = mu + sg * e[i];                                  // iwae1.py:59
+                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
+                    const float u = (z - mu) / sg;
+                    lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
+                    if (a.lq_dreg) {                                     // tasks/task02.py:63-65
+                        const float s2 = sg + 1e-6f, u2 = (z - mu) / s2;
+                        lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
+                    }
+                }
+                z8[4 * h + i] = z;
+                if (a.ZT) a.ZT[(size_t)f * a.ldT + row] = (uint16_t)(pack2(z, 0.0f) & 0xffffu);
+            }
+        }
+        if (valid)
+            *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * c) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+    }
+    if (valid) {
+        if (a.lp_prior) a.lp_prior[row] = lp;
+        a.lq[row] = lq;
+        if (a.lq_dreg) a.lq_dreg[row] = lq2;
+    }
+}
+
+// thread per data row: sum_d log N(z1; mup[row], sigp[row]) with z1 recomputed from the encoder head
+// and eps (iwae2.py:122); also the per-row gradients wrt the dec2 head when G != null is done in
+// gauss_bwd_kernel.
+__global__ void gauss_lp_kernel(GaussLpArgs a) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.M) return;
+    const int b = row / a.k, s = row - b * a.k;
+    const float* hz = a.zhead + (size_t)b * a.ldZH;         // generating head (per image)
+    const float* hp = a.phead + (size_t)row * a.ldPH;        // evaluating head (per row)
+    float lp = 0.0f;
+    for (int d4 = 0; d4 < (a.D + 3) / 4; ++d4) {
+        float e[4];
+        eps4(a.eps, b, s, row, d4, a.D, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = 4 * d4 + i;
+            if (f < a.D) {
+                const float z = hz[f] + hz[a.Dzp + f] * e[i];
+                const float u = (z - hp[f]) / hp[a.Dpp + f];
+                lp += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(hp[a.Dpp + f]);
+            }
+        }
+    }
+    a.out[row] = lp;
+}
+
+// one wave per image b: log_w over k, logmeanexp / softmax / objective gradients (iwae1.py:113-139)
+__global__ void lse_kernel(LseArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const int k = a.k;
+    float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
+    for (int s = lane; s < k; s += 64) {
+        const int r = b * k + s;
+        float lw = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+            if (a.term[t]) lw += a.coef[t] * a.term[t][r];
+        a.logw[r] = lw;
+        m = fmaxf(m, lw);
+        sum_lw += lw;
+        sum_px += a.term[0][r];
+        if (a.term[1]) sum_t1 += a.term[1][r];
+        if (a.term[2]) sum_t2 += a.term[2][r];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, o));
+        sum_lw += __shfl_xor(sum_lw, o);
+        sum_px += __shfl_xor(sum_px, o);
+        sum_t1 += __shfl_xor(sum_t1, o);
+        sum_t2 += __shfl_xor(sum_t2, o);
+    }
+    float se = 0.0f;
+    for (int s = lane; s < k; s += 64) se += __expf(a.logw[b * k + s] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    const float inv_se = 1.0f / se;
+    const float invB = 1.0f / (float)a.B, invkB = invB / (float)k;
+    float eq14 = 0.0f, dreg = 0.0f;
+    for (int s = lane; s < k; s += 64) {
+        const int r = b * k + s;
+        const float lw = a.logw[r];
+        const float wn = __expf(lw - m) * inv_se;       // iwae1.py:128-131 == softmax over k (:137)
+        eq14 += wn * lw;
+        a.wn[r] = wn;
+        float G;                                         // dLoss/dlog_w, loss = -objective (iwae1.py:157)
+        float4 cf = make_float4(1.0f, 0.0f, 0.0f, 0.0f); // (ca, cz, cq, cs) for latent_bwd_kernel
+        if (a.objective == OBJ_VAE_ELBO) {
+            G = -invkB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
+        } else if (a.objective == OBJ_VAE_ELBO_KL) {
+            G = -invkB;
+        } else if (a.objective == OBJ_DREG) {            // tasks/task02.py:61-76,95-96
+            G = -wn * invB;
+            const float c2 = wn * wn * invB;
+            cf.x = wn; cf.y = c2; cf.z = -c2;
+        } else {                                         // iwae_elbo, iwae_eq14 (same gradient)
+            G = -wn * invB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
+        }
+        if (a.lq_dreg) dreg += wn * wn * (a.term[1][r] + a.term[0][r] - a.lq_dreg[r]);   // tasks/task02.py:70-73
+        a.gx[r] = G;
+        a.cf[r] = cf;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { eq14 += __shfl_xor(eq14, o); dreg += __shfl_xor(dreg, o); }
+    // KL(q(z|x) || N(0,1)) per image (iwae1.py:116), TFP closed form
+    float kl = 0.0f;
+    if (a.head) {
+        for (int f = lane; f < a.D; f += 64) {
+            const float mu = a.head[(size_t)b * a.ldH + f], sg = a.head[(size_t)b * a.ldH + a.Dp + f];
+            const float ls = __logf(sg);
+            kl += 0.5f * mu * mu + 0.5f * expm1f(2.0f * ls) - ls;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o);
+    }
+    if (lane == 0) {
+        float* pb = a.per_b;
+        const int B = a.B;
+        pb[PB_LME * B + b] = m + __logf(se / (float)k);          // utils.py:6-8
+        pb[PB_MEAN * B + b] = sum_lw / (float)k;
+        pb[PB_EQ14 * B + b] = eq14;
+        pb[PB_KL * B + b] = kl;
+        pb[PB_PX * B + b] = sum_px / (float)k;
+        pb[PB_T1 * B + b] = sum_t1 / (float)k;
+        pb[PB_T2 * B + b] = sum_t2 / (float)k;
+        pb[PB_DREG * B + b] = dreg;
+    }
+}
+
+// single block: means over the batch -> scalars[16]
+__global__ void scalars_kernel(const float* per_b, int B, float beta, float* out) {
+    __shared__ float red[PB_COUNT][4];
+    float acc[PB_COUNT];
+#pragma unroll
+    for (int t = 0; t < PB_COUNT; ++t) acc[t] = 0.0f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x)
+#pragma unroll
+        for (int t = 0; t < PB_COUNT; ++t) acc[t] += per_b[t * B + b];
+#pragma unroll
+    for (int t = 0; t < PB_COUNT; ++t) {
+        float v = acc[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[t][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s[PB_COUNT];
+        for (int t = 0; t < PB_COUNT; ++t) s[t] = (red[t][0] + red[t][1] + red[t][2] + red[t][3]) / (float)B;
+        out[SC_IWAE_ELBO] = s[PB_LME];
+        out[SC_VAE_ELBO] = s[PB_MEAN];
+        out[SC_IWAE_EQ14] = s[PB_EQ14];
+        out[SC_VAE_ELBO_KL] = s[PB_PX] - beta * s[PB_KL];      // iwae1.py:121
+        out[SC_MEAN_LPXZ] = s[PB_PX];
+        out[SC_MEAN_T1] = s[PB_T1];
+        out[SC_MEAN_T2] = s[PB_T2];
+        out[SC_INFERENCE_LOSS] = -s[PB_DREG];                  // tasks/task02.py:76
+        out[SC_KL] = s[PB_KL];
+    }
+}
+
+// per image b and 4 features: reduce the sample axis:
+//   dz_tot = ca*dz_dec + cz*z + cq*(z-mu)/(sigma+1e-6)^2
+//   dmu = sum_s dz_tot + kmu*mu ; dsigma = sum_s (dz_tot*eps + cs/sigma) + ksig*(sigma - 1/sigma)
+//   da = dsigma * exp(a) = dsigma * (sigma - 1e-6)
+__global__ void latent_bwd_kernel(LatentBwdArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf4 = a.Dp / 4;
+    const int b = idx / nf4, f4 = idx % nf4;
+    if (b >= a.Bp) return;
+    const int f0 = 4 * f4;
+    float dmu[4] = {0, 0, 0, 0}, dsg[4] = {0, 0, 0, 0};
+    if (b < a.B && f0 < a.D) {
+        float mu[4], sg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = f0 + i < a.D;
+            mu[i] = ok ? a.head[(size_t)b * a.ldH + f0 + i] : 0.0f;
+            sg[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
+        }
+        for (int s = 0; s < a.k; ++s) {
+            const int row = b * a.k + s;
+            const float4 dz = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
+            const float4 cf = a.cf[row];
+            float e[4];
+            eps4(a.eps, b, s, row, f4, a.D, e);
+            const float dzv[4] = {dz.x, dz.y, dz.z, dz.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (f0 + i < a.D) {
+                    const float z = mu[i] + sg[i] * e[i];
+                    const float s2 = sg[i] + 1e-6f;
+                    const float t = cf.x * dzv[i] + cf.y * z + cf.z * (z - mu[i]) / (s2 * s2);
+                    dmu[i] += t;
+                    dsg[i] += t * e[i] + cf.w / sg[i];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (f0 + i < a.D) {
+                dmu[i] += a.kmu * mu[i];
+                dsg[i] += a.ksig * (sg[i] - 1.0f / sg[i]);
+                dsg[i] *= (sg[i] - 1e-6f);
+            } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+        }
+    }
+    if (b < a.B) {
+        *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
+        *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a.DHT[(size_t)(f0 + i) * a.Bp + b] = (uint16_t)(pack2(dmu[i], 0.0f) & 0xffffu);
+        a.DHT[(size_t)(a.Dp + f0 + i) * a.Bp + b] = (uint16_t)(pack2(dsg[i], 0.0f) & 0xffffu);
+    }
+}
+
+// per data row and 4 features, 2-layer model: everything that touches a per-row
+// Gaussian head.  mode 0 (dec2 head, after lpz1z2):   u=(z1-mup)/sigp
+//     dhead = G*[ u/sigp | (u^2-1)/sigp * exp(ap) ],  dz1_direct = G*(-u/sigp)   -> DZACC (fp32, =)
+// mode 1 (enc2 head, after dec2 backward gave dz2_dec):
+//     dz2 = dz2_dec - G*z2 ; dhead = [ dz2 | (dz2*eps2 + G/sig2) * exp(a2) ]
+__global__ void gauss_bwd_kernel(GaussBwdArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nf4 = a.Dp / 4;
+    const int row = idx / nf4, f4 = idx % nf4;
+    if (row >= a.Mp) return;
+    const bool valid = row < a.M;
+    const int f0 = 4 * f4;
+    float dm[4] = {0, 0, 0, 0}, ds[4] = {0, 0, 0, 0}, dzd[4] = {0, 0, 0, 0};
+    if (valid && f0 < a.D) {
+        const int b = row / a.k, s = row - b * a.k;
+        const float G = a.G[row];
+        const float* hp = a.head + (size_t)row * a.ldH;
+        float e[4];
+        eps4(a.eps, b, s, row, f4, a.D, e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + i;
+            if (f < a.D) {
+                const float mu = hp[f], sg = hp[a.Dp + f];
+                if (a.mode == 0) {
+                    const float* hz = a.zhead + (size_t)b * a.ldZH;
+                    const float z = hz[f] + hz[a.Dzp + f] * e[i];
+                    const float u = (z - mu) / sg;
+                    dm[i] = G * u / sg;
+                    ds[i] = G * (u * u - 1.0f) / sg * (sg - 1e-6f);
+                    dzd[i] = -G * u / sg;
+                } else {
+                    const float z = mu + sg * e[i];
+                    const float d = a.dz_in[(size_t)row * a.ldDZ + f] - G * z;
+                    dm[i] = d;
+                    ds[i] = (d * e[i] + G / sg) * (sg - 1e-6f);
+                }
+            }
+        }
+    }
+    if (valid) {
+        *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dm[0], dm[1]), pack2(dm[2], dm[3]));
+        *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
+        if (a.mode == 0) *(float4*)(a.dz_direct + (size_t)row * a.ldDZ + f0) = make_float4(dzd[0], dzd[1], dzd[2], dzd[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a.DHT[(size_t)(f0 + i) * a.ldT + row] = (uint16_t)(pack2(dm[i], 0.0f) & 0xffffu);
+        a.DHT[(size_t)(a.Dp + f0 + i) * a.ldT + row] = (uint16_t)(pack2(ds[i], 0.0f) & 0xffffu);
+    }
+}
+
+// out[row][f] = sum of up to 3 fp32 [M][ld] arrays (dz1 contributions of the 2-layer model)
+__global__ void add3_kernel(float* out, const float* a0, const float* a1, const float* a2, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = a0[i];
+    if (a1) v += a1[i];
+    if (a2) v += a2[i];
+    out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------
+// gradient slab reduce and Adam (+ bf16 A-image refresh)
+// ---------------------------------------------------------------------------------
+__global__ void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad) {
+    int l = 0;
+    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].block_begin) ++l;
+    const LayerDesc L = layers[l];
+    const int e = ((int)blockIdx.x - L.block_begin) * blockDim.x + threadIdx.x;
+    const int nW = L.Kin * L.Nout;
+    if (e >= nW + L.Nout) return;
+    float s = 0.0f;
+    if (e < nW) {
+        const int i = e / L.Nout, j = e % L.Nout;
+        const size_t off = (size_t)i * L.slab_ld + L.joff + j;
+        for (int sp = 0; sp < L.nsplit; ++sp) s += L.slabW[(size_t)sp * L.slab_stride + off];
+        grad[L.offW + e] = s;
+    } else {
+        const int j = e - nW;
+        for (int sp = 0; sp < L.nsplit; ++sp) s += L.slabB[(size_t)sp * L.slab_ld + L.joff + j];
+        grad[L.offb + j] = s;
+    }
+}
+
+// Keras Adam (main.py:93): theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps), eps = 1e-4;
+// then refresh the bf16 A-images the GEMM kernels stream (forward W^T and backward W).
+__global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, const float* grad, float* mom, float* vel,
+                            float alpha, float gscale, float beta1, float beta2, float eps, int do_update) {
+    int l = 0;
+    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].block_begin) ++l;
+    const LayerDesc L = layers[l];
+    const int e = ((int)blockIdx.x - L.block_begin) * blockDim.x + threadIdx.x;
+    const int nW = L.Kin * L.Nout;
+    if (e >= nW + L.Nout) return;
+    const size_t idx = (e < nW) ? (L.offW + e) : (L.offb + (e - nW));
+    float w = param[idx];
+    if (do_update) {
+        const float g = grad[idx] * gscale;
+        const float m = beta1 * mom[idx] + (1.0f - beta1) * g;
+        const float v = beta2 * vel[idx] + (1.0f - beta2) * g * g;
+        mom[idx] = m;
+        vel[idx] = v;
+        w -= alpha * m / (sqrtf(v) + eps);
+        param[idx] = w;
+    }
+    if (e < nW) {
+        const int i = e / L.Nout, j = e % L.Nout;
+        const uint16_t h = (uint16_t)(pack2(w, 0.0f) & 0xffffu);
+        *(uint16_t*)(L.imgF + img_mg_byte(L.joff + j, i, L.KT_F)) = h;
+        if (L.imgB) {
+            if (L.imgB_kmajor) *(uint16_t*)(L.imgB + img_k_byte(i, L.joff + j, L.MT_B)) = h;
+            else *(uint16_t*)(L.imgB + img_mg_byte(i, L.joff + j, L.KT_B)) = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// exports in the reference's [k, B, ...] order (iwae1.py:141-151), debug dumps
+// ---------------------------------------------------------------------------------
+__global__ void export_rows_kernel(const float* in, int B, int k, float* out) {   // [B*k] row order -> [k][B]
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B * k) return;
+    const int b = r / k, s = r - b * k;
+    out[(size_t)s * B + b] = in[r];
+}
+__global__ void export_z_kernel(SampleArgs a, float* zout, const float* wn, float* snis) {
+    // thread per (row, d4): z[k][B][D]; snis_z via atomics-free second kernel below
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nd4 = (a.D + 3) / 4;
+    const int row = idx / nd4, d4 = idx % nd4;
+    if (row >= a.M) return;
+    const int b = row / a.k, s = row - b * a.k;
+    const float* hd = a.head + (size_t)(a.head_per_row ? row : b) * a.ldH;
+    float e[4];
+    eps4(a.eps, b, s, row, d4, a.D, e);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = 4 * d4 + i;
+        if (f < a.D) zout[((size_t)s * a.B + b) * a.D + f] = hd[f] + hd[a.Dp + f] * e[i];
+    }
+}
+__global__ void snis_kernel(const float* z, const float* wn, int B, int k, int D, float* out) {   // iwae1.py:139
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, d = idx % D;
+    float s = 0.0f;
+    for (int i = 0; i < k; ++i) s += wn[b * k + i] * z[((size_t)i * B + b) * D + d];
+    out[idx] = s;
+}
+__global__ void unpack_p_kernel(const uint16_t* P, int rows, int F, int Fp, float* out) {   // P-layout bf16 -> [rows][F] fp32
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * F) return;
+    const int r = idx / F, f = idx % F;
+    out[idx] = __uint_as_float((uint32_t)P[(size_t)r * Fp + p_pos(f)] << 16);
+}
+__global__ void unpack_t_kernel(const uint16_t* T, int rows, int F, int ldT, float* out) {   // T-layout bf16 -> [rows][F] fp32
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * F) return;
+    const int r = idx / F, f = idx % F;
+    out[idx] = __uint_as_float((uint32_t)T[(size_t)f * ldT + r] << 16);
+}
+__global__ void eps_dump_kernel(EpsSrc e, int B, int k, int D, float* out) {   // [k][B][D]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nd4 = (D + 3) / 4;
+    const int row = idx / nd4, d4 = idx % nd4;
+    if (row >= B * k) return;
+    const int b = row / k, s = row - b * k;
+    float n[4];
+    eps4(e, b, s, row, d4, D, n);
+    for (int i = 0; i < 4; ++i)
+        if (4 * d4 + i < D) out[((size_t)s * B + b) * D + 4 * d4 + i] = n[i];
+}
+
+// ---------------------------------------------------------------------------------
+// launch wrappers (plain C++ callers in model.cpp)
+// ---------------------------------------------------------------------------------
+static inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
+    dim3 grid((a.M + 127) / 128, (a.MG + a.mg_per_block - 1) / a.mg_per_block);
+    const size_t lds = 2 * DENSE_UNIT;
+    switch (epi) {
+        case EPI_TANH: hipLaunchKernelGGL(dense_kernel<EPI_TANH>, grid, dim3(256), lds, st, a); break;
+        case EPI_HEAD: hipLaunchKernelGGL(dense_kernel<EPI_HEAD>, grid, dim3(256), lds, st, a); break;
+        case EPI_DX: hipLaunchKernelGGL(dense_kernel<EPI_DX>, grid, dim3(256), lds, st, a); break;
+        case EPI_F32: hipLaunchKernelGGL(dense_kernel<EPI_F32>, grid, dim3(256), lds, st, a); break;
+        case EPI_BERN: hipLaunchKernelGGL(dense_kernel<EPI_BERN>, grid, dim3(256), lds, st, a); break;
+        case EPI_SIGMOID: hipLaunchKernelGGL(dense_kernel<EPI_SIGMOID>, grid, dim3(256), lds, st, a); break;
+    }
+}
+void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)a.KT * 8192;
+    hipLaunchKernelGGL(out_bwd_kernel, dim3((a.M + 127) / 128), dim3(256), lds, st, a);
+}
+void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
+    dim3 grid((a.JT + 7) / 8, (a.IT + 15) / 16, nsplit);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 65536, st, a);
+}
+void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
+    hipLaunchKernelGGL(prep_rows_kernel, grid1((size_t)Bp * Xp, 256), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
+}
+void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, grid1(a.Mp, 128), dim3(128), 0, st, a); }
+void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }
+void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
+void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
+}
+void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(latent_bwd_kernel, grid1((size_t)a.Bp * (a.Dp / 4), 64), dim3(64), 0, st, a);
+}
+void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
+}
+void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add3_kernel, grid1(n, 256), dim3(256), 0, st, out, a0, a1, a2, n);
+}
+void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, grad);
+}
+void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
+                 float alpha, float gscale, float eps, int do_update, hipStream_t st) {
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, alpha, gscale, 0.9f, 0.999f, eps, do_update);
+}
+void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(export_rows_kernel, grid1((size_t)B * k, 256), dim3(256), 0, st, in, B, k, out);
+}
+void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st) {
+    hipLaunchKernelGGL(export_z_kernel, grid1((size_t)a.M * ((a.D + 3) / 4), 256), dim3(256), 0, st, a, zout, (const float*)nullptr, (float*)nullptr);
+}
+void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(snis_kernel, grid1((size_t)B * D, 256), dim3(256), 0, st, z, wn, B, k, D, out);
+}
+void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_p_kernel, grid1((size_t)rows * F, 256), dim3(256), 0, st, P, rows, F, Fp, out);
+}
+void launch_unpack_t(const uint16_t* T, int rows, int F, int ldT, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(unpack_t_kernel, grid1((size_t)rows * F, 256), dim3(256), 0, st, T, rows, F, ldT, out);
+}
+void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(eps_dump_kernel, grid1((size_t)B * k * ((D + 3) / 4), 256), dim3(256), 0, st, e, B, k, D, out);
+}
+
+}  // namespace iwae

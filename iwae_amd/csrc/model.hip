@@ -1,0 +1,1009 @@
+// Host side of libiwae_amd.so: device memory, launch sequencing and the C ABI of include/iwae_amd.h.
+// Step structure follows the reference's train_step (src/iwae1.py:153-162): forward (IWAE.call,
+// :98-151), backward (closed form of tape.gradient), Adam (main.py:93).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <random>
+#include "../../include/iwae_amd.h"
+#include "kernels.h"
+#include "layout.h"
+
+using namespace iwae;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? IWAE_ERR_NOMEM : IWAE_ERR_HIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+#define CHK(expr)            \
+    do {                     \
+        int rc_ = (expr);    \
+        if (rc_ != IWAE_OK) return rc_; \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct KerasLayer {
+    std::string name;
+    int Kin, Nout;
+    size_t offW, offb;
+};
+
+// one GEMM-able linear map; the mu|sigma head merges two Keras layers into one (joff = 0 / Dp)
+struct Linear {
+    int Kin = 0, Nspace = 0;          // in-features, out-feature space (heads: 2*Dp)
+    int Kp32 = 0, Np32 = 0, KT = 0, MG = 0;
+    int nsub = 0, sub[2] = {0, 0}, joff[2] = {0, 0};
+    char* imgF = nullptr; size_t imgF_bytes = 0;
+    char* imgB = nullptr; size_t imgB_bytes = 0; int KT_B = 0, MG_B = 0, MT_B = 0, kmajor = 0;
+    DevBuf slabW, slabB;
+    int IT = 0, JT = 0, nsplit = 1;
+};
+
+struct BlockWs {   // activations / gradients of one BasicBlock applied to R rows
+    DevBuf h1P, h1T, h2P, h2T, head, dheadP, dheadT, d2P, d2T, d1P, d1T, dx;
+};
+struct MlpWs {     // decode_z_to_x applied to M rows
+    DevBuf g1P, g1T, g2P, g2T, dlT, d2P, d2T, d1P, d1T, dz;
+};
+
+}  // namespace
+
+struct iwae_model {
+    iwae_config cfg;
+    int X, Xp32;
+    int H[2], D[2], Hp[2], Dp[2];
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<KerasLayer> klayers;
+    size_t nparam = 0;
+    // Linear maps.  1-layer: enc{l1,l2,head}, dec{d1,d2,out}.  2-layer adds enc2, dec2 blocks.
+    Linear enc1[3], enc2[3], dec2[3], dec1[3];
+    float *param = nullptr, *grad = nullptr, *mom = nullptr, *vel = nullptr;
+    int64_t adam_t = 0;
+    uint32_t noise_step = 0, batch_offset = 0;
+    // layer descriptor table
+    std::vector<LayerDesc> descs;
+    LayerDesc* d_descs = nullptr;
+    int elem_blocks = 0;
+    bool descs_dirty = true;
+    // per-call state
+    int B = 0, k = 0, M = 0, Mp = 0, Bp = 0;
+    float beta = 1.0f;
+    bool have_forward = false, user_eps = false;
+    DevBuf xin, xP, xT, epsbuf, zP[2], zT[2];
+    DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
+    DevBuf logw, wn, gx, cf, per_b, dzsum, dzdir;
+    BlockWs wenc1, wenc2, wdec2;
+    MlpWs wdec1;
+    DevBuf scratch;            // exports
+    float* d_scalars = nullptr;
+    float* h_scalars = nullptr;   // pinned
+};
+
+namespace {
+
+int ensure(DevBuf& b, size_t bytes, hipStream_t st) {
+    if (bytes <= b.cap) return IWAE_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return IWAE_OK;
+}
+template <class T>
+T* ptr(const DevBuf& b) { return (T*)b.p; }
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+void init_linear(Linear& L, int Kin, int Nspace, bool need_B, bool kmajor) {
+    L.Kin = Kin;
+    L.Nspace = Nspace;
+    L.Kp32 = round_up(Kin, 32);
+    L.Np32 = round_up(Nspace, 32);
+    L.KT = L.Kp32 / 32;
+    L.MG = (L.Np32 + 63) / 64;
+    L.imgF_bytes = (size_t)L.MG * L.KT * 4096;
+    L.kmajor = kmajor ? 1 : 0;
+    if (need_B) {
+        if (kmajor) {
+            L.MT_B = L.Kp32 / 16;                      // rows = in-features (hidden)
+            L.imgB_bytes = (size_t)L.MG * 2 * L.MT_B * 1024;   // one k-group per 64 out-features
+        } else {
+            L.KT_B = L.Np32 / 32;
+            L.MG_B = (L.Kp32 + 63) / 64;
+            L.imgB_bytes = (size_t)L.MG_B * L.KT_B * 4096;
+        }
+    }
+    L.IT = L.Kp32 / 16;
+    L.JT = L.Np32 / 16;
+}
+
+int alloc_linear(Linear& L) {
+    HIPCHK(hipMalloc((void**)&L.imgF, L.imgF_bytes));
+    HIPCHK(hipMemset(L.imgF, 0, L.imgF_bytes));
+    if (L.imgB_bytes) {
+        HIPCHK(hipMalloc((void**)&L.imgB, L.imgB_bytes));
+        HIPCHK(hipMemset(L.imgB, 0, L.imgB_bytes));
+    }
+    return IWAE_OK;
+}
+
+void free_linear(Linear& L) {
+    if (L.imgF) (void)hipFree(L.imgF);
+    if (L.imgB) (void)hipFree(L.imgB);
+    free_buf(L.slabW);
+    free_buf(L.slabB);
+}
+
+// Keras creation order: a BasicBlock is l1, l2, lmu, lstd
+void add_block(iwae_model* m, Linear* blk, const char* prefix, int Kin, int H, int D, bool need_dx_first) {
+    const int base = (int)m->klayers.size();
+    const char* nm[4] = {"l1", "l2", "lmu", "lstd"};
+    const int kin[4] = {Kin, H, H, H}, nout[4] = {H, H, D, D};
+    for (int i = 0; i < 4; ++i) {
+        KerasLayer kl;
+        kl.name = std::string(prefix) + "." + nm[i];
+        kl.Kin = kin[i];
+        kl.Nout = nout[i];
+        kl.offW = m->nparam;
+        m->nparam += (size_t)kin[i] * nout[i];
+        kl.offb = m->nparam;
+        m->nparam += nout[i];
+        m->klayers.push_back(kl);
+    }
+    const int Dp = round_up(D, 32);
+    init_linear(blk[0], Kin, H, need_dx_first, false);
+    blk[0].nsub = 1; blk[0].sub[0] = base;
+    init_linear(blk[1], H, H, true, false);
+    blk[1].nsub = 1; blk[1].sub[0] = base + 1;
+    init_linear(blk[2], H, 2 * Dp, true, false);
+    blk[2].nsub = 2; blk[2].sub[0] = base + 2; blk[2].sub[1] = base + 3; blk[2].joff[1] = Dp;
+}
+
+void add_mlp3(iwae_model* m, Linear* mlp, const char* prefix, int D, int H, int X) {
+    const int base = (int)m->klayers.size();
+    const char* nm[3] = {"d1", "d2", "out"};
+    const int kin[3] = {D, H, H}, nout[3] = {H, H, X};
+    for (int i = 0; i < 3; ++i) {
+        KerasLayer kl;
+        kl.name = std::string(prefix) + "." + nm[i];
+        kl.Kin = kin[i];
+        kl.Nout = nout[i];
+        kl.offW = m->nparam;
+        m->nparam += (size_t)kin[i] * nout[i];
+        kl.offb = m->nparam;
+        m->nparam += nout[i];
+        m->klayers.push_back(kl);
+    }
+    init_linear(mlp[0], D, H, true, false);
+    mlp[0].nsub = 1; mlp[0].sub[0] = base;
+    init_linear(mlp[1], H, H, true, false);
+    mlp[1].nsub = 1; mlp[1].sub[0] = base + 1;
+    init_linear(mlp[2], H, X, true, true);
+    mlp[2].nsub = 1; mlp[2].sub[0] = base + 2;
+}
+
+std::vector<Linear*> all_linears(iwae_model* m) {
+    std::vector<Linear*> v;
+    for (int i = 0; i < 3; ++i) v.push_back(&m->enc1[i]);
+    if (m->cfg.n_layers == 2) {
+        for (int i = 0; i < 3; ++i) v.push_back(&m->enc2[i]);
+        for (int i = 0; i < 3; ++i) v.push_back(&m->dec2[i]);
+    }
+    for (int i = 0; i < 3; ++i) v.push_back(&m->dec1[i]);
+    return v;
+}
+
+int build_descs(iwae_model* m) {
+    m->descs.assign(m->klayers.size(), LayerDesc());
+    for (Linear* L : all_linears(m)) {
+        for (int s = 0; s < L->nsub; ++s) {
+            const KerasLayer& kl = m->klayers[L->sub[s]];
+            LayerDesc& d = m->descs[L->sub[s]];
+            d.Kin = kl.Kin; d.Nout = kl.Nout; d.joff = L->joff[s];
+            d.offW = kl.offW; d.offb = kl.offb;
+            d.imgF = L->imgF; d.KT_F = L->KT;
+            d.imgB = L->imgB; d.KT_B = L->KT_B; d.MT_B = L->MT_B; d.imgB_kmajor = L->kmajor;
+            d.slabW = ptr<float>(L->slabW); d.slabB = ptr<float>(L->slabB);
+            d.nsplit = L->nsplit; d.slab_ld = L->JT * 16; d.slab_stride = (size_t)L->IT * 16 * L->JT * 16;
+        }
+    }
+    int blocks = 0;
+    for (auto& d : m->descs) {
+        d.block_begin = blocks;
+        blocks += (d.Kin * d.Nout + d.Nout + 255) / 256;
+    }
+    m->elem_blocks = blocks;
+    if (!m->d_descs) HIPCHK(hipMalloc((void**)&m->d_descs, sizeof(LayerDesc) * m->descs.size()));
+    HIPCHK(hipMemcpyAsync(m->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->descs_dirty = false;
+    return IWAE_OK;
+}
+
+int refresh_images(iwae_model* m) {   // rebuild bf16 A-images from the fp32 master weights
+    if (m->descs_dirty) CHK(build_descs(m));
+    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, 0.f, 1.f, 1e-4f, 0, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+EpsSrc eps_src(iwae_model* m, int layer) {
+    EpsSrc e;
+    e.user = nullptr;
+    if (m->user_eps) e.user = ptr<float>(m->epsbuf) + (layer == 0 ? 0 : (size_t)m->k * m->B * m->D[0]);
+    e.B = m->B;
+    e.seed = m->cfg.seed;
+    e.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k;
+    e.step = m->noise_step;
+    e.stream = (uint32_t)layer;
+    return e;
+}
+
+// ---------------------------------------------------------------- forward pieces
+int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, int rowsP, uint16_t* YP, uint16_t* YT, float* YF, int ldYF) {
+    DenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
+    const KerasLayer& k0 = m->klayers[L.sub[0]];
+    a.b0 = m->param + k0.offb; a.n0 = k0.Nout; a.split = 1 << 30;
+    if (L.nsub == 2) {
+        const KerasLayer& k1 = m->klayers[L.sub[1]];
+        a.b1 = m->param + k1.offb; a.n1 = k1.Nout; a.split = L.joff[1];
+    }
+    a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
+    a.YP = YP; a.ldYP = L.Np32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = ldYF;
+    launch_dense(epi, a, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+int block_alloc(iwae_model* m, Linear* blk, BlockWs& w, int R, int Rp, bool bwd, bool need_dx) {
+    const int Hp = blk[0].Np32, N2 = blk[2].Np32;
+    CHK(ensure(w.h1P, (size_t)Rp * Hp * 2, m->stream));
+    CHK(ensure(w.h1T, (size_t)Rp * Hp * 2, m->stream));
+    CHK(ensure(w.h2P, (size_t)Rp * Hp * 2, m->stream));
+    CHK(ensure(w.h2T, (size_t)Rp * Hp * 2, m->stream));
+    CHK(ensure(w.head, (size_t)Rp * N2 * 4, m->stream));
+    if (bwd) {
+        CHK(ensure(w.dheadP, (size_t)Rp * N2 * 2, m->stream));
+        CHK(ensure(w.dheadT, (size_t)Rp * N2 * 2, m->stream));
+        CHK(ensure(w.d2P, (size_t)Rp * Hp * 2, m->stream));
+        CHK(ensure(w.d2T, (size_t)Rp * Hp * 2, m->stream));
+        CHK(ensure(w.d1P, (size_t)Rp * Hp * 2, m->stream));
+        CHK(ensure(w.d1T, (size_t)Rp * Hp * 2, m->stream));
+        if (need_dx) CHK(ensure(w.dx, (size_t)Rp * blk[0].Kp32 * 4, m->stream));
+    }
+    (void)R;
+    return IWAE_OK;
+}
+
+int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R, int Rp) {
+    CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.h1T), nullptr, 0));
+    CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h2T), nullptr, 0));
+    CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, Rp, nullptr, nullptr, ptr<float>(w.head), blk[2].Np32));
+    return IWAE_OK;
+}
+
+// ---------------------------------------------------------------- backward pieces
+int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp) {
+    const int chunks = Rp / 128;
+    const int blocks = ((L.JT + 7) / 8) * ((L.IT + 15) / 16);
+    int nsplit = std::max(1, std::min(chunks, 768 / std::max(1, blocks)));
+    const int cps = (chunks + nsplit - 1) / nsplit;
+    nsplit = (chunks + cps - 1) / cps;
+    const size_t needW = (size_t)nsplit * L.IT * 16 * L.JT * 16 * 4, needB = (size_t)nsplit * L.JT * 16 * 4;
+    void* oldW = L.slabW.p; void* oldB = L.slabB.p;
+    CHK(ensure(L.slabW, needW, m->stream));
+    CHK(ensure(L.slabB, needB, m->stream));
+    if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
+    WgradArgs a;
+    a.AT = AT; a.IT = L.IT; a.GT = GT; a.JT = L.JT; a.Mp = Rp; a.rows_per_split = cps * 128;
+    a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB);
+    launch_wgrad(a, nsplit, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+// dX (times tanh' of the stored activation, or raw fp32) of a layer: X = dpre of the layer's outputs
+int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, int rowsP, const uint16_t* ACT, uint16_t* YP, uint16_t* YT, float* YF) {
+    DenseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = GP; a.ldX = L.Np32; a.img = L.imgB;
+    a.split = 1 << 30;
+    a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = L.MG_B; a.Np32 = L.Kp32;
+    a.YP = YP; a.ldYP = L.Kp32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = L.Kp32;
+    a.ACT = ACT; a.ldACT = L.Kp32;
+    launch_dense(ACT ? EPI_DX : EPI_F32, a, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inT, int R, int Rp, bool need_dx) {
+    CHK(wgrad(m, blk[2], ptr<uint16_t>(w.h2T), ptr<uint16_t>(w.dheadT), Rp));
+    CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d2T), nullptr));
+    CHK(wgrad(m, blk[1], ptr<uint16_t>(w.h1T), ptr<uint16_t>(w.d2T), Rp));
+    CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
+    CHK(wgrad(m, blk[0], inT, ptr<uint16_t>(w.d1T), Rp));
+    if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, Rp, nullptr, nullptr, nullptr, ptr<float>(w.dx)));
+    return IWAE_OK;
+}
+
+int copy_in(iwae_model* m, DevBuf& dst, const void* src, size_t bytes) {
+    CHK(ensure(dst, bytes, m->stream));
+    HIPCHK(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyDefault, m->stream));
+    return IWAE_OK;
+}
+
+int copy_out(iwae_model* m, void* dst, const void* src, size_t bytes) {
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, m->stream));
+    return IWAE_OK;
+}
+
+// ---------------------------------------------------------------- the forward pass
+int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd,
+                 const iwae_tensors* want) {
+    if (!x || B <= 0 || k <= 0) return fail(IWAE_ERR_ARG, "forward: need x, B > 0, k > 0");
+    if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
+    const bool two = m->cfg.n_layers == 2;
+    m->B = B; m->k = k; m->M = B * k; m->beta = beta;
+    m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
+    const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
+    hipStream_t st = m->stream;
+    m->user_eps = eps != nullptr;
+    if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
+    CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
+    CHK(ensure(m->xP, (size_t)Bp * Xp * 2, st));
+    CHK(ensure(m->xT, (size_t)Bp * Xp * 2, st));
+    launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), st);
+
+    // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
+    CHK(block_alloc(m, m->enc1, m->wenc1, B, Bp, bwd, false));
+    CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, Bp));
+
+    for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
+    float* lpxz = ptr<float>(m->rows[0]);
+    float* t1 = ptr<float>(m->rows[1]);   // 1-layer lpz   | 2-layer lpz1z2
+    float* t2 = ptr<float>(m->rows[2]);   // 1-layer lqzx  | 2-layer lpz2
+    float* t3 = ptr<float>(m->rows[3]);   //               | 2-layer lqz1x
+    float* t4 = ptr<float>(m->rows[4]);   //               | 2-layer lqz2z1
+    float* lqd = ptr<float>(m->rows[5]);
+
+    // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
+    CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
+    CHK(ensure(m->zT[0], (size_t)Mp * m->Dp[0] * 2, st));
+    {
+        SampleArgs s;
+        memset(&s, 0, sizeof(s));
+        s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
+        s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
+        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = ptr<uint16_t>(m->zT[0]); s.ldT = Mp;
+        s.lp_prior = two ? nullptr : t1;
+        s.lq = two ? t3 : t2;
+        s.lq_dreg = two ? nullptr : lqd;   // tasks/task02.py:63-65 (cheap; always available)
+        launch_sample(s, st);
+    }
+    if (two) {
+        // ---- q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
+        CHK(block_alloc(m, m->enc2, m->wenc2, M, Mp, bwd, true));
+        CHK(block_fwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, Mp));
+        CHK(ensure(m->zP[1], (size_t)Mp * m->Dp[1] * 2, st));
+        CHK(ensure(m->zT[1], (size_t)Mp * m->Dp[1] * 2, st));
+        SampleArgs s;
+        memset(&s, 0, sizeof(s));
+        s.head = ptr<float>(m->wenc2.head); s.ldH = 2 * m->Dp[1]; s.Dp = m->Dp[1]; s.D = m->D[1]; s.head_per_row = 1;
+        s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 1);
+        s.ZP = ptr<uint16_t>(m->zP[1]); s.ZT = ptr<uint16_t>(m->zT[1]); s.ldT = Mp;
+        s.lp_prior = t2; s.lq = t4; s.lq_dreg = nullptr;
+        launch_sample(s, st);
+        CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
+        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, Mp));
+        GaussLpArgs g;
+        memset(&g, 0, sizeof(g));
+        g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
+        g.phead = ptr<float>(m->wdec2.head); g.ldPH = 2 * m->Dp[0]; g.Dpp = m->Dp[0];
+        g.D = m->D[0]; g.M = M; g.k = k; g.eps = eps_src(m, 0); g.out = t1;
+        launch_gauss_lp(g, st);
+    }
+
+    // ---- decoder + Bernoulli log-likelihood (iwae1.py:81-83,111)
+    MlpWs& w = m->wdec1;
+    const int Hp = m->dec1[0].Np32;
+    CHK(ensure(w.g1P, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.g1T, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.g2P, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.g2T, (size_t)Mp * Hp * 2, st));
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, Mp, ptr<uint16_t>(w.g1P), bwd ? ptr<uint16_t>(w.g1T) : nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, Mp, ptr<uint16_t>(w.g2P), bwd ? ptr<uint16_t>(w.g2T) : nullptr, nullptr, 0));
+    {
+        Linear& L = m->dec1[2];
+        DenseArgs a;
+        memset(&a, 0, sizeof(a));
+        a.X = ptr<uint16_t>(w.g2P); a.ldX = L.Kp32; a.img = L.imgF;
+        a.b0 = m->param + m->klayers[L.sub[0]].offb; a.n0 = X; a.split = 1 << 30;
+        a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
+        a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
+        a.lpxz = lpxz;
+        a.logits_out = nullptr;
+        if (want && want->logits) {
+            CHK(ensure(m->scratch, (size_t)M * X * 4, st));
+            a.logits_out = ptr<float>(m->scratch);
+        }
+        launch_dense(EPI_BERN, a, st);
+        HIPCHK(hipGetLastError());
+        if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
+    }
+
+    // ---- log_w, log-mean-exp over k, objectives (iwae1.py:113-139)
+    CHK(ensure(m->logw, (size_t)Mp * 4, st));
+    CHK(ensure(m->wn, (size_t)Mp * 4, st));
+    CHK(ensure(m->gx, (size_t)Mp * 4, st));
+    CHK(ensure(m->cf, (size_t)Mp * 16, st));
+    CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
+    {
+        LseArgs a;
+        memset(&a, 0, sizeof(a));
+        if (!two) {
+            a.term[0] = lpxz; a.coef[0] = 1.f;
+            a.term[1] = t1; a.coef[1] = beta;
+            a.term[2] = t2; a.coef[2] = -beta;
+            a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
+            a.cz_on = 1.f;
+        } else {
+            a.term[0] = lpxz; a.coef[0] = 1.f;    // iwae2.py:128 (beta unused there)
+            a.term[1] = t1; a.coef[1] = 1.f;
+            a.term[2] = t2; a.coef[2] = 1.f;
+            a.term[3] = t3; a.coef[3] = -1.f;
+            a.term[4] = t4; a.coef[4] = -1.f;
+            a.head = nullptr;
+            a.cz_on = 0.f;
+        }
+        a.lq_dreg = two ? nullptr : lqd;
+        a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
+        a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
+        a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
+        launch_lse(a, st);
+        launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
+    }
+    HIPCHK(hipGetLastError());
+    m->have_forward = true;
+    return IWAE_OK;
+}
+
+// ---------------------------------------------------------------- the backward pass
+int backward_impl(iwae_model* m, int objective) {
+    if (!m->have_forward) return fail(IWAE_ERR_STATE, "backward without forward");
+    const bool two = m->cfg.n_layers == 2;
+    const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
+    hipStream_t st = m->stream;
+    MlpWs& w = m->wdec1;
+    const int Hp = m->dec1[0].Np32;
+    CHK(ensure(w.dlT, (size_t)Mp * Xp * 2, st));
+    CHK(ensure(w.d2P, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.d2T, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.d1T, (size_t)Mp * Hp * 2, st));
+    CHK(ensure(w.dz, (size_t)Mp * m->Dp[0] * 4, st));
+    {
+        Linear& L = m->dec1[2];
+        OutBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.G2 = ptr<uint16_t>(w.g2P); a.ldG = L.Kp32; a.img1 = L.imgF; a.img2 = L.imgB;
+        a.bias = m->param + m->klayers[L.sub[0]].offb; a.Xdim = X; a.Xp32 = Xp;
+        a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
+        a.M = M; a.KT = L.KT; a.NG = L.MG;
+        a.DLT = ptr<uint16_t>(w.dlT); a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = ptr<uint16_t>(w.d2T);
+        launch_out_bwd(a, st);
+        HIPCHK(hipGetLastError());
+    }
+    CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp));
+    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
+    CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp));
+    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, Mp, nullptr, nullptr, nullptr, ptr<float>(w.dz)));
+    CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp));
+
+    const float* dz1 = ptr<float>(w.dz);
+    if (two) {
+        // ---- p(z1|z2) head, dec2, q(z2|z1) head, enc2
+        CHK(ensure(m->dzdir, (size_t)Mp * m->Dp[0] * 4, st));
+        CHK(ensure(m->dzsum, (size_t)Mp * m->Dp[0] * 4, st));
+        GaussBwdArgs g;
+        memset(&g, 0, sizeof(g));
+        g.mode = 0; g.G = ptr<float>(m->gx);
+        g.head = ptr<float>(m->wdec2.head); g.ldH = 2 * m->Dp[0]; g.D = m->D[0]; g.Dp = m->Dp[0];
+        g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
+        g.dz_direct = ptr<float>(m->dzdir); g.ldDZ = m->Dp[0];
+        g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
+        g.DHP = ptr<uint16_t>(m->wdec2.dheadP); g.DHT = ptr<uint16_t>(m->wdec2.dheadT); g.ldT = Mp;
+        launch_gauss_bwd(g, st);
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zT[1]), M, Mp, true));
+        memset(&g, 0, sizeof(g));
+        g.mode = 1; g.G = ptr<float>(m->gx);
+        g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
+        g.dz_in = ptr<float>(m->wdec2.dx); g.ldDZ = m->Dp[1];
+        g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
+        g.DHP = ptr<uint16_t>(m->wenc2.dheadP); g.DHT = ptr<uint16_t>(m->wenc2.dheadT); g.ldT = Mp;
+        launch_gauss_bwd(g, st);
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zT[0]), M, Mp, true));
+        launch_add3(ptr<float>(m->dzsum), ptr<float>(w.dz), ptr<float>(m->dzdir), ptr<float>(m->wenc2.dx), (size_t)M * m->Dp[0], st);
+        dz1 = ptr<float>(m->dzsum);
+    }
+    {
+        LatentBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dz = dz1; a.ldDZ = m->Dp[0];
+        a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
+        a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
+        a.B = B; a.Bp = Bp; a.k = k;
+        a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
+        a.DHP = ptr<uint16_t>(m->wenc1.dheadP); a.DHT = ptr<uint16_t>(m->wenc1.dheadT);
+        launch_latent_bwd(a, st);
+    }
+    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), B, Bp, false));
+    if (m->descs_dirty) CHK(build_descs(m));
+    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->grad, st);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+int fetch_outputs(iwae_model* m, iwae_scalars* scalars, const iwae_tensors* want) {
+    hipStream_t st = m->stream;
+    const int B = m->B, k = m->k, M = m->M;
+    const bool two = m->cfg.n_layers == 2;
+    if (want) {
+        const float* rowsrc[6] = {ptr<float>(m->rows[0]), ptr<float>(m->rows[1]), ptr<float>(m->rows[2]),
+                                  ptr<float>(m->rows[3]), ptr<float>(m->rows[4]), ptr<float>(m->logw)};
+        float* dsts[7];
+        const float* srcs[7];
+        int n = 0;
+        if (want->lpxz) { dsts[n] = want->lpxz; srcs[n++] = rowsrc[0]; }
+        if (want->lpz) { dsts[n] = want->lpz; srcs[n++] = rowsrc[1]; }
+        if (want->lqzx) { dsts[n] = want->lqzx; srcs[n++] = two ? rowsrc[3] : rowsrc[2]; }
+        if (want->lpz2 && two) { dsts[n] = want->lpz2; srcs[n++] = rowsrc[2]; }
+        if (want->lqzx2 && two) { dsts[n] = want->lqzx2; srcs[n++] = rowsrc[4]; }
+        if (want->log_w) { dsts[n] = want->log_w; srcs[n++] = rowsrc[5]; }
+        if (want->al) { dsts[n] = want->al; srcs[n++] = ptr<float>(m->wn); }
+        const size_t zmax = (size_t)M * std::max(m->D[0], two ? m->D[1] : 0);
+        CHK(ensure(m->scratch, std::max((size_t)M * 4, zmax * 4 + (size_t)B * 256 * 4), st));
+        for (int i = 0; i < n; ++i) {
+            launch_export_rows(srcs[i], B, k, ptr<float>(m->scratch), st);
+            CHK(copy_out(m, dsts[i], m->scratch.p, (size_t)M * 4));
+        }
+        for (int layer = 0; layer < (two ? 2 : 1); ++layer) {
+            float* zdst = layer == 0 ? want->z : want->z2;
+            float* sdst = layer == 0 ? want->snis_z : want->snis_z2;
+            if (!zdst && !sdst) continue;
+            SampleArgs s;
+            memset(&s, 0, sizeof(s));
+            BlockWs& hw = layer == 0 ? m->wenc1 : m->wenc2;
+            s.head = ptr<float>(hw.head); s.ldH = 2 * m->Dp[layer]; s.Dp = m->Dp[layer]; s.D = m->D[layer];
+            s.head_per_row = layer; s.M = M; s.Mp = m->Mp; s.k = k; s.B = B; s.eps = eps_src(m, layer);
+            float* zdev = ptr<float>(m->scratch);
+            launch_export_z(s, zdev, st);
+            if (zdst) CHK(copy_out(m, zdst, zdev, (size_t)M * m->D[layer] * 4));
+            if (sdst) {
+                float* sdev = zdev + zmax;
+                launch_snis(zdev, ptr<float>(m->wn), B, k, m->D[layer], sdev, st);
+                CHK(copy_out(m, sdst, sdev, (size_t)B * m->D[layer] * 4));
+            }
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (scalars) {
+        HIPCHK(hipMemcpyAsync(m->h_scalars, m->d_scalars, SC_COUNT * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const float* s = m->h_scalars;
+        memset(scalars, 0, sizeof(*scalars));
+        scalars->vae_elbo = s[SC_VAE_ELBO];
+        scalars->vae_elbo_kl = s[SC_VAE_ELBO_KL];
+        scalars->iwae_elbo = s[SC_IWAE_ELBO];
+        scalars->iwae_eq14 = s[SC_IWAE_EQ14];
+        scalars->inference_loss = s[SC_INFERENCE_LOSS];
+        scalars->mean_lpxz = s[SC_MEAN_LPXZ];
+        scalars->mean_lpz = s[SC_MEAN_T1];
+        scalars->mean_lqzx = s[SC_MEAN_T2];
+        scalars->mean_kl = s[SC_KL];
+    } else if (want) {
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return IWAE_OK;
+}
+
+int check_objective(iwae_model* m, int objective) {
+    if (objective < 0 || objective > 4) return fail(IWAE_ERR_ARG, "unknown objective");
+    if (m->cfg.n_layers == 2 && (objective == OBJ_VAE_ELBO_KL || objective == OBJ_DREG))
+        return fail(IWAE_ERR_ARG, "objective not defined for the 2-layer model (KeyError in src/iwae2.py:154-173)");
+    return IWAE_OK;
+}
+
+int adam_impl(iwae_model* m, float lr, float gscale) {
+    if (m->descs_dirty) CHK(build_descs(m));
+    m->adam_t += 1;
+    const double t = (double)m->adam_t;
+    const float alpha = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gscale, 1e-4f, 1, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+const char* iwae_last_error(void) { return g_err.c_str(); }
+int iwae_version(void) { return 1; }
+
+int iwae_create(const iwae_config* cfg, iwae_handle* out) {
+    if (!cfg || !out) return fail(IWAE_ERR_ARG, "iwae_create: null argument");
+    if (cfg->n_layers != 1 && cfg->n_layers != 2) return fail(IWAE_ERR_ARG, "n_layers must be 1 or 2 (main.py:17)");
+    for (int i = 0; i < cfg->n_layers; ++i) {
+        if (cfg->n_hidden[i] < 1 || cfg->n_hidden[i] > 256) return fail(IWAE_ERR_ARG, "n_hidden must be in [1,256]");
+        if (cfg->n_latent[i] < 1 || cfg->n_latent[i] > 128) return fail(IWAE_ERR_ARG, "n_latent must be in [1,128]");
+    }
+    if (cfg->x_dim < 1 || cfg->x_dim > 4096) return fail(IWAE_ERR_ARG, "x_dim must be in [1,4096]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(IWAE_ERR_HIP, "no HIP device: the IWAE hot path needs an AMD GPU (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(cfg->device));
+    iwae_model* m = new iwae_model();
+    m->cfg = *cfg;
+    m->X = cfg->x_dim;
+    m->Xp32 = round_up(cfg->x_dim, 32);
+    for (int i = 0; i < 2; ++i) {
+        m->H[i] = cfg->n_hidden[i]; m->D[i] = cfg->n_latent[i];
+        m->Hp[i] = round_up(std::max(1, m->H[i]), 32); m->Dp[i] = round_up(std::max(1, m->D[i]), 32);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    m->own_stream = true;
+    if (cfg->n_layers == 1) {
+        add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
+        add_mlp3(m, m->dec1, "dec", m->D[0], m->H[0], m->X);
+    } else {
+        add_block(m, m->enc1, "enc1", m->X, m->H[0], m->D[0], false);
+        add_block(m, m->enc2, "enc2", m->D[0], m->H[1], m->D[1], true);
+        add_block(m, m->dec2, "dec2", m->D[1], m->H[1], m->D[0], true);
+        add_mlp3(m, m->dec1, "dec1", m->D[0], m->H[0], m->X);
+    }
+    for (Linear* L : all_linears(m)) {
+        int rc = alloc_linear(*L);
+        if (rc != IWAE_OK) { iwae_destroy(m); return rc; }
+    }
+    const size_t nb = m->nparam * 4;
+    HIPCHK(hipMalloc((void**)&m->param, nb));
+    HIPCHK(hipMalloc((void**)&m->grad, nb));
+    HIPCHK(hipMalloc((void**)&m->mom, nb));
+    HIPCHK(hipMalloc((void**)&m->vel, nb));
+    HIPCHK(hipMemset(m->grad, 0, nb));
+    HIPCHK(hipMemset(m->mom, 0, nb));
+    HIPCHK(hipMemset(m->vel, 0, nb));
+    HIPCHK(hipMalloc((void**)&m->d_scalars, SC_COUNT * 4));
+    HIPCHK(hipMemset(m->d_scalars, 0, SC_COUNT * 4));
+    HIPCHK(hipHostMalloc((void**)&m->h_scalars, SC_COUNT * 4));
+    // Keras Dense defaults: glorot-uniform kernels, zero biases (src/iwae1.py:31-34,72-75)
+    std::vector<float> init(m->nparam, 0.f);
+    std::mt19937_64 rng(cfg->seed ^ 0x9E3779B97F4A7C15ull);
+    for (const KerasLayer& kl : m->klayers) {
+        const double lim = sqrt(6.0 / (double)(kl.Kin + kl.Nout));
+        std::uniform_real_distribution<double> U(-lim, lim);
+        for (size_t i = 0; i < (size_t)kl.Kin * kl.Nout; ++i) init[kl.offW + i] = (float)U(rng);
+    }
+    HIPCHK(hipMemcpy(m->param, init.data(), nb, hipMemcpyHostToDevice));
+    int rc = refresh_images(m);
+    if (rc != IWAE_OK) { iwae_destroy(m); return rc; }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    *out = m;
+    return IWAE_OK;
+}
+
+void iwae_destroy(iwae_handle m) {
+    if (!m) return;
+    (void)hipSetDevice(m->cfg.device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (Linear* L : all_linears(m)) free_linear(*L);
+    DevBuf* bufs[] = {&m->xin, &m->xP, &m->xT, &m->epsbuf, &m->zP[0], &m->zP[1], &m->zT[0], &m->zT[1], &m->rows[0], &m->rows[1],
+                      &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->dzsum,
+                      &m->dzdir, &m->scratch};
+    for (DevBuf* b : bufs) free_buf(*b);
+    BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
+    for (BlockWs* w : bw) {
+        DevBuf* bb[] = {&w->h1P, &w->h1T, &w->h2P, &w->h2T, &w->head, &w->dheadP, &w->dheadT, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dx};
+        for (DevBuf* b : bb) free_buf(*b);
+    }
+    {
+        MlpWs* w = &m->wdec1;
+        DevBuf* bb[] = {&w->g1P, &w->g1T, &w->g2P, &w->g2T, &w->dlT, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dz};
+        for (DevBuf* b : bb) free_buf(*b);
+    }
+    if (m->param) (void)hipFree(m->param);
+    if (m->grad) (void)hipFree(m->grad);
+    if (m->mom) (void)hipFree(m->mom);
+    if (m->vel) (void)hipFree(m->vel);
+    if (m->d_descs) (void)hipFree(m->d_descs);
+    if (m->d_scalars) (void)hipFree(m->d_scalars);
+    if (m->h_scalars) (void)hipHostFree(m->h_scalars);
+    if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int iwae_set_stream(iwae_handle m, void* s) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->own_stream) { HIPCHK(hipStreamDestroy(m->stream)); m->own_stream = false; }
+    if (s) {
+        m->stream = (hipStream_t)s;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        m->own_stream = true;
+    }
+    return IWAE_OK;
+}
+
+int iwae_sync(iwae_handle m) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+
+int iwae_param_count(iwae_handle m, size_t* n) {
+    if (!m || !n) return fail(IWAE_ERR_ARG, "null argument");
+    *n = m->nparam;
+    return IWAE_OK;
+}
+int iwae_num_tensors(iwae_handle m, int32_t* n) {
+    if (!m || !n) return fail(IWAE_ERR_ARG, "null argument");
+    *n = (int32_t)m->klayers.size() * 2;
+    return IWAE_OK;
+}
+int iwae_tensor_info(iwae_handle m, int32_t idx, char* name, size_t cap, int32_t* rows, int32_t* cols, size_t* offset) {
+    if (!m || idx < 0 || idx >= (int32_t)m->klayers.size() * 2) return fail(IWAE_ERR_ARG, "tensor index out of range");
+    const KerasLayer& kl = m->klayers[idx / 2];
+    const bool bias = idx & 1;
+    if (name && cap) snprintf(name, cap, "%s/%s", kl.name.c_str(), bias ? "bias" : "kernel");
+    if (rows) *rows = bias ? kl.Nout : kl.Kin;
+    if (cols) *cols = bias ? 1 : kl.Nout;
+    if (offset) *offset = bias ? kl.offb : kl.offW;
+    return IWAE_OK;
+}
+
+int iwae_set_params(iwae_handle m, const float* flat, size_t n) {
+    if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "set_params: size mismatch");
+    HIPCHK(hipMemcpyAsync(m->param, flat, n * 4, hipMemcpyDefault, m->stream));
+    CHK(refresh_images(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+int iwae_get_params(iwae_handle m, float* flat, size_t n) {
+    if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "get_params: size mismatch");
+    HIPCHK(hipMemcpyAsync(flat, m->param, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+int iwae_set_output_bias(iwae_handle m, const float* bias, size_t n) {
+    if (!m || !bias || n != (size_t)m->X) return fail(IWAE_ERR_ARG, "set_output_bias: need x_dim values");
+    HIPCHK(hipMemcpyAsync(m->param + m->klayers.back().offb, bias, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+int iwae_get_grads(iwae_handle m, float* flat, size_t n) {
+    if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "get_grads: size mismatch");
+    HIPCHK(hipMemcpyAsync(flat, m->grad, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+int iwae_get_adam_state(iwae_handle m, float* mo, float* ve, size_t n, int64_t* step) {
+    if (!m || n != m->nparam) return fail(IWAE_ERR_ARG, "get_adam_state: size mismatch");
+    if (mo) HIPCHK(hipMemcpyAsync(mo, m->mom, n * 4, hipMemcpyDefault, m->stream));
+    if (ve) HIPCHK(hipMemcpyAsync(ve, m->vel, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (step) *step = m->adam_t;
+    return IWAE_OK;
+}
+int iwae_set_adam_state(iwae_handle m, const float* mo, const float* ve, size_t n, int64_t step) {
+    if (!m || !mo || !ve || n != m->nparam || step < 0) return fail(IWAE_ERR_ARG, "set_adam_state: bad argument");
+    HIPCHK(hipMemcpyAsync(m->mom, mo, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipMemcpyAsync(m->vel, ve, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->adam_t = step;
+    return IWAE_OK;
+}
+
+int iwae_forward(iwae_handle m, const float* x, int32_t B, int32_t k, float beta, const float* eps, iwae_scalars* scalars,
+                 const iwae_tensors* want) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(forward_impl(m, x, B, k, beta, eps, OBJ_IWAE_ELBO, false, want));
+    CHK(fetch_outputs(m, scalars, want));
+    m->noise_step += 1;
+    return IWAE_OK;
+}
+
+int iwae_forward_backward(iwae_handle m, const float* x, int32_t B, int32_t k, float beta, int32_t objective, const float* eps,
+                          iwae_scalars* scalars, const iwae_tensors* want) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(check_objective(m, objective));
+    CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
+    CHK(backward_impl(m, objective));
+    CHK(fetch_outputs(m, scalars, want));
+    m->noise_step += 1;
+    return IWAE_OK;
+}
+
+int iwae_grad_devptr(iwae_handle m, void** p, size_t* n) {
+    if (!m || !p || !n) return fail(IWAE_ERR_ARG, "null argument");
+    *p = m->grad;
+    *n = m->nparam;
+    return IWAE_OK;
+}
+
+int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    return adam_impl(m, lr, grad_scale);
+}
+
+int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float beta, float lr, int32_t objective, const float* eps,
+                    iwae_scalars* scalars, const iwae_tensors* want) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(check_objective(m, objective));
+    CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
+    CHK(backward_impl(m, objective));
+    CHK(fetch_outputs(m, nullptr, want));   // tensors refer to the pre-update forward (src/iwae1.py:162)
+    CHK(adam_impl(m, lr, 1.0f));
+    CHK(fetch_outputs(m, scalars, nullptr));
+    m->noise_step += 1;
+    return IWAE_OK;
+}
+
+int iwae_set_step(iwae_handle m, uint32_t noise_step, uint32_t batch_offset) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    m->noise_step = noise_step;
+    m->batch_offset = batch_offset;
+    return IWAE_OK;
+}
+
+int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* per_image) {
+    if (!m || !x || N <= 0 || k <= 0 || !llh) return fail(IWAE_ERR_ARG, "eval_llh: bad argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    if (chunk <= 0) chunk = std::max(1, (int)(((int64_t)1 << 19) / k));
+    chunk = std::min(chunk, N);
+    std::vector<float> lme(chunk);
+    double total = 0.0;
+    const uint32_t saved_off = m->batch_offset;
+    for (int i0 = 0; i0 < N; i0 += chunk) {
+        const int nb = std::min(chunk, N - i0);
+        m->batch_offset = saved_off + (uint32_t)i0;
+        CHK(forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr));
+        HIPCHK(hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        for (int i = 0; i < nb; ++i) {
+            total += (double)lme[i];       // MyMetric: sum / count (src/utils.py:39-41)
+            if (per_image) per_image[i0 + i] = lme[i];
+        }
+    }
+    m->batch_offset = saved_off;
+    m->noise_step += 1;
+    *llh = total / (double)N;
+    return IWAE_OK;
+}
+
+int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
+    if (!m || !z || !probs || n <= 0) return fail(IWAE_ERR_ARG, "decode: bad argument");
+    if (m->cfg.n_layers != 1) return fail(IWAE_ERR_ARG, "decode: 1-layer model only (use the Python shim's sample for 2 layers)");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    hipStream_t st = m->stream;
+    const int np = round_up(n, 128), D = m->D[0], Dp = m->Dp[0], Hp = m->dec1[0].Np32, Xp = m->Xp32;
+    MlpWs& w = m->wdec1;
+    CHK(copy_in(m, m->xin, z, (size_t)n * D * 4));
+    CHK(ensure(m->zP[0], (size_t)np * Dp * 2, st));
+    CHK(ensure(w.g1P, (size_t)np * Hp * 2, st));
+    CHK(ensure(w.g2P, (size_t)np * Hp * 2, st));
+    CHK(ensure(m->scratch, (size_t)np * Xp * 4, st));
+    launch_prep_rows(ptr<float>(m->xin), n, D, Dp, np, ptr<uint16_t>(m->zP[0]), nullptr, st);
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, np, ptr<uint16_t>(w.g1P), nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, np, ptr<uint16_t>(w.g2P), nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[2], EPI_SIGMOID, ptr<uint16_t>(w.g2P), n, np, nullptr, nullptr, ptr<float>(m->scratch), Xp));
+    HIPCHK(hipMemcpy2DAsync(probs, (size_t)m->X * 4, m->scratch.p, (size_t)Xp * 4, (size_t)m->X * 4, n, hipMemcpyDefault, st));
+    HIPCHK(hipStreamSynchronize(st));
+    m->have_forward = false;
+    return IWAE_OK;
+}
+
+int iwae_debug_eps(iwae_handle m, int32_t B, int32_t k, int32_t layer, float* out) {
+    if (!m || !out || B <= 0 || k <= 0 || layer < 0 || layer >= m->cfg.n_layers) return fail(IWAE_ERR_ARG, "debug_eps: bad argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    const int D = m->D[layer];
+    CHK(ensure(m->scratch, (size_t)B * k * D * 4, m->stream));
+    EpsSrc e;
+    e.user = nullptr; e.B = B; e.seed = m->cfg.seed; e.row_offset = (uint64_t)m->batch_offset * k; e.step = m->noise_step; e.stream = layer;
+    launch_eps_dump(e, B, k, D, ptr<float>(m->scratch), m->stream);
+    HIPCHK(hipMemcpyAsync(out, m->scratch.p, (size_t)B * k * D * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return IWAE_OK;
+}
+
+int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, int32_t* rows, int32_t* cols) {
+    if (!m || !name) return fail(IWAE_ERR_ARG, "debug_tensor: null argument");
+    if (!m->have_forward) return fail(IWAE_ERR_STATE, "debug_tensor: no forward pass yet");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    struct Ent { const char* nm; int kind; const DevBuf* buf; int R; int F; int Fp; int ld; };   // kind 0 P, 1 T, 2 fp32
+    const int B = m->B, M = m->M, Mp = m->Mp, Bp = m->Bp;
+    const int H0 = m->H[0], Hp0 = m->Hp[0], D0 = m->D[0], Dp0 = m->Dp[0];
+    std::vector<Ent> ents = {
+        {"x", 0, &m->xP, B, m->X, m->Xp32, 0}, {"xT", 1, &m->xT, B, m->X, m->Xp32, Bp},
+        {"enc.h1", 0, &m->wenc1.h1P, B, H0, Hp0, 0}, {"enc.h1T", 1, &m->wenc1.h1T, B, H0, Hp0, Bp},
+        {"enc.h2", 0, &m->wenc1.h2P, B, H0, Hp0, 0}, {"enc.h2T", 1, &m->wenc1.h2T, B, H0, Hp0, Bp},
+        {"enc.head", 2, &m->wenc1.head, B, 2 * Dp0, 2 * Dp0, 0},
+        {"enc.dhead", 0, &m->wenc1.dheadP, B, 2 * Dp0, 2 * Dp0, 0}, {"enc.dheadT", 1, &m->wenc1.dheadT, B, 2 * Dp0, 2 * Dp0, Bp},
+        {"enc.d2", 0, &m->wenc1.d2P, B, H0, Hp0, 0}, {"enc.d1", 0, &m->wenc1.d1P, B, H0, Hp0, 0},
+        {"z", 0, &m->zP[0], M, D0, Dp0, 0}, {"zT", 1, &m->zT[0], M, D0, Dp0, Mp},
+        {"dec.g1", 0, &m->wdec1.g1P, M, H0, Hp0, 0}, {"dec.g1T", 1, &m->wdec1.g1T, M, H0, Hp0, Mp},
+        {"dec.g2", 0, &m->wdec1.g2P, M, H0, Hp0, 0}, {"dec.g2T", 1, &m->wdec1.g2T, M, H0, Hp0, Mp},
+        {"dec.dlT", 1, &m->wdec1.dlT, M, m->X, m->Xp32, Mp},
+        {"dec.d2", 0, &m->wdec1.d2P, M, H0, Hp0, 0}, {"dec.d2T", 1, &m->wdec1.d2T, M, H0, Hp0, Mp},
+        {"dec.d1", 0, &m->wdec1.d1P, M, H0, Hp0, 0}, {"dec.d1T", 1, &m->wdec1.d1T, M, H0, Hp0, Mp},
+        {"dec.dz", 2, &m->wdec1.dz, M, Dp0, Dp0, 0},
+        {"gx", 2, &m->gx, M, 1, 1, 0}, {"wn", 2, &m->wn, M, 1, 1, 0}, {"log_w", 2, &m->logw, M, 1, 1, 0},
+    };
+    if (m->cfg.n_layers == 2) {
+        const int H1 = m->H[1], Hp1 = m->Hp[1], D1 = m->D[1], Dp1 = m->Dp[1];
+        std::vector<Ent> e2 = {
+            {"enc2.h1", 0, &m->wenc2.h1P, M, H1, Hp1, 0}, {"enc2.h2", 0, &m->wenc2.h2P, M, H1, Hp1, 0},
+            {"enc2.head", 2, &m->wenc2.head, M, 2 * Dp1, 2 * Dp1, 0}, {"enc2.dhead", 0, &m->wenc2.dheadP, M, 2 * Dp1, 2 * Dp1, 0},
+            {"enc2.dx", 2, &m->wenc2.dx, M, Dp0, Dp0, 0},
+            {"z2", 0, &m->zP[1], M, D1, Dp1, 0},
+            {"dec2.h1", 0, &m->wdec2.h1P, M, H1, Hp1, 0}, {"dec2.h2", 0, &m->wdec2.h2P, M, H1, Hp1, 0},
+            {"dec2.head", 2, &m->wdec2.head, M, 2 * Dp0, 2 * Dp0, 0}, {"dec2.dhead", 0, &m->wdec2.dheadP, M, 2 * Dp0, 2 * Dp0, 0},
+            {"dec2.dx", 2, &m->wdec2.dx, M, Dp1, Dp1, 0},
+            {"dz1", 2, &m->dzsum, M, Dp0, Dp0, 0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0, 0},
+        };
+        ents.insert(ents.end(), e2.begin(), e2.end());
+    }
+    for (const Ent& e : ents) {
+        if (strcmp(e.nm, name) != 0) continue;
+        if (rows) *rows = e.R;
+        if (cols) *cols = e.F;
+        if (!out) return IWAE_OK;
+        if (!e.buf->p) return fail(IWAE_ERR_STATE, std::string("debug_tensor: buffer not populated: ") + name);
+        const size_t n = (size_t)e.R * e.F;
+        if (cap < n) return fail(IWAE_ERR_ARG, "debug_tensor: output too small");
+        if (e.kind == 2) {
+            HIPCHK(hipMemcpyAsync(out, e.buf->p, n * 4, hipMemcpyDefault, m->stream));
+        } else {
+            CHK(ensure(m->scratch, n * 4, m->stream));
+            if (e.kind == 0) launch_unpack_p(ptr<uint16_t>(*e.buf), e.R, e.F, e.Fp, ptr<float>(m->scratch), m->stream);
+            else launch_unpack_t(ptr<uint16_t>(*e.buf), e.R, e.F, e.ld, ptr<float>(m->scratch), m->stream);
+            HIPCHK(hipMemcpyAsync(out, m->scratch.p, n * 4, hipMemcpyDefault, m->stream));
+        }
+        HIPCHK(hipStreamSynchronize(m->stream));
+        return IWAE_OK;
+    }
+    return fail(IWAE_ERR_ARG, std::string("debug_tensor: unknown name ") + name);
+}
+
+}  // extern "C"

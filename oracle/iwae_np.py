@@ -157,6 +157,7 @@ class _Dense:
         else:
             dpre = dy
         dpre_r = self.rnd(dpre)                  # gradient operand as stored (bf16)
+        self.dpre = dpre_r
         x2 = self.x.reshape(-1, self.x.shape[-1])
         d2 = dpre_r.reshape(-1, dpre_r.shape[-1])
         self.dW = x2.T @ d2
@@ -260,12 +261,12 @@ def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None):
     return res
 
 
-def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None):
+def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None, tape=None):
     """Closed-form gradient of loss = -res[objective] (iwae1.py:155-159) w.r.t. the
     14 tensors; objective "dreg" = tasks/task02.py:87-101 (encoder <- inference_loss,
     decoder <- -iwae_elbo).  Returns (res, [(dW, db)...])."""
     rnd = rnd or _id
-    tape = {}
+    tape = {} if tape is None else tape
     dreg = objective == "dreg"
     res = forward_1layer(params, x, eps, beta, rnd, dreg=dreg, _tape=tape)
     enc, dec = tape["enc"], tape["dec"]
@@ -284,6 +285,7 @@ def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None)
         raise KeyError(objective)         # iwae1.py:157 raises KeyError for unknown keys
     dlogits = G[:, :, None] * (xx[None] - p)          # d lpxz / d logits = x - sigmoid(l)
     dz_dec = dec.bwd(dlogits)
+    tape.update(G=G, dz_dec=dz_dec)
     if objective == "dreg":
         # encoder gets d inference_loss; decoder backward is linear in the row weight
         sig2 = sigma + SIGMA_EPS
@@ -346,12 +348,12 @@ def forward_2layer(params, x, eps1, eps2, beta=1.0, rnd=None, _tape=None):
     return res
 
 
-def loss_grads_2layer(params, x, eps1, eps2, beta=1.0, objective="iwae_elbo", rnd=None):
+def loss_grads_2layer(params, x, eps1, eps2, beta=1.0, objective="iwae_elbo", rnd=None, tape=None):
     """Closed form of tape.gradient(-res[objective]) for iwae2.py:169-178."""
     rnd = rnd or _id
     if objective not in OBJECTIVES_2L:
         raise KeyError(objective)         # iwae2.py:173: 'vae_elbo_kl' is a KeyError in the reference
-    t = {}
+    t = {} if tape is None else tape
     res = forward_2layer(params, x, eps1, eps2, beta, rnd, _tape=t)
     k, B, wn = t["k"], t["B"], t["wn"]
     G = (-wn / B) if objective in ("iwae_elbo", "iwae_eq14") else (-np.ones_like(wn) / (k * B))
