@@ -24,8 +24,7 @@ struct EpsSrc {
 struct DenseArgs {
     const uint16_t* X; int ldX;       // P-layout rows [M][ldX], ldX = 32*KT
     const char* img;                  // MG-major A-image of the weight
-    const float* b0; int n0;          // bias of out-features [0, n0)
-    const float* b1; int n1; int split;   // bias of out-features [split, split+n1) (second head)
+    int split;                        // EPI_HEAD: out-features >= split are the sigma head (exp + 1e-6)
     int M, KT, MG, mg_per_block;
     int Np32;                         // out-features that are stored (multiple of 32)
     uint16_t* YP; int ldYP;           // bf16 P-layout out
@@ -41,12 +40,13 @@ struct OutBwdArgs {
     const uint16_t* G2; int ldG;      // last hidden activation, P-layout [M][32*KT]
     const char* img1;                 // MG-major image of W^T (out = pixels, k = hidden)
     const char* img2;                 // K-major image of W   (out = hidden, k = pixels)
-    const float* bias; int Xdim; int Xp32;
+    int Xdim; int Xp32;
     const float* gx;                  // [M] dLoss/dlpxz
     const uint16_t* XB; int ldXB; int k;
     int M, KT, NG;
     uint16_t* DLT; int ldT;           // dlogits, T-layout [Xp32][ldT]
     uint16_t* DPP; uint16_t* DPT;     // dpre of the last hidden layer, P [M][32*KT] and T [32*KT][ldT]
+    unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
 struct WgradArgs {
@@ -109,7 +109,8 @@ struct LayerDesc {
     char* imgF; int KT_F;             // forward image (rows = out-features)
     char* imgB; int KT_B; int MT_B; int imgB_kmajor;   // backward image (rows = in-features) or null
     const float* slabW; const float* slabB; int nsplit; int slab_ld; size_t slab_stride;
-    int block_begin;                  // first block of this layer in the flat elementwise grids
+    int block_begin;                  // first block of this layer in the flat elementwise grid (256 elements per block)
+    int rblock_begin;                 // same for the slab-reduce grid (64 elements per block)
 };
 
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);

@@ -39,30 +39,63 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+// raw v_exp_f32 / v_log_f32 (base 2, ~1 ulp, no denormal fix-up code: arguments here never need it)
+__device__ __forceinline__ float exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_raw(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float tanh_fast(float x) {
     // 1 - 2/(e^{2x}+1): exact limits at +-inf, abs error ~1e-7 (the result is rounded to bf16 anyway)
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * rcp_fast(e + 1.0f);
+    return 1.0f - 2.0f * rcp_fast(exp2_raw(x * (2.0f * LOG2E_F)) + 1.0f);
 }
-__device__ __forceinline__ float softplus_fast(float l) { return fmaxf(l, 0.0f) + __logf(1.0f + __expf(-fabsf(l))); }
-__device__ __forceinline__ float sigmoid_fast(float l) { return rcp_fast(1.0f + __expf(-l)); }
+__device__ __forceinline__ float sigmoid_fast(float l) { return rcp_fast(1.0f + exp2_raw(-l * LOG2E_F)); }
 
-// async global -> LDS copy, 16 B per lane; LDS destination = wave-uniform base + lane*16
-__device__ __forceinline__ void glds16(const char* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// async global -> LDS copy (LDS-DMA), 16 B per lane; LDS destination = M0 (wave-uniform byte address)
+// + lane*16.  Issued through inline asm on purpose: with the builtin, hipcc cannot prove that the
+// DMA does not alias later ds_reads and drains it (s_waitcnt vmcnt(0)) before every k-step, which
+// serialises the weight prefetch with the MFMAs.  Completion is ordered by the explicit
+// "s_waitcnt vmcnt(0)" + barrier at the top of each group (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void glds16(const char* g, uint32_t lds_wave_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_wave_base) : "memory");
 }
 
-// stream `bytes` (multiple of 1 KiB) of an A-image into LDS with the whole workgroup
+// stream `bytes` (multiple of 1 KiB) of an A-image into LDS with the whole workgroup (wave must be
+// wave-uniform, e.g. readfirstlane(threadIdx.x >> 6))
 template <int NWAVES>
 __device__ __forceinline__ void stage_image(const char* src, char* lds, int bytes, int wave, int lane) {
-    for (int off = wave * 1024; off < bytes; off += NWAVES * 1024) glds16(src + off + lane * 16, lds + off);
+    const uint32_t base = lds_addr_of(lds);
+    for (int off = wave * 1024; off < bytes; off += NWAVES * 1024)
+        glds16(src + off + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(base + (uint32_t)off)));
 }
 
-__device__ __forceinline__ float bias_at(const float* b0, int n0, const float* b1, int n1, int split, int f) {
-    if (f < split) return (f < n0) ? b0[f] : 0.0f;
-    const int f1 = f - split;
-    return (f1 < n1) ? b1[f1] : 0.0f;
+// Group boundary wait.  The builtin tells hipcc's waitcnt pass that every vector-memory op it knows
+// about has retired (otherwise it re-waits vmcnt(0) in front of the first MFMA of the group, which
+// also drains the LDS-DMA just issued for the NEXT group); the asm form is the one that must stay:
+// it also covers the asm-issued LDS-DMA, which the pass cannot see.
+__device__ __forceinline__ void wait_all_vmem() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// A-fragment stream with P ds_read_b128 in flight: rd(i) -> uint4, use(i, frag).  Without this the
+// compiler emits read -> lgkmcnt(0) -> 2 MFMA per fragment and a lone wave pays the LDS latency
+// (~64-128 cycles) for every 32 cycles of MFMA.
+template <int N, int P, class RD, class USE>
+__device__ __forceinline__ void lds_pipeline(RD rd, USE use) {
+    uint4 av[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (i < N) av[i] = rd(i);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        use(i, av[i % P]);
+        if (i + P < N) av[i % P] = rd(i + P);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -85,11 +118,10 @@ __device__ __forceinline__ void normal4(uint64_t grow, uint32_t d4, uint32_t str
     const float s24 = 5.9604644775390625e-08f;   // 2^-24
     const float u0 = ((float)(r[0] >> 8) + 0.5f) * s24, u1 = ((float)(r[1] >> 8) + 0.5f) * s24;
     const float u2 = ((float)(r[2] >> 8) + 0.5f) * s24, u3 = ((float)(r[3] >> 8) + 0.5f) * s24;
-    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
-    float sa, ca, sb, cb;
-    sincosf(6.283185307179586f * u1, &sa, &ca);
-    sincosf(6.283185307179586f * u3, &sb, &cb);
-    n[0] = ra * ca; n[1] = ra * sa; n[2] = rb * cb; n[3] = rb * sb;
+    // v_log/v_sqrt/v_sin/v_cos (v_sin/v_cos take revolutions: sin(2*pi*u) = v_sin(u)); abs error ~1e-6
+    const float ra = __builtin_amdgcn_sqrtf(-2.0f * __logf(u0)), rb = __builtin_amdgcn_sqrtf(-2.0f * __logf(u2));
+    n[0] = ra * __builtin_amdgcn_cosf(u1); n[1] = ra * __builtin_amdgcn_sinf(u1);
+    n[2] = rb * __builtin_amdgcn_cosf(u3); n[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 // 4 consecutive eps values for features 4*d4 .. 4*d4+3 of data row (b,s)
 __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int d4, int D, float n[4]) {
@@ -105,27 +137,37 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 // ---------------------------------------------------------------------------------
 // dense_kernel: Y^T[out][rows] = W^T-image x X^T, one wave = 32 data rows (2 column groups of
 // 16, rows interleaved r0+2*rho+g so a T-layout store packs two adjacent rows per lane).
-// Weights stream through LDS one 64-out-feature group (x <=8 k-steps) at a time, double
-// buffered with global_load_lds; the data operand lives in registers for K <= 256.
+// Weights (and the bias of the group, as a trailing 1 KiB block) stream through LDS one
+// 64-out-feature group (x <=8 k-steps) at a time, double buffered with global_load_lds; the
+// data operand lives in registers for K <= 256.  Software pipeline per group u:
+//   wait+barrier | DMA weights(u+1) | stores of epilogue(u-1) | loads for epilogue(u+1) |
+//   MFMA(u) | epilogue math(u)
+// so neither load latency nor store acknowledgement sits in front of a barrier.
 // ---------------------------------------------------------------------------------
-#define DENSE_UNIT 32768
+#define DENSE_UNIT 33792   // 8 k-steps x 4 KiB + 1 KiB bias block
 
-template <int EPI>
+template <int EPI, int KTC>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
 __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int r0 = (blockIdx.x * 4 + wave) * 32;
     int row[2];
     bool valid[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; }
+    // loads are issued unconditionally from a clamped row and zeroed by a select afterwards: a
+    // branch per load would put a vmcnt wait behind every one of them
+    const int rowc[2] = {min(row[0], a.M - 1), min(row[1], a.M - 1)};
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
-    const int KT = a.KT;
-    const int nkw = (KT + 7) >> 3;
+    const int KT = KTC ? KTC : a.KT;
+    const int nkw = KTC ? 1 : ((KT + 7) >> 3);
     const int mg0 = blockIdx.y * a.mg_per_block;
     const int mg1 = min(a.MG, mg0 + a.mg_per_block);
     const int nunits = (mg1 - mg0) * nkw;
+    const size_t gbytes = img_mg_group_bytes(KT);
+    constexpr bool kPacked = (EPI == EPI_TANH || EPI == EPI_DX);     // bf16 P/T outputs
+    constexpr bool kPre = (EPI == EPI_DX || EPI == EPI_BERN);        // epilogue reads a global operand
 
     uint4 bfr[8][2];
     auto load_b = [&](int kw) {
@@ -134,7 +176,10 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (kw * 8 + ks < KT && valid[g]) v = *(const uint4*)(a.X + (size_t)row[g] * a.ldX + (kw * 8 + ks) * 32 + q * 8);
+                if (KTC ? ks < KTC : kw * 8 + ks < KT) {
+                    v = *(const uint4*)(a.X + (size_t)rowc[g] * a.ldX + (kw * 8 + ks) * 32 + q * 8);
+                    if (!valid[g]) v = make_uint4(0, 0, 0, 0);
+                }
                 bfr[ks][g] = v;
             }
         }
@@ -142,11 +187,9 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     auto stage = [&](int unit, int buf) {
         const int mg = mg0 + unit / nkw, kw = unit % nkw;
         const int nks = min(8, KT - kw * 8);
-        stage_image<4>(a.img + ((size_t)(mg * KT + kw * 8)) * 4096, smem + buf * DENSE_UNIT, nks * 4096, wave, lane);
+        const int bytes = nks * 4096 + ((kw == nkw - 1) ? 1024 : 0);   // last window carries the bias block
+        stage_image<4>(a.img + (size_t)mg * gbytes + (size_t)kw * 8 * 4096, smem + buf * DENSE_UNIT, bytes, wave, lane);
     };
-
-    if (nunits > 0) stage(0, 0);
-    if (nkw == 1) load_b(0);
 
     // EPI_BERN state
     float rowacc[2] = {0.0f, 0.0f};
@@ -155,6 +198,52 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) { bidx[g] = valid[g] ? row[g] / a.k : 0; sidx[g] = valid[g] ? row[g] - bidx[g] * a.k : 0; }
     }
+    // lane-constant byte offsets (32-bit) next to wave-uniform 64-bit bases
+    const uint32_t prow_off[2] = {(uint32_t)(8 * q) * 2u, (uint32_t)(8 * q) * 2u};
+    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
+    (void)prow_off;
+
+    auto load_pre = [&](int mg, uint4 (&pre)[2][2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                pre[p][g] = make_uint4(0, 0, 0, 0);
+                const int fbase = 64 * mg + 32 * p;      // wave-uniform guards only
+                if (EPI == EPI_DX && fbase < a.Np32) pre[p][g] = *(const uint4*)(a.ACT + (size_t)rowc[g] * a.ldACT + fbase + 8 * q);
+                if (EPI == EPI_BERN && fbase < a.ldXB) pre[p][g] = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+                if (!valid[g]) pre[p][g] = make_uint4(0, 0, 0, 0);
+            }
+    };
+
+    // deferred bf16 stores of the previous group
+    uint4 stP[2][2];
+    uint32_t stT[2][8];
+    int st_mg = -1;
+    auto emit_stores = [&]() {
+        if (!kPacked || st_mg < 0) return;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int fbase = 64 * st_mg + 32 * p;
+            if (fbase < a.Np32) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (valid[g]) *(uint4*)(a.YP + (size_t)row[g] * a.ldYP + fbase + 8 * q) = stP[p][g];
+                if (a.YT) {
+                    char* tb = (char*)a.YT + (size_t)fbase * a.ldT * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[p][j];
+                }
+            }
+        }
+        st_mg = -1;
+    };
+
+    if (nunits > 0) stage(0, 0);
+    if (nkw == 1) load_b(0);
+    uint4 pre[2][2], pre_n[2][2];
+    if (kPre && mg0 < mg1) load_pre(mg0, pre);
 
     for (int mg = mg0; mg < mg1; ++mg) {
         f32x4 acc[4][2];
@@ -163,62 +252,70 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+        const char* lbias = smem;
         for (int kw = 0; kw < nkw; ++kw) {
             const int unit = (mg - mg0) * nkw + kw, buf = unit & 1;
             if (nkw > 1) load_b(kw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_all_vmem();
             __syncthreads();
             if (unit + 1 < nunits) stage(unit + 1, buf ^ 1);
-            const int nks = min(8, KT - kw * 8);
+            if (kw == 0) {
+                emit_stores();
+                if (kPre && mg + 1 < mg1) load_pre(mg + 1, pre_n);
+            }
+            const int nks = KTC ? KTC : min(8, KT - kw * 8);
             const char* lb = smem + buf * DENSE_UNIT + a_off;
+            lbias = smem + buf * DENSE_UNIT + nks * 4096;
+            if (KTC) {
+                lds_pipeline<(KTC ? KTC : 1) * 4, 8>(
+                    [&](int i) { return *(const uint4*)(lb + i * 1024); },
+                    [&](int i, const uint4& av) {
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks < nks) {
+                        for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, bfr[i >> 2][g], acc[i & 3][g]);
+                    });
+            } else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint4 av = *(const uint4*)(lb + (ks * 4 + t) * 1024);
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks < nks) {
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                        for (int t = 0; t < 4; ++t) {
+                            const uint4 av = *(const uint4*)(lb + (ks * 4 + t) * 1024);
+#pragma unroll
+                            for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                        }
                     }
                 }
             }
         }
 
-        // ---------------- epilogue for out-features 64*mg .. 64*mg+63 ----------------
-        if (EPI == EPI_TANH || EPI == EPI_DX) {
+        // ---------------- epilogue math for out-features 64*mg .. 64*mg+63 ----------------
+        float4 bias4[4];   // bias of features 16t + 4q + i, from the image's bias block
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bias4[t] = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
+        auto bias_of = [&](int t, int i) { return i == 0 ? bias4[t].x : i == 1 ? bias4[t].y : i == 2 ? bias4[t].z : bias4[t].w; };
+
+        if (kPacked) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int fbase = 64 * mg + 32 * p;
-                if (fbase < a.Np32) {
-                    float v[2][8];
+                float v[2][8];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        uint4 act = make_uint4(0, 0, 0, 0);
-                        if (EPI == EPI_DX && valid[g]) act = *(const uint4*)(a.ACT + (size_t)row[g] * a.ldACT + fbase + 8 * q);
+                for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float x = acc[2 * p + (j >> 2)][g][j & 3];
-                            if (EPI == EPI_TANH) {
-                                const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
-                                v[g][j] = tanh_fast(x + bias_at(a.b0, a.n0, a.b1, a.n1, a.split, f));
-                            } else {
-                                const float y = bf_at(act, j);
-                                v[g][j] = x * (1.0f - y * y);
-                            }
-                        }
-                        if (valid[g])
-                            *(uint4*)(a.YP + (size_t)row[g] * a.ldYP + fbase + 8 * q) =
-                                make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
-                    }
-                    if (a.YT) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
-                            *(uint32_t*)(a.YT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = acc[2 * p + (j >> 2)][g][j & 3];
+                        if (EPI == EPI_TANH) {
+                            v[g][j] = tanh_fast(x + bias_of(2 * p + (j >> 2), j & 3));
+                        } else {
+                            const float y = bf_at(pre[p][g], j);
+                            v[g][j] = x * (1.0f - y * y);
                         }
                     }
+                    stP[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
                 }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) stT[p][j] = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
             }
+            st_mg = mg;
         } else if (EPI == EPI_HEAD || EPI == EPI_F32 || EPI == EPI_SIGMOID) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -230,8 +327,8 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             float x = acc[t][g][i];
-                            if (EPI != EPI_F32) x += bias_at(a.b0, a.n0, a.b1, a.n1, a.split, f0 + i);
-                            if (EPI == EPI_HEAD && f0 + i >= a.split) x = __expf(x) + 1e-6f;   // iwae1.py:34,42
+                            if (EPI != EPI_F32) x += bias_of(t, i);
+                            if (EPI == EPI_HEAD && f0 + i >= a.split) x = exp2_raw(x * LOG2E_F) + 1e-6f;   // iwae1.py:34,42
                             if (EPI == EPI_SIGMOID) x = sigmoid_fast(x);
                             op[i] = x;
                         }
@@ -240,28 +337,44 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
                 }
             }
         } else if (EPI == EPI_BERN) {
+            // log p(x|z) = sum_j x_j l_j - softplus(l_j), softplus(l) = max(l,0) + ln2*log2(1 + 2^(-|l| log2e))  (iwae1.py:111)
+            const bool full = 64 * mg + 64 <= a.Xdim;     // wave-uniform: only the last pixel group needs masks
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int fbase = 64 * mg + 32 * p;
-                if (fbase < a.Xdim) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        uint4 xv = make_uint4(0, 0, 0, 0);
-                        if (valid[g]) xv = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+                for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
-                            if (f < a.Xdim) {
-                                const float l = acc[2 * p + (j >> 2)][g][j & 3] + a.b0[f];
-                                rowacc[g] += bf_at(xv, j) * l - softplus_fast(l);    // x*l - softplus(l), iwae1.py:111
-                                if (a.logits_out && valid[g]) a.logits_out[((size_t)sidx[g] * a.B + bidx[g]) * a.Xdim + f] = l;
-                            }
-                        }
+                    for (int j = 0; j < 8; ++j) {
+                        const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                        const float lg = log2_raw(1.0f + exp2_raw(-fabsf(l) * LOG2E_F));
+                        float term = fmaf(bf_at(pre[p][g], j), l, -fmaxf(l, 0.0f));
+                        term = fmaf(-LN2_F, lg, term);
+                        if (!full) term = (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? term : 0.0f;
+                        rowacc[g] += term;
                     }
                 }
             }
+            if (a.logits_out) {     // rare path (the reference dict's "logits"): reference [k,B,X] order
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int f = 64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3);
+                            if (valid[g] && f < a.Xdim)
+                                a.logits_out[((size_t)sidx[g] * a.B + bidx[g]) * a.Xdim + f] = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                        }
+            }
+        }
+        if (kPre) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) pre[p][g] = pre_n[p][g];
         }
     }
+    emit_stores();
 
     if (EPI == EPI_BERN) {
 #pragma unroll
@@ -281,14 +394,30 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 //   dg2 += dl V3^T   (the dl accumulator IS the B operand, no LDS round trip)
 // then dpre2 = dg2 * (1 - g2^2) written P- and T-layout.   (iwae1.py:74-75,111,159)
 // One wave per SIMD (4 waves, 32 rows each): 16x2 f32x4 accumulators for dg2 stay resident.
+// Same software pipeline as dense_kernel (x prefetched one group ahead, dl stores deferred).
 // ---------------------------------------------------------------------------------
+// STAMPS = true is a diagnostic build only (s_memtime per phase, summed per wave into a.stamps;
+// nothing is computed from the stamps).  The product path launches STAMPS = false.
+#define OB_STAMP(slot)                                                                         \
+    if (STAMPS) {                                                                              \
+        unsigned long long t_;                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        tsum[slot] += t_ - tprev;                                                              \
+        tprev = t_;                                                                            \
+    }
+template <int KTC, bool STAMPS>
 __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int r0 = (blockIdx.x * 4 + wave) * 32;
-    const int KT = a.KT, MT2 = 2 * a.KT;
-    const int unit = KT * 8192;   // KT*4 KiB (W^T group) + 2*MT2 KiB (W k-group)
+    const int KT = KTC ? KTC : a.KT, MT2 = 2 * KT;
+    const int u1 = KT * 4096 + 1024;           // W^T group incl. its bias block
+    const int unit = u1 + 2 * MT2 * 1024;      // + W k-group
     int row[2], bidx[2];
     bool valid[2];
     float gx[2];
@@ -300,11 +429,22 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
         gx[g] = valid[g] ? a.gx[row[g]] : 0.0f;
     }
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
 
     auto stage = [&](int ng, int buf) {
         char* d = smem + buf * unit;
-        stage_image<4>(a.img1 + (size_t)ng * KT * 4096, d, KT * 4096, wave, lane);
-        stage_image<4>(a.img2 + (size_t)ng * 2 * MT2 * 1024, d + KT * 4096, 2 * MT2 * 1024, wave, lane);
+        stage_image<4>(a.img1 + (size_t)ng * u1, d, u1, wave, lane);
+        stage_image<4>(a.img2 + (size_t)ng * 2 * MT2 * 1024, d + u1, 2 * MT2 * 1024, wave, lane);
+    };
+    auto load_x = [&](int ng, uint4 (&xv)[2][2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                xv[p][g] = make_uint4(0, 0, 0, 0);
+                const int fbase = 64 * ng + 32 * p;      // wave-uniform guard; invalid rows read image 0 and are zeroed by gx = 0
+                if (fbase < a.Xp32) xv[p][g] = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+            }
     };
     stage(0, 0);
 
@@ -314,9 +454,14 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (ks < KT && valid[g]) v = *(const uint4*)(a.G2 + (size_t)row[g] * a.ldG + ks * 32 + q * 8);
+            if (KTC ? ks < KTC : ks < KT) {
+                v = *(const uint4*)(a.G2 + (size_t)min(row[g], a.M - 1) * a.ldG + ks * 32 + q * 8);
+                if (!valid[g]) v = make_uint4(0, 0, 0, 0);
+            }
             bfr[ks][g] = v;
         }
+    uint4 xv[2][2], xv_n[2][2];
+    load_x(0, xv);
 
     f32x4 acc2[16][2];
 #pragma unroll
@@ -324,78 +469,124 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+    uint32_t stT[2][8];
+    int st_ng = -1;
+    auto emit_stores = [&]() {
+        if (st_ng < 0) return;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int fbase = 64 * st_ng + 32 * p;
+            if (fbase < a.Xp32) {
+                char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[p][j];
+            }
+        }
+        st_ng = -1;
+    };
+
+    OB_STAMP(0)   // prologue
     for (int ng = 0; ng < a.NG; ++ng) {
         const int buf = ng & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_all_vmem();
+        OB_STAMP(1)   // vmcnt wait
         __syncthreads();
+        OB_STAMP(2)   // barrier
         if (ng + 1 < a.NG) stage(ng + 1, buf ^ 1);
+        emit_stores();
+        if (ng + 1 < a.NG) load_x(ng + 1, xv_n);
+        OB_STAMP(3)   // issue DMA + stores + x loads
         const char* l1 = smem + buf * unit + a_off;
-        const char* l2 = l1 + KT * 4096;
+        const char* lbias = smem + buf * unit + KT * 4096;
+        const char* l2 = smem + buf * unit + u1 + a_off;
 
         f32x4 acc[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (KTC) {
+            lds_pipeline<(KTC ? KTC : 1) * 4, 8>(
+                [&](int i) { return *(const uint4*)(l1 + i * 1024); },
+                [&](int i, const uint4& av) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if (ks < KT) {
+                    for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, bfr[i >> 2][g], acc[i & 3][g]);
+                });
+        } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint4 av = *(const uint4*)(l1 + (ks * 4 + t) * 1024);
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks < KT) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4 av = *(const uint4*)(l1 + (ks * 4 + t) * 1024);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                    }
                 }
             }
         }
+        OB_STAMP(4)   // MFMA phase 1
+        float4 bias4[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bias4[t] = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
+        auto bias_of = [&](int t, int i) { return i == 0 ? bias4[t].x : i == 1 ? bias4[t].y : i == 2 ? bias4[t].z : bias4[t].w; };
 
+        const bool full = 64 * ng + 64 <= a.Xdim;    // wave-uniform
         uint4 bf2[2][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int fbase = 64 * ng + 32 * p;
             float v[2][8];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                uint4 xv = make_uint4(0, 0, 0, 0);
-                if (valid[g] && fbase < a.Xp32) xv = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
-                    float d = 0.0f;
-                    if (f < a.Xdim) {
-                        const float l = acc[2 * p + (j >> 2)][g][j & 3] + a.bias[f];
-                        d = gx[g] * (bf_at(xv, j) - sigmoid_fast(l));
-                    }
+                    const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                    float d = gx[g] * (bf_at(xv[p][g], j) - sigmoid_fast(l));     // d lpxz / d l = x - sigmoid(l)
+                    if (!full) d = (64 * ng + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? d : 0.0f;
                     v[g][j] = d;
                 }
                 bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
             }
-            if (fbase < a.Xp32) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = fbase + 16 * (j >> 2) + 4 * q + (j & 3);
-                    *(uint32_t*)(a.DLT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(v[0][j], v[1][j]);
-                }
-            }
+            for (int j = 0; j < 8; ++j) stT[p][j] = pack2(v[0][j], v[1][j]);
         }
+        st_ng = ng;
+        OB_STAMP(5)   // epilogue math
 
+        if (KTC) {
+            constexpr int MTC = 2 * (KTC ? KTC : 1);
+            lds_pipeline<2 * MTC, 8>(
+                [&](int i) { return *(const uint4*)(l2 + i * 1024); },
+                [&](int i, const uint4& av) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+                    for (int g = 0; g < 2; ++g) acc2[i % MTC][g] = mfma16(av, bf2[i / MTC][g], acc2[i % MTC][g]);
+                });
+        } else {
 #pragma unroll
-            for (int mt = 0; mt < 16; ++mt) {
-                if (mt < MT2) {
-                    const uint4 av = *(const uint4*)(l2 + (kk * MT2 + mt) * 1024);
+            for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc2[mt][g] = mfma16(av, bf2[kk][g], acc2[mt][g]);
+                for (int mt = 0; mt < 16; ++mt) {
+                    if (mt < MT2) {
+                        const uint4 av = *(const uint4*)(l2 + (kk * MT2 + mt) * 1024);
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc2[mt][g] = mfma16(av, bf2[kk][g], acc2[mt][g]);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) xv[p][g] = xv_n[p][g];
+        OB_STAMP(6)   // MFMA phase 2
     }
+    emit_stores();
 
     // dpre2 = dg2 * (1 - g2^2); the g2 B-operand registers hold exactly the lane's own features
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        if (ks < KT) {
+        if (KTC ? ks < KTC : ks < KT) {
             float v[2][8];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -408,98 +599,115 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
                     *(uint4*)(a.DPP + (size_t)row[g] * a.ldG + ks * 32 + 8 * q) =
                         make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
             }
+            char* tb = (char*)a.DPT + (size_t)(ks * 32) * a.ldT * 2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int f = ks * 32 + 16 * (j >> 2) + 4 * q + (j & 3);
-                *(uint32_t*)(a.DPT + (size_t)f * a.ldT + r0 + 2 * rho) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
-            }
+            for (int j = 0; j < 8; ++j)
+                *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
         }
+    }
+    OB_STAMP(7)   // final epilogue
+    if (STAMPS && a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tsum[i];
     }
 }
 
 // ---------------------------------------------------------------------------------
 // wgrad_kernel: dW[i][j] (+db[j]) partial sums over a range of data rows.
 //   out[i][j] = sum_r AT[i][r] * GT[j][r]      (both operands T-layout, r contiguous)
-// grid = (j-blocks of 128, i-blocks of 256, row splits); 4 waves, each all <=16 i-tiles x 2
-// j-tiles.  The shared A operand goes through LDS in fragment order; each wave loads its own
-// G fragments straight from global.  Partials go to fp32 slabs (deterministic, no atomics).
+// grid = (j-blocks of 128, i-blocks of 256, row splits); 8 waves, wave w owns j-tile w of the
+// block and all <=16 i-tiles (16 accumulator tiles).  Per 128-row chunk the shared A operand is
+// DMA'd into LDS in fragment order (the bank swizzle is applied on the per-lane SOURCE address,
+// the LDS image stays lane-linear), double buffered; each wave's own G fragments are loaded a
+// chunk ahead.  Partials go to fp32 slabs (deterministic, no atomics).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // [rs 4][it 16][1 KiB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 x [rs 4][it 16][1 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int it0 = blockIdx.y * 16;
     const int nit = min(16, a.IT - it0);
-    const int jt0 = blockIdx.x * 8 + wave * 2;
+    const int jt = blockIdx.x * 8 + wave;
+    const bool jvalid = jt < a.JT;
+    const int jtc = min(jt, a.JT - 1);
     const int split = blockIdx.z;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.Mp, rbeg + a.rows_per_split);
+    const int nchunk = (rend - rbeg + 127) / 128;
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    // DMA source of this lane inside a 16-feature x 32-row fragment block: LDS slot (lane&3) of
+    // feature row (lane>>2) must receive the rows 8*q_src .. 8*q_src+7
+    const int di = lane >> 2, dq = (lane & 3) ^ hperm((lane >> 2) >> 2);
+    const size_t asrc_lane = ((size_t)di * a.Mp + (size_t)dq * 8) * 2;
+    const size_t gsrc_lane = ((size_t)(jtc * 16 + rho) * a.Mp + (size_t)q * 8) * 2;
 
-    f32x4 acc[16][2];
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) acc[t][jj] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float bsum[2] = {0.0f, 0.0f};
-    bool jvalid[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) jvalid[jj] = (jt0 + jj) < a.JT;
-
-    for (int r = rbeg; r < rend; r += 128) {
-        __syncthreads();
-        // stage A: chunk c = ((it*16 + i)*4 + rs)*4 + qq ; 256 B contiguous per (it,i)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int c = u * 256 + tid;
-            const int qq = c & 3, rs = (c >> 2) & 3, i = (c >> 4) & 15, it = c >> 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (it < nit) v = *(const uint4*)(a.AT + (size_t)((it0 + it) * 16 + i) * a.Mp + r + rs * 32 + qq * 8);
-            *(uint4*)(smem + (rs * 16 + it) * 1024 + i * 64 + ((qq ^ hperm(i >> 2)) * 16)) = v;
+    auto stage = [&](int c, int buf) {
+        const int r = rbeg + c * 128;
+        const uint32_t lbase = lds_addr_of(smem + buf * 65536);
+        for (int blk = wave; blk < 4 * nit; blk += 8) {     // blk = rs * nit + it  (wave-uniform)
+            const int rs = blk / nit, it = blk - rs * nit;
+            const char* src = (const char*)a.AT + ((size_t)(it0 + it) * 16 * a.Mp + (size_t)(r + rs * 32)) * 2 + asrc_lane;
+            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + (uint32_t)(rs * 16 + it) * 1024u)));
         }
+    };
+    auto load_g = [&](int c, uint4 (&g)[4]) {
+        const int r = rbeg + c * 128;
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs) g[rs] = *(const uint4*)((const char*)a.GT + gsrc_lane + (size_t)(r + rs * 32) * 2);
+    };
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+    uint4 gcur[4], gnext[4];
+    if (nchunk > 0) { stage(0, 0); load_g(0, gcur); }
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        wait_all_vmem();
         __syncthreads();
+        if (c + 1 < nchunk) { stage(c + 1, buf ^ 1); load_g(c + 1, gnext); }
+        const char* lb = smem + buf * 65536 + a_off;
 #pragma unroll
         for (int rs = 0; rs < 4; ++rs) {
-            uint4 gf[2];
+            const uint4 g = gcur[rs];
+            bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
+            if (nit == 14) {          // hidden width 200 -> 224: straight-line, pipelined LDS reads
+                lds_pipeline<14, 7>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
+                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+            } else if (nit == 16) {
+                lds_pipeline<16, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
+                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+            } else if (nit == 8) {
+                lds_pipeline<8, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
+                                   [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+            } else {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                gf[jj] = make_uint4(0, 0, 0, 0);
-                if (jvalid[jj]) gf[jj] = *(const uint4*)(a.GT + (size_t)((jt0 + jj) * 16 + rho) * a.Mp + r + rs * 32 + q * 8);
-                bsum[jj] += bflo(gf[jj].x) + bfhi(gf[jj].x) + bflo(gf[jj].y) + bfhi(gf[jj].y) + bflo(gf[jj].z) + bfhi(gf[jj].z) + bflo(gf[jj].w) + bfhi(gf[jj].w);
-            }
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                if (it < nit) {
-                    const uint4 av = *(const uint4*)(smem + (rs * 16 + it) * 1024 + a_off);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) acc[it][jj] = mfma16(av, gf[jj], acc[it][jj]);
-                }
+                for (int it = 0; it < 16; ++it)
+                    if (it < nit) acc[it] = mfma16(*(const uint4*)(lb + (rs * 16 + it) * 1024), g, acc[it]);
             }
         }
+#pragma unroll
+        for (int rs = 0; rs < 4; ++rs) gcur[rs] = gnext[rs];
     }
 
     // D: lane(col j = rho, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
-    float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+    if (jvalid) {
+        float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        if (it < nit) {
+        for (int it = 0; it < 16; ++it) {
+            if (it < nit) {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                if (jvalid[jj]) {
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-                        slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + (jt0 + jj) * 16 + rho] = acc[it][jj][ii];
-                }
+                for (int ii = 0; ii < 4; ++ii)
+                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + rho] = acc[it][ii];
             }
         }
-    }
-    if (blockIdx.y == 0) {
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            float v = bsum[jj];
+        if (blockIdx.y == 0) {
+            float v = bsum;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (q == 0 && jvalid[jj]) a.slabB[(size_t)split * a.JT * 16 + (jt0 + jj) * 16 + rho] = v;
+            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + rho] = v;
         }
     }
 }
@@ -518,48 +726,53 @@ __global__ void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, u
     if (XT) XT[(size_t)f * Bp + b] = h;
 }
 
-// thread per data row: z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T)
+// z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T).
+// block = 64 data rows (lanes) x Dp/8 waves, wave c owns the 8 features of P-layout chunk c:
+// the T-layout store is a full 128 B line per feature, the row sums go through LDS.
 __global__ void sample_kernel(SampleArgs a) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= a.Mp) return;
+    __shared__ float red[3][16][64];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6, nc = a.Dp / 8;
+    const int row = blockIdx.x * 64 + lane;
     const bool valid = row < a.M;
     const int b = valid ? row / a.k : 0, s = valid ? row - b * a.k : 0;
     const float* hd = a.head + (size_t)(a.head_per_row ? (valid ? row : 0) : b) * a.ldH;
     float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
-    for (int c = 0; c < a.Dp / 8; ++c) {
-        const int t = c >> 2, qq = c & 3;
-        float z8[8];
+    const int t = c >> 2, qq = c & 3;
+    float z8[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int f0 = 32 * t + 16 * h + 4 * qq;
-            float e[4];
-            eps4(a.eps, b, s, row, f0 >> 2, a.D, e);
+    for (int h = 0; h < 2; ++h) {
+        const int f0 = 32 * t + 16 * h + 4 * qq;
+        float e[4];
+        eps4(a.eps, b, s, row, f0 >> 2, a.D, e);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int f = f0 + i;
-                float z = 0.0f;
-                if (valid && f < a.D) {
-                    const float mu = hd[f], sg = hd[a.Dp + f];
-                    z = mu + sg * e[i];                                  // iwae1.py:59
-                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
-                    const float u = (z - mu) / sg;
-                    lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
-                    if (a.lq_dreg) {                                     // tasks/task02.py:63-65
-                        const float s2 = sg + 1e-6f, u2 = (z - mu) / s2;
-                        lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
-                    }
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + i;
+            float z = 0.0f;
+            if (valid && f < a.D) {
+                const float mu = hd[f], sg = hd[a.Dp + f];
+                z = mu + sg * e[i];                                  // iwae1.py:59
+                lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
+                const float u = (z - mu) / sg;
+                lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
+                if (a.lq_dreg) {                                     // tasks/task02.py:63-65
+                    const float s2 = sg + 1e-6f, u2 = (z - mu) / s2;
+                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
                 }
-                z8[4 * h + i] = z;
-                if (a.ZT) a.ZT[(size_t)f * a.ldT + row] = (uint16_t)(pack2(z, 0.0f) & 0xffffu);
             }
+            z8[4 * h + i] = z;
+            if (a.ZT) a.ZT[(size_t)f * a.ldT + row] = (uint16_t)(pack2(z, 0.0f) & 0xffffu);
         }
-        if (valid)
-            *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * c) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
     }
-    if (valid) {
-        if (a.lp_prior) a.lp_prior[row] = lp;
-        a.lq[row] = lq;
-        if (a.lq_dreg) a.lq_dreg[row] = lq2;
+    if (valid)
+        *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * c) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+    red[0][c][lane] = lp; red[1][c][lane] = lq; red[2][c][lane] = lq2;
+    __syncthreads();
+    if (c == 0 && valid) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+        for (int i = 0; i < nc; ++i) { s0 += red[0][i][lane]; s1 += red[1][i][lane]; s2 += red[2][i][lane]; }
+        if (a.lp_prior) a.lp_prior[row] = s0;
+        a.lq[row] = s1;
+        if (a.lq_dreg) a.lq_dreg[row] = s2;
     }
 }
 
@@ -706,26 +919,29 @@ __global__ void scalars_kernel(const float* per_b, int B, float beta, float* out
     }
 }
 
-// per image b and 4 features: reduce the sample axis:
+// one block per image b: reduce the sample axis.  Thread (f4, sg) handles 4 latent
+// features and the samples s = sg, sg+SG, ...; partial sums meet in LDS.
 //   dz_tot = ca*dz_dec + cz*z + cq*(z-mu)/(sigma+1e-6)^2
 //   dmu = sum_s dz_tot + kmu*mu ; dsigma = sum_s (dz_tot*eps + cs/sigma) + ksig*(sigma - 1/sigma)
 //   da = dsigma * exp(a) = dsigma * (sigma - 1e-6)
-__global__ void latent_bwd_kernel(LatentBwdArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nf4 = a.Dp / 4;
-    const int b = idx / nf4, f4 = idx % nf4;
-    if (b >= a.Bp) return;
+__global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
+    __shared__ float red[256][8];
+    const int nf4 = a.Dp / 4;              // <= 32
+    const int SG = 256 / nf4;
+    const int f4 = threadIdx.x % nf4, sg = threadIdx.x / nf4;
+    const int b = blockIdx.x;
     const int f0 = 4 * f4;
     float dmu[4] = {0, 0, 0, 0}, dsg[4] = {0, 0, 0, 0};
-    if (b < a.B && f0 < a.D) {
-        float mu[4], sg[4];
+    float mu[4] = {0, 0, 0, 0}, sgm[4] = {1, 1, 1, 1};
+    const bool act = b < a.B && f0 < a.D && sg < SG;
+    if (act) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = f0 + i < a.D;
             mu[i] = ok ? a.head[(size_t)b * a.ldH + f0 + i] : 0.0f;
-            sg[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
+            sgm[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
         }
-        for (int s = 0; s < a.k; ++s) {
+        for (int s = sg; s < a.k; s += SG) {
             const int row = b * a.k + s;
             const float4 dz = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
             const float4 cf = a.cf[row];
@@ -735,20 +951,29 @@ __global__ void latent_bwd_kernel(LatentBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (f0 + i < a.D) {
-                    const float z = mu[i] + sg[i] * e[i];
-                    const float s2 = sg[i] + 1e-6f;
+                    const float z = mu[i] + sgm[i] * e[i];
+                    const float s2 = sgm[i] + 1e-6f;
                     const float t = cf.x * dzv[i] + cf.y * z + cf.z * (z - mu[i]) / (s2 * s2);
                     dmu[i] += t;
-                    dsg[i] += t * e[i] + cf.w / sg[i];
+                    dsg[i] += t * e[i] + cf.w / sgm[i];
                 }
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = dmu[i]; red[threadIdx.x][4 + i] = dsg[i]; }
+    __syncthreads();
+    if (sg != 0) return;
+    if (act) {
+        for (int g = 1; g < SG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dmu[i] += red[g * nf4 + f4][i]; dsg[i] += red[g * nf4 + f4][4 + i]; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (f0 + i < a.D) {
                 dmu[i] += a.kmu * mu[i];
-                dsg[i] += a.ksig * (sg[i] - 1.0f / sg[i]);
-                dsg[i] *= (sg[i] - 1e-6f);
+                dsg[i] += a.ksig * (sgm[i] - 1.0f / sgm[i]);
+                dsg[i] *= (sgm[i] - 1e-6f);
             } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
         }
     }
@@ -828,23 +1053,30 @@ __global__ void add3_kernel(float* out, const float* a0, const float* a1, const 
 // ---------------------------------------------------------------------------------
 // gradient slab reduce and Adam (+ bf16 A-image refresh)
 // ---------------------------------------------------------------------------------
-__global__ void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad) {
+__global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad) {
+    // block = 64 consecutive gradient elements x 4 split groups; partial sums meet in LDS
+    __shared__ float red[4][64];
     int l = 0;
-    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].block_begin) ++l;
+    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].rblock_begin) ++l;
     const LayerDesc L = layers[l];
-    const int e = ((int)blockIdx.x - L.block_begin) * blockDim.x + threadIdx.x;
+    const int e = ((int)blockIdx.x - L.rblock_begin) * 64 + (threadIdx.x & 63);
+    const int sg = threadIdx.x >> 6;
     const int nW = L.Kin * L.Nout;
-    if (e >= nW + L.Nout) return;
     float s = 0.0f;
     if (e < nW) {
         const int i = e / L.Nout, j = e % L.Nout;
-        const size_t off = (size_t)i * L.slab_ld + L.joff + j;
-        for (int sp = 0; sp < L.nsplit; ++sp) s += L.slabW[(size_t)sp * L.slab_stride + off];
-        grad[L.offW + e] = s;
-    } else {
-        const int j = e - nW;
-        for (int sp = 0; sp < L.nsplit; ++sp) s += L.slabB[(size_t)sp * L.slab_ld + L.joff + j];
-        grad[L.offb + j] = s;
+        const float* p = L.slabW + (size_t)i * L.slab_ld + L.joff + j;
+        for (int sp = sg; sp < L.nsplit; sp += 4) s += p[(size_t)sp * L.slab_stride];
+    } else if (e < nW + L.Nout) {
+        const float* p = L.slabB + L.joff + (e - nW);
+        for (int sp = sg; sp < L.nsplit; sp += 4) s += p[(size_t)sp * L.slab_ld];
+    }
+    red[sg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sg == 0 && e < nW + L.Nout) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (e < nW) grad[L.offW + e] = s;
+        else grad[L.offb + (e - nW)] = s;
     }
 }
 
@@ -869,7 +1101,9 @@ __global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, 
         w -= alpha * m / (sqrtf(v) + eps);
         param[idx] = w;
     }
-    if (e < nW) {
+    if (e >= nW) {
+        *(float*)(L.imgF + img_mg_bias_byte(L.joff + (e - nW), L.KT_F)) = w;
+    } else {
         const int i = e / L.Nout, j = e % L.Nout;
         const uint16_t h = (uint16_t)(pack2(w, 0.0f) & 0xffffu);
         *(uint16_t*)(L.imgF + img_mg_byte(L.joff + j, i, L.KT_F)) = h;
@@ -942,37 +1176,57 @@ __global__ void eps_dump_kernel(EpsSrc e, int B, int k, int D, float* out) {   /
 // ---------------------------------------------------------------------------------
 static inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+template <int KTC>
+static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    switch (epi) {
+        case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_HEAD: hipLaunchKernelGGL((dense_kernel<EPI_HEAD, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_SIGMOID: hipLaunchKernelGGL((dense_kernel<EPI_SIGMOID, KTC>), grid, dim3(256), lds, st, a); break;
+    }
+}
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     dim3 grid((a.M + 127) / 128, (a.MG + a.mg_per_block - 1) / a.mg_per_block);
     const size_t lds = 2 * DENSE_UNIT;
-    switch (epi) {
-        case EPI_TANH: hipLaunchKernelGGL(dense_kernel<EPI_TANH>, grid, dim3(256), lds, st, a); break;
-        case EPI_HEAD: hipLaunchKernelGGL(dense_kernel<EPI_HEAD>, grid, dim3(256), lds, st, a); break;
-        case EPI_DX: hipLaunchKernelGGL(dense_kernel<EPI_DX>, grid, dim3(256), lds, st, a); break;
-        case EPI_F32: hipLaunchKernelGGL(dense_kernel<EPI_F32>, grid, dim3(256), lds, st, a); break;
-        case EPI_BERN: hipLaunchKernelGGL(dense_kernel<EPI_BERN>, grid, dim3(256), lds, st, a); break;
-        case EPI_SIGMOID: hipLaunchKernelGGL(dense_kernel<EPI_SIGMOID>, grid, dim3(256), lds, st, a); break;
+    // compile-time k-step counts for the reference model's shapes (200->224, 100->128, 50->64, head 256)
+    switch (a.KT) {
+        case 2: launch_dense_k<2>(epi, a, grid, lds, st); break;
+        case 4: launch_dense_k<4>(epi, a, grid, lds, st); break;
+        case 7: launch_dense_k<7>(epi, a, grid, lds, st); break;
+        case 8: launch_dense_k<8>(epi, a, grid, lds, st); break;
+        default: launch_dense_k<0>(epi, a, grid, lds, st); break;
     }
 }
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)a.KT * 8192;
-    hipLaunchKernelGGL(out_bwd_kernel, dim3((a.M + 127) / 128), dim3(256), lds, st, a);
+    const size_t lds = 2 * ((size_t)a.KT * 8192 + 1024);
+    dim3 grid((a.M + 127) / 128);
+    if (a.stamps) {   // diagnostic build
+        hipLaunchKernelGGL((out_bwd_kernel<7, true>), grid, dim3(256), lds, st, a);
+        return;
+    }
+    switch (a.KT) {
+        case 7: hipLaunchKernelGGL((out_bwd_kernel<7, false>), grid, dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((out_bwd_kernel<4, false>), grid, dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL((out_bwd_kernel<0, false>), grid, dim3(256), lds, st, a); break;
+    }
 }
 void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
     dim3 grid((a.JT + 7) / 8, (a.IT + 15) / 16, nsplit);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 65536, st, a);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), 131072, st, a);
 }
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
     hipLaunchKernelGGL(prep_rows_kernel, grid1((size_t)Bp * Xp, 256), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
 }
-void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, grid1(a.Mp, 128), dim3(128), 0, st, a); }
+void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3(a.Mp / 64), dim3(64 * (a.Dp / 8)), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
 }
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(latent_bwd_kernel, grid1((size_t)a.Bp * (a.Dp / 4), 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(a.Bp), dim3(256), 0, st, a);
 }
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);

@@ -23,8 +23,9 @@
 //           of 16 out-features x 32 in-features; lane(rr,q) reads 16 B at
 //           rr*64 + ((q ^ hp(rr>>2))*16), which is bank-conflict-free for
 //           ds_read_b128's four 16-lane groups (MI355X_MICROARCH.md, LDS table).
-//           Blocks are ordered [mgroup(64 out)][kstep][tile(4)] ("MG-major", streamed
-//           one out-feature group at a time) or [kgroup(64 in)][kk(2)][mtile]
+//           Blocks are ordered [mgroup(64 out)][kstep][tile(4)] + one 1 KiB block per mgroup
+//           holding the fp32 bias of its 64 out-features ("MG-major", streamed one
+//           out-feature group at a time) or [kgroup(64 in)][kk(2)][mtile]
 //           ("K-major", streamed one in-feature group at a time).
 #pragma once
 #include <stdint.h>
@@ -45,10 +46,15 @@ IWAE_HD int p_pos(int f) { return (f & ~31) + 8 * ((f & 15) >> 2) + 4 * ((f & 31
 
 // byte offset of element (out-feature m, in-feature kf) inside an MG-major image
 // whose k extent is KT k-steps (KT = round_up(K,32)/32)
+IWAE_HD size_t img_mg_group_bytes(int KT) { return (size_t)(4 * KT + 1) * 1024; }
 IWAE_HD size_t img_mg_byte(int m, int kf, int KT) {
     const int mg = m >> 6, tile = (m >> 4) & 3, rr = m & 15;
     const int ks = kf >> 5, h = (kf >> 4) & 1, q = (kf >> 2) & 3, i = kf & 3;
-    return ((size_t)(mg * KT + ks) * 4 + tile) * 1024 + rr * 64 + ((q ^ hperm(rr >> 2)) * 16) + (4 * h + i) * 2;
+    return (size_t)mg * img_mg_group_bytes(KT) + (size_t)(ks * 4 + tile) * 1024 + rr * 64 + ((q ^ hperm(rr >> 2)) * 16) + (4 * h + i) * 2;
+}
+// byte offset of the fp32 bias of out-feature m (last block of its group)
+IWAE_HD size_t img_mg_bias_byte(int m, int KT) {
+    return (size_t)(m >> 6) * img_mg_group_bytes(KT) + (size_t)KT * 4096 + (m & 63) * 4;
 }
 
 // byte offset inside a K-major image with MT out-feature tiles (MT = round_up(Mout,16)/16)

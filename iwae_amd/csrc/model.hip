@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <random>
@@ -78,7 +79,7 @@ struct iwae_model {
     // layer descriptor table
     std::vector<LayerDesc> descs;
     LayerDesc* d_descs = nullptr;
-    int elem_blocks = 0;
+    int elem_blocks = 0, reduce_blocks = 0;
     bool descs_dirty = true;
     // per-call state
     int B = 0, k = 0, M = 0, Mp = 0, Bp = 0;
@@ -90,6 +91,8 @@ struct iwae_model {
     BlockWs wenc1, wenc2, wdec2;
     MlpWs wdec1;
     DevBuf scratch;            // exports
+    DevBuf stamps;             // diagnostic (IWAE_STAMPS=1)
+    bool want_stamps = false;
     float* d_scalars = nullptr;
     float* h_scalars = nullptr;   // pinned
 };
@@ -125,7 +128,7 @@ void init_linear(Linear& L, int Kin, int Nspace, bool need_B, bool kmajor) {
     L.Np32 = round_up(Nspace, 32);
     L.KT = L.Kp32 / 32;
     L.MG = (L.Np32 + 63) / 64;
-    L.imgF_bytes = (size_t)L.MG * L.KT * 4096;
+    L.imgF_bytes = (size_t)L.MG * img_mg_group_bytes(L.KT);
     L.kmajor = kmajor ? 1 : 0;
     if (need_B) {
         if (kmajor) {
@@ -134,7 +137,7 @@ void init_linear(Linear& L, int Kin, int Nspace, bool need_B, bool kmajor) {
         } else {
             L.KT_B = L.Np32 / 32;
             L.MG_B = (L.Kp32 + 63) / 64;
-            L.imgB_bytes = (size_t)L.MG_B * L.KT_B * 4096;
+            L.imgB_bytes = (size_t)L.MG_B * img_mg_group_bytes(L.KT_B);
         }
     }
     L.IT = L.Kp32 / 16;
@@ -231,12 +234,15 @@ int build_descs(iwae_model* m) {
             d.nsplit = L->nsplit; d.slab_ld = L->JT * 16; d.slab_stride = (size_t)L->IT * 16 * L->JT * 16;
         }
     }
-    int blocks = 0;
+    int blocks = 0, rblocks = 0;
     for (auto& d : m->descs) {
         d.block_begin = blocks;
+        d.rblock_begin = rblocks;
         blocks += (d.Kin * d.Nout + d.Nout + 255) / 256;
+        rblocks += (d.Kin * d.Nout + d.Nout + 63) / 64;
     }
     m->elem_blocks = blocks;
+    m->reduce_blocks = rblocks;
     if (!m->d_descs) HIPCHK(hipMalloc((void**)&m->d_descs, sizeof(LayerDesc) * m->descs.size()));
     HIPCHK(hipMemcpyAsync(m->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -268,13 +274,8 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, i
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
-    const KerasLayer& k0 = m->klayers[L.sub[0]];
-    a.b0 = m->param + k0.offb; a.n0 = k0.Nout; a.split = 1 << 30;
-    if (L.nsub == 2) {
-        const KerasLayer& k1 = m->klayers[L.sub[1]];
-        a.b1 = m->param + k1.offb; a.n1 = k1.Nout; a.split = L.joff[1];
-    }
-    a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
+    a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
+    a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32;
     a.YP = YP; a.ldYP = L.Np32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = ldYF;
     launch_dense(epi, a, m->stream);
     HIPCHK(hipGetLastError());
@@ -312,7 +313,7 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R,
 int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp) {
     const int chunks = Rp / 128;
     const int blocks = ((L.JT + 7) / 8) * ((L.IT + 15) / 16);
-    int nsplit = std::max(1, std::min(chunks, 768 / std::max(1, blocks)));
+    int nsplit = std::max(1, std::min(chunks, 256 / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
     const size_t needW = (size_t)nsplit * L.IT * 16 * L.JT * 16 * 4, needB = (size_t)nsplit * L.JT * 16 * 4;
@@ -334,7 +335,7 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, int rowsP, 
     memset(&a, 0, sizeof(a));
     a.X = GP; a.ldX = L.Np32; a.img = L.imgB;
     a.split = 1 << 30;
-    a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = L.MG_B; a.Np32 = L.Kp32;
+    a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = (rows <= 8192) ? 1 : L.MG_B; a.Np32 = L.Kp32;
     a.YP = YP; a.ldYP = L.Kp32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = L.Kp32;
     a.ACT = ACT; a.ldACT = L.Kp32;
     launch_dense(ACT ? EPI_DX : EPI_F32, a, m->stream);
@@ -443,7 +444,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         DenseArgs a;
         memset(&a, 0, sizeof(a));
         a.X = ptr<uint16_t>(w.g2P); a.ldX = L.Kp32; a.img = L.imgF;
-        a.b0 = m->param + m->klayers[L.sub[0]].offb; a.n0 = X; a.split = 1 << 30;
+        a.split = 1 << 30;
         a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
         a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
         a.lpxz = lpxz;
@@ -452,7 +453,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
         }
-        launch_dense(EPI_BERN, a, st);
+            launch_dense(EPI_BERN, a, st);
         HIPCHK(hipGetLastError());
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
@@ -512,11 +513,15 @@ int backward_impl(iwae_model* m, int objective) {
         OutBwdArgs a;
         memset(&a, 0, sizeof(a));
         a.G2 = ptr<uint16_t>(w.g2P); a.ldG = L.Kp32; a.img1 = L.imgF; a.img2 = L.imgB;
-        a.bias = m->param + m->klayers[L.sub[0]].offb; a.Xdim = X; a.Xp32 = Xp;
+        a.Xdim = X; a.Xp32 = Xp;
         a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DLT = ptr<uint16_t>(w.dlT); a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = ptr<uint16_t>(w.d2T);
-        launch_out_bwd(a, st);
+        if (m->want_stamps && L.KT == 7) {
+            CHK(ensure(m->stamps, (size_t)(Mp / 128) * 4 * 8 * 8, st));
+            a.stamps = ptr<unsigned long long>(m->stamps);
+        }
+            launch_out_bwd(a, st);
         HIPCHK(hipGetLastError());
     }
     CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp));
@@ -564,7 +569,7 @@ int backward_impl(iwae_model* m, int objective) {
     }
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), B, Bp, false));
     if (m->descs_dirty) CHK(build_descs(m));
-    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->grad, st);
+    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, st);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -671,6 +676,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipSetDevice(cfg->device));
     iwae_model* m = new iwae_model();
     m->cfg = *cfg;
+    m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
+
     m->X = cfg->x_dim;
     m->Xp32 = round_up(cfg->x_dim, 32);
     for (int i = 0; i < 2; ++i) {
@@ -805,6 +812,7 @@ int iwae_get_params(iwae_handle m, float* flat, size_t n) {
 int iwae_set_output_bias(iwae_handle m, const float* bias, size_t n) {
     if (!m || !bias || n != (size_t)m->X) return fail(IWAE_ERR_ARG, "set_output_bias: need x_dim values");
     HIPCHK(hipMemcpyAsync(m->param + m->klayers.back().offb, bias, n * 4, hipMemcpyDefault, m->stream));
+    CHK(refresh_images(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     return IWAE_OK;
 }
@@ -983,6 +991,18 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
             {"dz1", 2, &m->dzsum, M, Dp0, Dp0, 0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0, 0},
         };
         ents.insert(ents.end(), e2.begin(), e2.end());
+    }
+    if (strcmp(name, "stamps") == 0) {   // diagnostic: [waves][8] phase cycle sums of out_bwd, as float
+        const int nw = (Mp / 128) * 4;
+        if (rows) *rows = nw;
+        if (cols) *cols = 8;
+        if (!out) return IWAE_OK;
+        if (!m->stamps.p) return fail(IWAE_ERR_STATE, "stamps not enabled (IWAE_STAMPS=1)");
+        std::vector<unsigned long long> h((size_t)nw * 8);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        HIPCHK(hipMemcpy(h.data(), m->stamps.p, h.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) out[i] = (float)h[i];
+        return IWAE_OK;
     }
     for (const Ent& e : ents) {
         if (strcmp(e.nm, name) != 0) continue;
