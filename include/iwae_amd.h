@@ -134,6 +134,12 @@ int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t c
 /* IWAE.sample(z): decoder only, src/iwae1.py:168-178 (z [n,D_last]) -> probs [n, x_dim] */
 int iwae_decode(iwae_handle h, const float* z, int32_t n, float* probs);
 
+/* HIP-event timing of the dominant kernels on the handle's stream (used by bench.py's roofline
+ * object): enable, run steps, then read the average launch duration.  name is one of "out_bwd"
+ * (decoder output layer backward), "bernoulli_fwd" (output layer + log-likelihood), "wgrad_out". */
+int iwae_enable_timing(iwae_handle h, int32_t enable);
+int iwae_kernel_time(iwae_handle h, const char* name, double* avg_us, int64_t* launches);
+
 /* debugging: fetch an internal activation / gradient as float32 [rows, feat] (names in DESIGN.md) */
 int iwae_debug_tensor(iwae_handle h, const char* name, float* out, size_t cap, int32_t* rows, int32_t* cols);
 /* the N(0,1) draws the device generator produces for (B,k): [k,B,D] */

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string>
 #include <vector>
@@ -14,6 +15,9 @@
 #include "layout.h"
 
 using namespace iwae;
+
+static_assert(sizeof(iwae_config) == 48 && offsetof(iwae_config, seed) == 32, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
+static_assert(sizeof(iwae_scalars) == 64 && sizeof(iwae_tensors) == 12 * sizeof(void*), "ABI struct layout");
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -92,6 +96,10 @@ struct iwae_model {
     MlpWs wdec1;
     DevBuf scratch;            // exports
     DevBuf stamps;             // diagnostic (IWAE_STAMPS=1)
+    // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start[3], ev_stop[3];   // 0 out_bwd, 1 bernoulli fwd, 2 wgrad(out)
+    size_t ev_used[3] = {0, 0, 0};
     bool want_stamps = false;
     float* d_scalars = nullptr;
     float* h_scalars = nullptr;   // pinned
@@ -256,6 +264,24 @@ int refresh_images(iwae_model* m) {   // rebuild bf16 A-images from the fp32 mas
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
+
+struct ScopedTimer {     // records a start/stop event pair around a launch when timing is enabled
+    iwae_model* m; int id; bool on;
+    ScopedTimer(iwae_model* m_, int id_) : m(m_), id(id_), on(m_->timing) {
+        if (!on) return;
+        if (m->ev_used[id] == m->ev_start[id].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            m->ev_start[id].push_back(a); m->ev_stop[id].push_back(b);
+        }
+        (void)hipEventRecord(m->ev_start[id][m->ev_used[id]], m->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(m->ev_stop[id][m->ev_used[id]], m->stream);
+        m->ev_used[id] += 1;
+    }
+};
 
 EpsSrc eps_src(iwae_model* m, int layer) {
     EpsSrc e;
@@ -453,7 +479,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
         }
-            launch_dense(EPI_BERN, a, st);
+            { ScopedTimer tm(m, 1); launch_dense(EPI_BERN, a, st); }
         HIPCHK(hipGetLastError());
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
@@ -521,10 +547,10 @@ int backward_impl(iwae_model* m, int objective) {
             CHK(ensure(m->stamps, (size_t)(Mp / 128) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
-            launch_out_bwd(a, st);
+            { ScopedTimer tm(m, 0); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
-    CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp));
+    { ScopedTimer tm(m, 2); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp)); }
     CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
     CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp));
     CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, Mp, nullptr, nullptr, nullptr, ptr<float>(w.dz)));
@@ -752,6 +778,10 @@ void iwae_destroy(iwae_handle m) {
     if (m->d_descs) (void)hipFree(m->d_descs);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);
+    for (int i = 0; i < 3; ++i) {
+        for (hipEvent_t e : m->ev_start[i]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : m->ev_stop[i]) (void)hipEventDestroy(e);
+    }
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -939,6 +969,30 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     HIPCHK(hipMemcpy2DAsync(probs, (size_t)m->X * 4, m->scratch.p, (size_t)Xp * 4, (size_t)m->X * 4, n, hipMemcpyDefault, st));
     HIPCHK(hipStreamSynchronize(st));
     m->have_forward = false;
+    return IWAE_OK;
+}
+
+int iwae_enable_timing(iwae_handle m, int32_t enable) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->timing = enable != 0;
+    for (int i = 0; i < 3; ++i) m->ev_used[i] = 0;
+    return IWAE_OK;
+}
+
+int iwae_kernel_time(iwae_handle m, const char* name, double* avg_us, int64_t* launches) {
+    if (!m || !name || !avg_us) return fail(IWAE_ERR_ARG, "kernel_time: null argument");
+    const int id = !strcmp(name, "out_bwd") ? 0 : !strcmp(name, "bernoulli_fwd") ? 1 : !strcmp(name, "wgrad_out") ? 2 : -1;
+    if (id < 0) return fail(IWAE_ERR_ARG, "kernel_time: unknown kernel (out_bwd | bernoulli_fwd | wgrad_out)");
+    HIPCHK(hipStreamSynchronize(m->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < m->ev_used[id]; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, m->ev_start[id][i], m->ev_stop[id][i]));
+        tot += ms;
+    }
+    *avg_us = m->ev_used[id] ? tot * 1e3 / (double)m->ev_used[id] : 0.0;
+    if (launches) *launches = (int64_t)m->ev_used[id];
     return IWAE_OK;
 }
 

@@ -202,6 +202,14 @@ class NativeModel:
         check(self.lib.iwae_decode(self.h, z.ctypes.data, z.shape[0], out.ctypes.data))
         return out
 
+    def enable_timing(self, on=True):
+        check(self.lib.iwae_enable_timing(self.h, 1 if on else 0))
+
+    def kernel_time(self, name):
+        us, cnt = C.c_double(), C.c_int64()
+        check(self.lib.iwae_kernel_time(self.h, name.encode(), C.byref(us), C.byref(cnt)))
+        return us.value, cnt.value
+
     def debug_tensor(self, name):
         r, c = C.c_int32(), C.c_int32()
         check(self.lib.iwae_debug_tensor(self.h, name.encode(), None, 0, C.byref(r), C.byref(c)))

@@ -1,0 +1,52 @@
+"""Data-parallel training step: one process per GPU (torch.distributed, backend "nccl" = RCCL
+over xGMI).  The reference has no counterpart (single device, main.py:32); the path shards
+naturally because the loss is a mean over images (src/iwae1.py:120-134):
+
+  rank r takes images [r*B/N, (r+1)*B/N) -> forward + backward on its shard (mean over ITS images)
+  one all-reduce(SUM) of the flat fp32 gradient buffer (455,384 floats, in place on the device)
+  Adam with grad_scale = 1/N on every rank (replicas stay bit-identical)
+
+Noise is keyed by the GLOBAL image index (batch_offset), so N ranks draw the same eps as 1 rank.
+The helpers take plain torch tensors so the host logic is testable on CPU with gloo."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous, equal shards (the all-reduce average assumes equal shard sizes)."""
+    if n % world_size:
+        raise ValueError("global batch %d not divisible by world size %d" % (n, world_size))
+    per = n // world_size
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_sum_(flat, group=None):
+    """In-place sum of the flat gradient over ranks; one message, not one per tensor."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+class _DevArray:
+    """Expose a raw device pointer of the C ABI to torch (no copy) via __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class DataParallelStep:
+    def __init__(self, net, rank, world_size, group=None):
+        self.net, self.rank, self.world, self.group = net, int(rank), int(world_size), group
+        ptr, n = net.grad_devptr()
+        self.grad = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+        # run the library on torch's current stream so the collective is ordered after the backward
+        net.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.step_idx = 0
+
+    def step(self, x_devptr, b_local, k, beta, lr, objective_id, global_batch_offset=0):
+        """x_devptr: this rank's shard, already resident in HBM ([b_local, x_dim] float32)."""
+        self.net.set_step(self.step_idx, global_batch_offset + self.rank * b_local)
+        self.net.forward_backward_devptr(x_devptr, b_local, k, beta, objective_id)
+        allreduce_sum_(self.grad, self.group)
+        self.net.adam_step(lr, 1.0 / self.world)
+        self.step_idx += 1

@@ -167,4 +167,4 @@ class CpuTrainer:
                 m.mul_(0.9).add_(gi, alpha=0.1)
                 v.mul_(0.999).addcmul_(gi, gi, value=0.001)
                 p.sub_(alpha * m / (v.sqrt() + 1e-4))
-        return float(res[objective])
+        return float(res[objective].detach())

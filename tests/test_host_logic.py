@@ -1,0 +1,156 @@
+"""CPU tests of the host-side logic: data layouts the kernels rely on (Python mirror of
+iwae_amd/csrc/layout.h), reference-API helpers, and the data-parallel exchange over gloo (2 ranks)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- mirror of layout.h -----------------------------------------------------------------
+def hperm(x):
+    return (0x78 >> (2 * x)) & 3
+
+
+def p_pos(f):
+    return (f & ~31) + 8 * ((f & 15) >> 2) + 4 * ((f & 31) >> 4) + (f & 3)
+
+
+def img_mg_byte(m, kf, KT):
+    mg, tile, rr = m >> 6, (m >> 4) & 3, m & 15
+    ks, h, q, i = kf >> 5, (kf >> 4) & 1, (kf >> 2) & 3, kf & 3
+    return mg * (4 * KT + 1) * 1024 + (ks * 4 + tile) * 1024 + rr * 64 + ((q ^ hperm(rr >> 2)) * 16) + (4 * h + i) * 2
+
+
+def test_layout_header_matches_mirror():
+    src = open(os.path.join(ROOT, "iwae_amd", "csrc", "layout.h")).read()
+    assert "(0x78 >> (2 * x)) & 3" in src
+    assert "(f & ~31) + 8 * ((f & 15) >> 2) + 4 * ((f & 31) >> 4) + (f & 3)" in src
+    assert "(4 * KT + 1) * 1024" in src
+
+
+def test_p_layout_is_a_permutation_with_lane_chunks():
+    pos = [p_pos(f) for f in range(256)]
+    assert sorted(pos) == list(range(256))
+    # lane quad q owns features {32t+4q+i} U {32t+16+4q+i}: 8 contiguous positions = one 16-byte load
+    for t in range(4):
+        for q in range(4):
+            own = [32 * t + 16 * h + 4 * q + i for h in range(2) for i in range(4)]
+            assert sorted(p_pos(f) for f in own) == list(range(32 * t + 8 * q, 32 * t + 8 * q + 8))
+
+
+def test_image_blocks_are_bijective_and_bank_conflict_free():
+    KT = 7
+    offs = {img_mg_byte(m, kf, KT) for m in range(64) for kf in range(32 * KT)}
+    assert len(offs) == 64 * 32 * KT and max(offs) < (4 * KT) * 1024 and all(o % 2 == 0 for o in offs)
+    # ds_read_b128 services a wave in four 16-lane groups (MI355X_MICROARCH.md, LDS table); bank = (addr/4) % 64
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+              list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+              list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+    for g in groups:
+        banks = {}
+        for lane in g:
+            rho, q = lane & 15, lane >> 4
+            a = rho * 64 + ((q ^ hperm(rho >> 2)) * 16)
+            for b in range(4):
+                banks.setdefault((a // 4 + b) % 64, set()).add(a)
+        assert max(len(s) for s in banks.values()) == 1
+
+
+def test_utils_and_optimizer_shim():
+    from iwae_amd import utils
+    from iwae_amd.optimizers import Adam
+    lw = np.random.default_rng(0).standard_normal((5, 3)) * 30
+    ref = np.log(np.mean(np.exp(lw - lw.max(0)), 0)) + lw.max(0)
+    np.testing.assert_allclose(utils.logmeanexp(lw, 0), ref)
+    np.random.seed(1)
+    xb = utils.bernoullisample(np.full((100, 50), 0.25))
+    assert xb.dtype == np.float32 and set(np.unique(xb)) <= {0.0, 1.0} and abs(xb.mean() - 0.25) < 0.03
+    m = utils.MyMetric()
+    m.update_state(np.array([[1.0]])); m.update_state(np.array([[3.0]]))
+    assert float(m.result()) == 2.0
+    b = utils.bias_from_mean(np.array([0.0, 0.5, 1.0]))
+    np.testing.assert_allclose(b, [-np.log(1 / 0.001 - 1), 0.0, -np.log(1 / 0.999 - 1)], rtol=1e-6)
+    opt = Adam(1e-3, epsilon=1e-4)
+    assert np.isclose(opt.learning_rate.numpy(), 1e-3)
+    opt.learning_rate.assign(5e-4)
+    assert np.isclose(float(opt.learning_rate), 5e-4)
+    with pytest.raises(ValueError):
+        Adam(1e-3)            # Keras default epsilon 1e-7 is not what the reference trains with
+
+
+def test_main_cli_flags_identical_to_reference():
+    sys.argv = ["main.py"]
+    import importlib
+    main = importlib.import_module("main")
+    a = main.parser.parse_args([])
+    assert (a.stochastic_layers, a.n_samples, a.batch_size, a.epochs, a.objective, a.gpu) == (1, 5, 20, -1, "iwae_elbo", "0")
+    a = main.parser.parse_args(["--stochastic_layers", "2", "--n_samples", "50", "--objective", "iwae_eq14", "--batch_size", "1024", "--epochs", "3", "--gpu", "1"])
+    assert a.stochastic_layers == 2 and a.objective == "iwae_eq14"
+    with pytest.raises(SystemExit):
+        main.parser.parse_args(["--objective", "nope"])
+    with pytest.raises(SystemExit):
+        main.parser.parse_args(["--stochastic_layers", "3"])
+
+
+# ---- data-parallel exchange, 2 ranks over gloo ---------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import iwae_np as O
+    from iwae_amd import parallel
+    import make_golden as MG
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, k = 8, 5
+    x, P, eps = MG.inputs(1, 16, 4, 48, B, k, 21)
+    lo, hi = parallel.shard_bounds(B, rank, world)
+    # each rank: mean-over-its-shard gradient (what iwae_forward_backward leaves on the device)
+    _, g = O.loss_grads_1layer(P, x[lo:hi], eps[:, lo:hi], 1.0, "iwae_elbo")
+    flat = torch.tensor(O.flatten_grads(g))
+    parallel.allreduce_sum_(flat)
+    flat = flat / world                       # grad_scale = 1/world in iwae_adam_step
+    p1, _, _ = O.adam_update(O.flatten_params(P), flat.numpy(), 0.0, 0.0, 1, 1e-3)
+    if rank == 0:
+        _, gfull = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo")
+        pf, _, _ = O.adam_update(O.flatten_params(P), O.flatten_grads(gfull), 0.0, 0.0, 1, 1e-3)
+        q.put((float(np.max(np.abs(flat.numpy() - O.flatten_grads(gfull)))), float(np.max(np.abs(p1 - pf)))))
+    # replicas stay identical
+    t = torch.tensor(p1)
+    lst = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(lst, t)
+    assert all(torch.equal(lst[0], o) for o in lst)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gerr, perr = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert gerr < 1e-12 and perr < 1e-12
+
+
+def test_shard_bounds():
+    from iwae_amd import parallel
+    assert [parallel.shard_bounds(8192, r, 8) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
+    with pytest.raises(ValueError):
+        parallel.shard_bounds(10, 0, 4)

@@ -1,0 +1,122 @@
+"""CPU tests of the oracle: closed-form backward vs autograd, golden-fixture regression, the noise
+generator's published known-answer vectors, Keras-form Adam, bf16 rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import iwae_np as O, iwae_torch as T, philox_np
+import make_golden as MG
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _max_rel(ga, gb):
+    return max(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300) for (aw, ab), (bw, bb) in zip(ga, gb) for a, b in ((aw, bw), (ab, bb)))
+
+
+@pytest.mark.parametrize("objective", ["vae_elbo", "iwae_elbo", "iwae_eq14", "vae_elbo_kl", "dreg"])
+def test_closed_form_backward_matches_autograd_1layer(objective):
+    x, P, eps = MG.inputs(1, 16, 4, 48, 5, 7, 3)
+    r1, g1 = O.loss_grads_1layer(P, x, eps, 0.7, objective)
+    r2, g2 = T.loss_grads(P, x, eps, 0.7, objective, 1)
+    assert _max_rel(g1, g2) < 1e-11
+    for k in r1:
+        if k in r2:
+            np.testing.assert_allclose(r1[k], r2[k], rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("objective", ["vae_elbo", "iwae_elbo", "iwae_eq14"])
+def test_closed_form_backward_matches_autograd_2layer(objective):
+    x, P, eps = MG.inputs(2, [16, 8], [4, 2], 48, 4, 6, 4)
+    r1, g1 = O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, objective)
+    r2, g2 = T.loss_grads(P, x, eps, 1.0, objective, 2)
+    assert _max_rel(g1, g2) < 1e-11
+    for k in r1:
+        if k in r2:
+            np.testing.assert_allclose(r1[k], r2[k], rtol=1e-11, atol=1e-11)
+
+
+def test_2layer_has_no_vae_elbo_kl():          # src/iwae2.py:154-173: KeyError in the reference
+    x, P, eps = MG.inputs(2, [16, 8], [4, 2], 48, 2, 2, 5)
+    with pytest.raises(KeyError):
+        O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, "vae_elbo_kl")
+
+
+def test_parameter_counts_match_survey():       # 455,384 and 521,084
+    assert sum(a * b + b for _, (a, b) in O.layer_shapes(1, 200, 100)) == 455384
+    assert sum(a * b + b for _, (a, b) in O.layer_shapes(2, [200, 100], [100, 50])) == 521084
+
+
+@pytest.mark.parametrize("name", ["tiny_1layer", "tiny_2layer", "full_1layer_B8_k50", "full_1layer_B20_k1", "full_2layer_B4_k5"])
+def test_oracle_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    nl = int(g["n_layers"])
+    nh = g["n_hidden"].tolist() if nl == 2 else int(g["n_hidden"])
+    nlat = g["n_latent"].tolist() if nl == 2 else int(g["n_latent"])
+    for tag, rnd in (("exact", None), ("bf16", O.bf16_round)):
+        for obj in [str(o) for o in g["objectives"]]:
+            x, P, eps, res, gr, gflat, p1 = MG.run(nl, nh, nlat, int(g["x_dim"]), int(g["B"]), int(g["k"]), int(g["seed"]), obj, float(g["beta"]), rnd)
+            pre = "%s/%s/" % (tag, obj)
+            for key in res:
+                if pre + key in g:
+                    np.testing.assert_allclose(res[key], g[pre + key], rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(MG.grad_summary(gr), g[pre + "grad_summary"], rtol=1e-9, atol=1e-12)
+            if "x" in g:      # fixtures that carry their inputs: the regenerated inputs must be those
+                np.testing.assert_array_equal(x, g["x"])
+                np.testing.assert_allclose(O.flatten_params(P), g["params_flat"], rtol=0, atol=0)
+
+
+def test_logmeanexp_is_stable_and_exact():       # src/utils.py:6-8
+    lw = np.array([[-1000.0, -1.0], [-1001.0, -2.0], [-999.0, -3.0]])
+    out = O.logmeanexp(lw, axis=0)
+    ref0 = -999.0 + np.log((np.exp(-1.0) + np.exp(-2.0) + 1.0) / 3.0)
+    ref1 = -1.0 + np.log((1.0 + np.exp(-1.0) + np.exp(-2.0)) / 3.0)
+    np.testing.assert_allclose(out, [ref0, ref1], rtol=1e-13)
+    assert np.isclose(O.logmeanexp(np.full((7, 2), -3.25), 0), -3.25).all()      # k identical weights
+
+
+def test_keras_adam_first_steps():
+    # Keras form (epsilon outside the bias correction): after step 1, m_hat/sqrt(v_hat) = sign(g), so
+    # theta moves by lr * |g| / (|g| + eps*sqrt(1-b2)/(... )) -- checked against a hand evaluation
+    g = np.array([0.5, -2.0, 1e-5])
+    th, m, v = O.adam_update(np.zeros(3), g, 0.0, 0.0, 1, 1e-3)
+    alpha = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    ref = -alpha * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-4)
+    np.testing.assert_allclose(th, ref, rtol=1e-14)
+    th2, m2, v2 = O.adam_update(th, g, m, v, 2, 1e-3)
+    assert np.all(np.abs(th2) > np.abs(th))
+
+
+def test_learning_rate_schedule():                # main.py:44-51
+    d, epochs = O.learning_rate_schedule()
+    assert epochs == 3280
+    assert sorted(d) == [0, 1, 4, 13, 40, 121, 364, 1093]
+    np.testing.assert_allclose(d[0], 1e-3)
+    np.testing.assert_allclose(d[1093], 1e-4, rtol=1e-12)
+
+
+def test_bf16_round_matches_torch():
+    a = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 37.0
+    ref = torch.tensor(a).to(torch.bfloat16).to(torch.float32).numpy()
+    np.testing.assert_array_equal(O.bf16_round(a).astype(np.float32), ref)
+
+
+def test_philox_known_answer_vectors():
+    """Random123 kat_vectors for philox4x32-10 (the published algorithm the device generator uses)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, exp in kat:
+        r = philox_np.philox4x32_10(*[np.uint32(v) for v in c], *k)
+        assert tuple(int(v) for v in r) == exp
+
+
+def test_device_eps_is_standard_normal_and_split_invariant():
+    e = philox_np.device_eps(123, 5, 64, 50, 100)
+    assert e.shape == (50, 64, 100)
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1.0) < 0.01
+    # rows are keyed by the global image index: a shard with batch_offset reproduces the slice
+    e2 = philox_np.device_eps(123, 5, 16, 50, 100, batch_offset=32)
+    np.testing.assert_array_equal(e[:, 32:48], e2)

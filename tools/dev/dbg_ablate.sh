@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for F in 0 1 2 3 4 8 16 32 64 20 127; do
-  IWAE_DEBUG_FLAGS=$F timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abl/f$F -- python3 $R/tests/dbg_time.py 1024 50 1 ${STEPS:-60} > $R/gpurun_out/abl_f$F.log 2>&1 || echo "flag $F failed"
+  IWAE_DEBUG_FLAGS=$F timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abl/f$F -- python3 $R/tools/dev/dbg_time.py 1024 50 1 ${STEPS:-60} > $R/gpurun_out/abl_f$F.log 2>&1 || echo "flag $F failed"
 done
 python3 - <<'PY'
 import csv, glob, os

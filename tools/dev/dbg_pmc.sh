@@ -9,7 +9,7 @@ P3="SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_I
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python3 $R/tests/dbg_time.py $B $K $L 10 > $R/gpurun_out/${TAG}_p$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/${TAG}_p$i -- python3 $R/tools/dev/dbg_time.py $B $K $L 10 > $R/gpurun_out/${TAG}_p$i.log 2>&1 || echo "pmc pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

@@ -3,8 +3,8 @@
 B=${1:-1024}; K=${2:-50}; L=${3:-1}; TAG=${4:-run}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 120 python3 $R/tests/dbg_time.py $B $K $L 300
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/tests/dbg_time.py $B $K $L 50 > $R/gpurun_out/prof_$TAG.log 2>&1 || echo "rocprof failed"
+timeout -k 10 120 python3 $R/tools/dev/dbg_time.py $B $K $L 300
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/tools/dev/dbg_time.py $B $K $L 50 > $R/gpurun_out/prof_$TAG.log 2>&1 || echo "rocprof failed"
 python3 - <<PY
 import csv, glob
 fs = glob.glob('$R/gpurun_out/prof_$TAG/*/*kernel_trace.csv')

@@ -1,7 +1,7 @@
 """Developer script (GPU box): phase cycle shares inside out_bwd (diagnostic STAMPS build)."""
 import os, sys
 os.environ["IWAE_STAMPS"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import iwae_np as O
 from iwae_amd.native import NativeModel

@@ -1,6 +1,6 @@
 """Developer script (GPU box): quick step timing at the C2 shape. Not a pytest."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import iwae_np as O
 from iwae_amd.native import NativeModel
