@@ -3,7 +3,8 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+# -fno-slp-vectorize: packed v_pk_*_f32 next to MFMAs costs more issue slots than it saves (plus v_mov shuffles)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize"
 $HIPCC $FLAGS -c kernels.hip -o kernels.o
 $HIPCC $FLAGS -c model.hip -o model.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libiwae_amd.so kernels.o model.o

@@ -9,6 +9,7 @@
 //   adam_kernel                      Adam(eps=1e-4)           main.py:93, src/iwae1.py:160
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kernels.h"
 #include "layout.h"
 
@@ -85,8 +86,8 @@ __device__ __forceinline__ void wait_all_vmem() {
 // A-fragment stream with P ds_read_b128 in flight: rd(i) -> uint4, use(i, frag).  Without this the
 // compiler emits read -> lgkmcnt(0) -> 2 MFMA per fragment and a lone wave pays the LDS latency
 // (~64-128 cycles) for every 32 cycles of MFMA.
-template <int N, int P, class RD, class USE>
-__device__ __forceinline__ void lds_pipeline(RD rd, USE use) {
+template <int N, int P, class RD, class USE, class SIDE>
+__device__ __forceinline__ void lds_pipeline(RD rd, USE use, SIDE side) {
     uint4 av[P];
 #pragma unroll
     for (int i = 0; i < P; ++i)
@@ -95,7 +96,12 @@ __device__ __forceinline__ void lds_pipeline(RD rd, USE use) {
     for (int i = 0; i < N; ++i) {
         use(i, av[i % P]);
         if (i + P < N) av[i % P] = rd(i + P);
+        side(i);       // e.g. one LDS-DMA piece of the NEXT group: drains under the MFMAs instead of in front of them
     }
+}
+template <int N, int P, class RD, class USE>
+__device__ __forceinline__ void lds_pipeline(RD rd, USE use) {
+    lds_pipeline<N, P>(rd, use, [](int) {});
 }
 
 // ---------------------------------------------------------------------------------
@@ -190,6 +196,16 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
         const int bytes = nks * 4096 + ((kw == nkw - 1) ? 1024 : 0);   // last window carries the bias block
         stage_image<4>(a.img + (size_t)mg * gbytes + (size_t)kw * 8 * 4096, smem + buf * DENSE_UNIT, bytes, wave, lane);
     };
+    // compile-time shapes: the group is NPC 1 KiB DMA pieces, wave w moves pieces w, w+4, ...; they are issued
+    // one at a time between the MFMAs of the previous group (the per-CU L2->LDS rate, ~60-70 GB/s, is what a
+    // lump of 29 pieces in front of the MFMAs would wait for)
+    constexpr int NPC = (KTC ? KTC : 1) * 4 + 1, NIDXC = (NPC + 3) / 4;
+    auto dma_piece = [&](int unit, int buf, int idx) {
+        const int p = wave + 4 * idx;                 // wave-uniform
+        if (p < NPC)
+            glds16(a.img + (size_t)(mg0 + unit) * gbytes + (size_t)p * 1024 + lane * 16,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * DENSE_UNIT) + (uint32_t)p * 1024u)));
+    };
 
     // EPI_BERN state
     float rowacc[2] = {0.0f, 0.0f};
@@ -258,7 +274,8 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
             if (nkw > 1) load_b(kw);
             wait_all_vmem();
             __syncthreads();
-            if (unit + 1 < nunits) stage(unit + 1, buf ^ 1);
+            const bool more = unit + 1 < nunits;
+            if (!KTC && more) stage(unit + 1, buf ^ 1);
             if (kw == 0) {
                 emit_stores();
                 if (kPre && mg + 1 < mg1) load_pre(mg + 1, pre_n);
@@ -267,12 +284,18 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
             const char* lb = smem + buf * DENSE_UNIT + a_off;
             lbias = smem + buf * DENSE_UNIT + nks * 4096;
             if (KTC) {
-                lds_pipeline<(KTC ? KTC : 1) * 4, 8>(
+                constexpr int NF = (KTC ? KTC : 1) * 4, STEP = NF / NIDXC > 0 ? NF / NIDXC : 1;
+                lds_pipeline<NF, 8>(
                     [&](int i) { return *(const uint4*)(lb + i * 1024); },
                     [&](int i, const uint4& av) {
 #pragma unroll
                         for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, bfr[i >> 2][g], acc[i & 3][g]);
-                    });
+                    },
+                    [&](int i) { if (more && i % STEP == 0 && i / STEP < NIDXC) dma_piece(unit + 1, buf ^ 1, i / STEP); });
+                if (more) {
+#pragma unroll
+                    for (int idx = (NF + STEP - 1) / STEP; idx < NIDXC; ++idx) dma_piece(unit + 1, buf ^ 1, idx);
+                }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
@@ -338,22 +361,26 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
             }
         } else if (EPI == EPI_BERN) {
             // log p(x|z) = sum_j x_j l_j - softplus(l_j), softplus(l) = max(l,0) + ln2*log2(1 + 2^(-|l| log2e))  (iwae1.py:111)
-            const bool full = 64 * mg + 64 <= a.Xdim;     // wave-uniform: only the last pixel group needs masks
+            // wave-uniform branch: only the last pixel group needs masks
+            auto bern_body = [&](auto masked) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
-                        const float lg = log2_raw(1.0f + exp2_raw(-fabsf(l) * LOG2E_F));
-                        float term = fmaf(bf_at(pre[p][g], j), l, -fmaxf(l, 0.0f));
-                        term = fmaf(-LN2_F, lg, term);
-                        if (!full) term = (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? term : 0.0f;
-                        rowacc[g] += term;
+                        for (int j = 0; j < 8; ++j) {
+                            const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                            const float lg = log2_raw(1.0f + exp2_raw(-fabsf(l) * LOG2E_F));
+                            float term = fmaf(bf_at(pre[p][g], j), l, -fmaxf(l, 0.0f));
+                            term = fmaf(-LN2_F, lg, term);
+                            if (decltype(masked)::value) term = (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? term : 0.0f;
+                            rowacc[g] += term;
+                        }
                     }
                 }
-            }
+            };
+            if (64 * mg + 64 <= a.Xdim) bern_body(std::false_type{});
+            else bern_body(std::true_type{});
             if (a.logits_out) {     // rare path (the reference dict's "logits"): reference [k,B,X] order
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
@@ -532,25 +559,28 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
         for (int t = 0; t < 4; ++t) bias4[t] = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
         auto bias_of = [&](int t, int i) { return i == 0 ? bias4[t].x : i == 1 ? bias4[t].y : i == 2 ? bias4[t].z : bias4[t].w; };
 
-        const bool full = 64 * ng + 64 <= a.Xdim;    // wave-uniform
         uint4 bf2[2][2];
+        auto dl_body = [&](auto masked) {       // wave-uniform branch: only the last pixel group needs masks
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            float v[2][8];
+            for (int p = 0; p < 2; ++p) {
+                float v[2][8];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < 2; ++g) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
-                    float d = gx[g] * (bf_at(xv[p][g], j) - sigmoid_fast(l));     // d lpxz / d l = x - sigmoid(l)
-                    if (!full) d = (64 * ng + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? d : 0.0f;
-                    v[g][j] = d;
+                    for (int j = 0; j < 8; ++j) {
+                        const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                        float d = gx[g] * (bf_at(xv[p][g], j) - sigmoid_fast(l));     // d lpxz / d l = x - sigmoid(l)
+                        if (decltype(masked)::value) d = (64 * ng + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? d : 0.0f;
+                        v[g][j] = d;
+                    }
+                    bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
                 }
-                bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
-            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) stT[p][j] = pack2(v[0][j], v[1][j]);
-        }
+                for (int j = 0; j < 8; ++j) stT[p][j] = pack2(v[0][j], v[1][j]);
+            }
+        };
+        if (64 * ng + 64 <= a.Xdim) dl_body(std::false_type{});
+        else dl_body(std::true_type{});
         st_ng = ng;
         OB_STAMP(5)   // epilogue math
 
@@ -613,6 +643,215 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// out_bwd_pair_kernel: same maths as out_bwd_kernel, restructured so that two waves per SIMD fit.
+// 8 waves = 4 PAIRS; both waves of a pair own the same 32 data rows.  Per 64-pixel group wave
+// `half` (0/1) of the pair
+//   * recomputes the logits of pixels [32*half, 32*half+32) of the group and turns them into dl,
+//   * publishes its two bf16 dl fragments (2 x 1 KiB) in LDS and picks up its partner's,
+//   * accumulates dg2 for hidden tiles [KTC*half, KTC*half + KTC) over all 64 pixels.
+// Registers per wave: 56 (g2) + 16 + 56 (dg2 half) + ~50 instead of ~350, so DMA issue, MFMA and
+// the sigmoid epilogue of the two co-resident waves overlap.
+// ---------------------------------------------------------------------------------
+template <int KTC, bool STAMPS>
+__global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int KT = KTC, MT2 = 2 * KTC, MH = KTC;
+    constexpr int u1 = KT * 4096 + 1024;           // W^T group incl. its bias block
+    constexpr int unit = u1 + 2 * MT2 * 1024;      // + W k-group
+    char* const xch = smem + 2 * unit;             // [pair 4][half 2][g 2][1 KiB] dl fragments
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave >> 1, half = wave & 1;
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + pair) * 32;
+    int row[2], bidx[2];
+    bool valid[2];
+    float gx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        row[g] = r0 + 2 * rho + g;
+        valid[g] = row[g] < a.M;
+        bidx[g] = valid[g] ? row[g] / a.k : 0;
+        gx[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+    }
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
+
+    // the two weight images of a group are one contiguous LDS unit of NP 1 KiB DMA pieces; wave w moves
+    // pieces w, w+8, ...  Piece i of the next group is issued between the MFMAs of the current one.
+    constexpr int NP1 = u1 / 1024, NP = unit / 1024;
+    auto dma_piece = [&](int ng, int buf, int idx) {
+        const int p = wave + 8 * idx;                 // wave-uniform
+        if (p < NP) {
+            const char* src = (p < NP1) ? a.img1 + (size_t)ng * u1 + (size_t)p * 1024
+                                        : a.img2 + (size_t)ng * 2 * MT2 * 1024 + (size_t)(p - NP1) * 1024;
+            glds16(src + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * unit) + (uint32_t)p * 1024u)));
+        }
+    };
+    constexpr int NIDX = (NP + 7) / 8;
+    auto stage = [&](int ng, int buf) {
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) dma_piece(ng, buf, idx);
+    };
+    auto load_x = [&](int ng, uint4 (&xv)[2]) {
+        const int fbase = 64 * ng + 32 * half;      // wave-uniform guard; invalid rows read image 0, zeroed by gx = 0
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            xv[g] = make_uint4(0, 0, 0, 0);
+            if (fbase < a.Xp32) xv[g] = *(const uint4*)(a.XB + (size_t)bidx[g] * a.ldXB + fbase + 8 * q);
+        }
+    };
+    stage(0, 0);
+
+    uint4 bfr[KT][2];
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 v = *(const uint4*)(a.G2 + (size_t)min(row[g], a.M - 1) * a.ldG + ks * 32 + q * 8);
+            if (!valid[g]) v = make_uint4(0, 0, 0, 0);
+            bfr[ks][g] = v;
+        }
+    uint4 xv[2], xv_n[2];
+    load_x(0, xv);
+
+    f32x4 acc2[MH][2];
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    uint32_t stT[8];
+    int st_ng = -1;
+    auto emit_stores = [&]() {
+        if (st_ng < 0) return;
+        const int fbase = 64 * st_ng + 32 * half;
+        if (fbase < a.Xp32) {
+            char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[j];
+        }
+        st_ng = -1;
+    };
+
+    OB_STAMP(0)
+    for (int ng = 0; ng < a.NG; ++ng) {
+        const int buf = ng & 1;
+        wait_all_vmem();
+        OB_STAMP(1)
+        __syncthreads();
+        OB_STAMP(2)
+        const bool more = ng + 1 < a.NG;
+        emit_stores();
+        if (more) load_x(ng + 1, xv_n);
+        OB_STAMP(3)
+        const char* l1 = smem + buf * unit + a_off + (2 * half) * 1024;          // this half's two pixel tiles
+        const char* lbias = smem + buf * unit + KT * 4096 + (32 * half) * 4;
+        const char* l2 = smem + buf * unit + u1 + a_off + (MH * half) * 1024;    // this half's hidden tiles
+
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        lds_pipeline<KT * 2, 8>(
+            [&](int i) { return *(const uint4*)(l1 + ((i >> 1) * 4 + (i & 1)) * 1024); },
+            [&](int i, const uint4& av) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc[i & 1][g] = mfma16(av, bfr[i >> 1][g], acc[i & 1][g]);
+            },
+            [&](int i) { if (more && (i & 1) == 0 && (i >> 1) < NIDX) dma_piece(ng + 1, buf ^ 1, i >> 1); });
+        if (more) {
+#pragma unroll
+            for (int idx = KT; idx < NIDX; ++idx) dma_piece(ng + 1, buf ^ 1, idx);
+        }
+        OB_STAMP(4)
+        float4 bias4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bias4[t] = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
+        auto bias_of = [&](int t, int i) { return i == 0 ? bias4[t].x : i == 1 ? bias4[t].y : i == 2 ? bias4[t].z : bias4[t].w; };
+
+        uint4 own[2];
+        auto dl_body = [&](auto masked) {       // wave-uniform branch: only the last pixel group needs masks
+            float v[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float l = acc[j >> 2][g][j & 3] + bias_of(j >> 2, j & 3);
+                    float d = gx[g] * (bf_at(xv[g], j) - sigmoid_fast(l));     // d lpxz / d l = x - sigmoid(l)
+                    if (decltype(masked)::value) d = (64 * ng + 32 * half + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? d : 0.0f;
+                    v[g][j] = d;
+                }
+                own[g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stT[j] = pack2(v[0][j], v[1][j]);
+        };
+        if (64 * ng + 32 * half + 32 <= a.Xdim) dl_body(std::false_type{});
+        else dl_body(std::true_type{});
+        st_ng = ng;
+
+        OB_STAMP(5)
+        // exchange the dl fragments inside the pair
+#pragma unroll
+        for (int g = 0; g < 2; ++g) *(uint4*)(xch + ((pair * 2 + half) * 2 + g) * 1024 + lane * 16) = own[g];
+        __syncthreads();
+        uint4 bf2[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint4 other = *(const uint4*)(xch + ((pair * 2 + (half ^ 1)) * 2 + g) * 1024 + lane * 16);
+            bf2[0][g] = half ? other : own[g];       // selects, not runtime-indexed arrays (those go to scratch)
+            bf2[1][g] = half ? own[g] : other;
+        }
+
+        lds_pipeline<2 * MH, 8>(
+            [&](int i) { return *(const uint4*)(l2 + ((i / MH) * MT2 + (i % MH)) * 1024); },
+            [&](int i, const uint4& av) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc2[i % MH][g] = mfma16(av, (i / MH) ? bf2[1][g] : bf2[0][g], acc2[i % MH][g]);
+            });
+#pragma unroll
+        for (int g = 0; g < 2; ++g) xv[g] = xv_n[g];
+        OB_STAMP(6)
+    }
+    emit_stores();
+
+    // dpre2 = dg2 * (1 - g2^2) for this half's hidden tiles; tile mt = MH*half + t  <->  (ks = mt>>1, h = mt&1)
+#pragma unroll
+    for (int t = 0; t < MH; ++t) {
+        const int mt = MH * half + t;      // wave-uniform
+        float v[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 gsel = bfr[0][g];
+#pragma unroll
+            for (int ks = 1; ks < KT; ++ks)
+                if ((mt >> 1) == ks) gsel = bfr[ks][g];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float y0 = bf_at(gsel, i), y1 = bf_at(gsel, 4 + i);
+                const float y = (mt & 1) ? y1 : y0;
+                v[g][i] = acc2[t][g][i] * (1.0f - y * y);
+            }
+            if (valid[g])
+                *(uint2*)(a.DPP + (size_t)row[g] * a.ldG + (mt >> 1) * 32 + 8 * q + 4 * (mt & 1)) = make_uint2(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]));
+        }
+        char* tb = (char*)a.DPT + (size_t)(mt * 16) * a.ldT * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *(uint32_t*)(tb + (size_t)i * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][i] : 0.0f, valid[1] ? v[1][i] : 0.0f);
+    }
+    OB_STAMP(7)
+    if (STAMPS && a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // wgrad_kernel: dW[i][j] (+db[j]) partial sums over a range of data rows.
 //   out[i][j] = sum_r AT[i][r] * GT[j][r]      (both operands T-layout, r contiguous)
 // grid = (j-blocks of 128, i-blocks of 256, row splits); 8 waves, wave w owns j-tile w of the
@@ -667,7 +906,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
         const int buf = c & 1;
         wait_all_vmem();
         __syncthreads();
-        if (c + 1 < nchunk) { stage(c + 1, buf ^ 1); load_g(c + 1, gnext); }
+        const bool more = c + 1 < nchunk;
+        if (more) load_g(c + 1, gnext);
+        // the next chunk's A tile is DMA'd piece by piece between the MFMAs below (blk = wave + 8*idx)
+        int dma_idx = 0;
+        auto dma_next = [&]() {
+            const int blk = wave + 8 * dma_idx;       // wave-uniform
+            if (more && blk < 4 * nit) {
+                const int rs = blk / nit, it = blk - rs * nit, r = rbeg + (c + 1) * 128;
+                const char* src = (const char*)a.AT + ((size_t)(it0 + it) * 16 * a.Mp + (size_t)(r + rs * 32)) * 2 + asrc_lane;
+                glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (buf ^ 1) * 65536) + (uint32_t)(rs * 16 + it) * 1024u)));
+            }
+            ++dma_idx;
+        };
         const char* lb = smem + buf * 65536 + a_off;
 #pragma unroll
         for (int rs = 0; rs < 4; ++rs) {
@@ -675,19 +926,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
             bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
             if (nit == 14) {          // hidden width 200 -> 224: straight-line, pipelined LDS reads
                 lds_pipeline<14, 7>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+                                    [&](int i) { if (i == 0 || i == 7) dma_next(); });
             } else if (nit == 16) {
                 lds_pipeline<16, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+                                    [&](int i) { if (i == 0 || i == 8) dma_next(); });
             } else if (nit == 8) {
                 lds_pipeline<8, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                   [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); });
+                                   [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+                                   [&](int i) { if (i == 0) dma_next(); });
             } else {
+                dma_next();
+                dma_next();
 #pragma unroll
                 for (int it = 0; it < 16; ++it)
                     if (it < nit) acc[it] = mfma16(*(const uint4*)(lb + (rs * 16 + it) * 1024), g, acc[it]);
             }
         }
+        while (dma_idx < 8) dma_next();      // 4*nit <= 64 pieces = 8 per wave
 #pragma unroll
         for (int rs = 0; rs < 4; ++rs) gcur[rs] = gnext[rs];
     }
@@ -1203,12 +1460,14 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     const size_t lds = 2 * ((size_t)a.KT * 8192 + 1024);
     dim3 grid((a.M + 127) / 128);
     if (a.stamps) {   // diagnostic build
-        hipLaunchKernelGGL((out_bwd_kernel<7, true>), grid, dim3(256), lds, st, a);
+        hipLaunchKernelGGL((out_bwd_pair_kernel<7, true>), grid, dim3(512), lds + 16384, st, a);
         return;
     }
+    const size_t lds2 = lds + 16384;     // + dl exchange area of the pair kernel
     switch (a.KT) {
-        case 7: hipLaunchKernelGGL((out_bwd_kernel<7, false>), grid, dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((out_bwd_kernel<4, false>), grid, dim3(256), lds, st, a); break;
+        case 7: hipLaunchKernelGGL((out_bwd_pair_kernel<7, false>), grid, dim3(512), lds2, st, a); break;
+        case 4: hipLaunchKernelGGL((out_bwd_pair_kernel<4, false>), grid, dim3(512), lds2, st, a); break;
+        case 2: hipLaunchKernelGGL((out_bwd_pair_kernel<2, false>), grid, dim3(512), lds2, st, a); break;
         default: hipLaunchKernelGGL((out_bwd_kernel<0, false>), grid, dim3(256), lds, st, a); break;
     }
 }
