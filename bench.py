@@ -151,7 +151,7 @@ def main():
                        "global_batch": B_PER_GPU * world, "n_samples": K_SAMPLES, "parallelism": "dp%d" % world,
                        "step_gemm_tflops": round(FLOP_PER_STEP * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3)},
-            "roofline": {"bound": "mfma", "kernel": "out_bwd_kernel<7> (decoder output-layer backward, logits recomputed)",
+            "roofline": {"bound": "mfma", "kernel": "out_bwd_pair_kernel<7> (decoder output-layer backward, logits recomputed)",
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_us": round(ob_us, 2), "launches": ob_n, "flop_per_launch": FLOP_OUT_BWD},

@@ -115,7 +115,7 @@ struct LayerDesc {
 
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
-void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st);
+void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st);
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st);
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);

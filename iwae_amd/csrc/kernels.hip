@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <algorithm>
 #include "kernels.h"
 #include "layout.h"
 
@@ -860,111 +861,131 @@ __global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
 // the LDS image stays lane-linear), double buffered; each wave's own G fragments are loaded a
 // chunk ahead.  Partials go to fp32 slabs (deterministic, no atomics).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
+template <int JW, int NW>     // JW j-tiles per wave, NW waves: the block covers NW*JW j-tiles, A is re-read JT/(NW*JW) times
+__global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 x [rs 4][it 16][1 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rho = lane & 15, q = lane >> 4;
     const int it0 = blockIdx.y * 16;
     const int nit = min(16, a.IT - it0);
-    const int jt = blockIdx.x * 8 + wave;
-    const bool jvalid = jt < a.JT;
-    const int jtc = min(jt, a.JT - 1);
     const int split = blockIdx.z;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.Mp, rbeg + a.rows_per_split);
     const int nchunk = (rend - rbeg + 127) / 128;
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    int jt[JW];
+    bool jvalid[JW];
+    size_t gsrc_lane[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) {
+        jt[w] = (blockIdx.x * NW + wave) * JW + w;
+        jvalid[w] = jt[w] < a.JT;
+        gsrc_lane[w] = ((size_t)(min(jt[w], a.JT - 1) * 16 + rho) * a.Mp + (size_t)q * 8) * 2;
+    }
     // DMA source of this lane inside a 16-feature x 32-row fragment block: LDS slot (lane&3) of
     // feature row (lane>>2) must receive the rows 8*q_src .. 8*q_src+7
     const int di = lane >> 2, dq = (lane & 3) ^ hperm((lane >> 2) >> 2);
     const size_t asrc_lane = ((size_t)di * a.Mp + (size_t)dq * 8) * 2;
-    const size_t gsrc_lane = ((size_t)(jtc * 16 + rho) * a.Mp + (size_t)q * 8) * 2;
 
-    auto stage = [&](int c, int buf) {
-        const int r = rbeg + c * 128;
-        const uint32_t lbase = lds_addr_of(smem + buf * 65536);
-        for (int blk = wave; blk < 4 * nit; blk += 8) {     // blk = rs * nit + it  (wave-uniform)
-            const int rs = blk / nit, it = blk - rs * nit;
+    auto load_g1 = [&](int c, int w, int rs) {
+        return *(const uint4*)((const char*)a.GT + gsrc_lane[w] + (size_t)(rbeg + c * 128 + rs * 32) * 2);
+    };
+    auto dma_piece = [&](int c, int buf, int idx) {
+        const int blk = wave + NW * idx;      // blk = rs * nit + it  (wave-uniform)
+        if (blk < 4 * nit) {
+            const int rs = blk / nit, it = blk - rs * nit, r = rbeg + c * 128;
             const char* src = (const char*)a.AT + ((size_t)(it0 + it) * 16 * a.Mp + (size_t)(r + rs * 32)) * 2 + asrc_lane;
-            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lbase + (uint32_t)(rs * 16 + it) * 1024u)));
+            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * 65536) + (uint32_t)(rs * 16 + it) * 1024u)));
         }
     };
-    auto load_g = [&](int c, uint4 (&g)[4]) {
-        const int r = rbeg + c * 128;
-#pragma unroll
-        for (int rs = 0; rs < 4; ++rs) g[rs] = *(const uint4*)((const char*)a.GT + gsrc_lane + (size_t)(r + rs * 32) * 2);
-    };
 
-    f32x4 acc[16];
+    f32x4 acc[16][JW];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float bsum = 0.0f;
-    uint4 gcur[4], gnext[4];
-    if (nchunk > 0) { stage(0, 0); load_g(0, gcur); }
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int w = 0; w < JW; ++w) acc[t][w] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) bsum[w] = 0.0f;
+    uint4 gcur[JW][4];     // G fragments of the current chunk; refilled in place for the next one as soon as a row-step is done
+    if (nchunk > 0) {
+#pragma unroll
+        for (int idx = 0; idx < 64 / NW; ++idx) dma_piece(0, 0, idx);
+#pragma unroll
+        for (int w = 0; w < JW; ++w)
+#pragma unroll
+            for (int rs = 0; rs < 4; ++rs) gcur[w][rs] = load_g1(0, w, rs);
+    }
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         wait_all_vmem();
         __syncthreads();
         const bool more = c + 1 < nchunk;
-        if (more) load_g(c + 1, gnext);
-        // the next chunk's A tile is DMA'd piece by piece between the MFMAs below (blk = wave + 8*idx)
+        // the next chunk's A tile is DMA'd piece by piece between the MFMAs below
         int dma_idx = 0;
         auto dma_next = [&]() {
-            const int blk = wave + 8 * dma_idx;       // wave-uniform
-            if (more && blk < 4 * nit) {
-                const int rs = blk / nit, it = blk - rs * nit, r = rbeg + (c + 1) * 128;
-                const char* src = (const char*)a.AT + ((size_t)(it0 + it) * 16 * a.Mp + (size_t)(r + rs * 32)) * 2 + asrc_lane;
-                glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (buf ^ 1) * 65536) + (uint32_t)(rs * 16 + it) * 1024u)));
-            }
+            if (more) dma_piece(c + 1, buf ^ 1, dma_idx);
             ++dma_idx;
         };
         const char* lb = smem + buf * 65536 + a_off;
 #pragma unroll
         for (int rs = 0; rs < 4; ++rs) {
-            const uint4 g = gcur[rs];
-            bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
-            if (nit == 14) {          // hidden width 200 -> 224: straight-line, pipelined LDS reads
-                lds_pipeline<14, 7>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+#pragma unroll
+            for (int w = 0; w < JW; ++w) {
+                const uint4 g = gcur[w][rs];
+                bsum[w] += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
+            }
+            auto use = [&](int i, const uint4& av) {
+#pragma unroll
+                for (int w = 0; w < JW; ++w) acc[i][w] = mfma16(av, gcur[w][rs], acc[i][w]);
+            };
+            if (NW == 16) {           // one code path keeps the 128-register budget of the 16-wave block
+                lds_pipeline<16, 3>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
+                                    [&](int i, const uint4& av) { if (i < nit) use(i, av); },
+                                    [&](int i) { if (i == 0) dma_next(); });
+            } else if (nit == 14) {   // hidden width 200 -> 224: straight-line, pipelined LDS reads
+                lds_pipeline<14, 7>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
                                     [&](int i) { if (i == 0 || i == 7) dma_next(); });
             } else if (nit == 16) {
-                lds_pipeline<16, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                    [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+                lds_pipeline<16, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
                                     [&](int i) { if (i == 0 || i == 8) dma_next(); });
             } else if (nit == 8) {
-                lds_pipeline<8, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                   [&](int i, const uint4& av) { acc[i] = mfma16(av, g, acc[i]); },
+                lds_pipeline<8, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
                                    [&](int i) { if (i == 0) dma_next(); });
             } else {
                 dma_next();
                 dma_next();
 #pragma unroll
                 for (int it = 0; it < 16; ++it)
-                    if (it < nit) acc[it] = mfma16(*(const uint4*)(lb + (rs * 16 + it) * 1024), g, acc[it]);
+                    if (it < nit) use(it, *(const uint4*)(lb + (rs * 16 + it) * 1024));
+            }
+            if (more) {
+#pragma unroll
+                for (int w = 0; w < JW; ++w) gcur[w][rs] = load_g1(c + 1, w, rs);
             }
         }
-        while (dma_idx < 8) dma_next();      // 4*nit <= 64 pieces = 8 per wave
-#pragma unroll
-        for (int rs = 0; rs < 4; ++rs) gcur[rs] = gnext[rs];
+        while (dma_idx < 64 / NW) dma_next();      // 4*nit <= 64 pieces
     }
 
     // D: lane(col j = rho, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
-    if (jvalid) {
-        float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+    float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+#pragma unroll
+    for (int w = 0; w < JW; ++w) {
+        if (!jvalid[w]) continue;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             if (it < nit) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
-                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + rho] = acc[it][ii];
+                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt[w] * 16 + rho] = acc[it][w][ii];
             }
         }
         if (blockIdx.y == 0) {
-            float v = bsum;
+            float v = bsum[w];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + rho] = v;
+            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt[w] * 16 + rho] = v;
         }
     }
 }
@@ -972,15 +993,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradArgs a) {
 // ---------------------------------------------------------------------------------
 // elementwise / reduction kernels
 // ---------------------------------------------------------------------------------
-// x fp32 [B][X] -> bf16 P-layout [B][Xp] and T-layout [Xp][Bp] (pads written as zero)
-__global__ void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = idx % Xp, b = idx / Xp;
+// x fp32 [B][X] -> bf16 P-layout [B][Xp] and T-layout [Xp][Bp] (pads written as zero).
+// block = 64 rows (lanes) x 4 chunk-waves; a thread converts one 8-feature P chunk of one row.
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 64 + lane;
+    const int nchunk = Xp / 8;
     if (b >= Bp) return;
-    const float v = (b < B && f < X) ? x[(size_t)b * X + f] : 0.0f;
-    const uint16_t h = (uint16_t)(pack2(v, 0.0f) & 0xffffu);
-    if (b < B) XP[(size_t)b * Xp + p_pos(f)] = h;
-    if (XT) XT[(size_t)f * Bp + b] = h;
+    for (int c = blockIdx.y * 4 + (threadIdx.x >> 6); c < nchunk; c += gridDim.y * 4) {
+        const int t = c >> 2, qq = c & 3;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f0 = 32 * t + 16 * h + 4 * qq;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * h + i] = (b < B && f0 + i < X) ? x[(size_t)b * X + f0 + i] : 0.0f;
+            if (XT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) XT[(size_t)(f0 + i) * Bp + b] = (uint16_t)(pack2(v[4 * h + i], 0.0f) & 0xffffu);
+            }
+        }
+        if (b < B) *(uint4*)(XP + (size_t)b * Xp + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
 }
 
 // z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T).
@@ -1471,12 +1505,14 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
         default: hipLaunchKernelGGL((out_bwd_kernel<0, false>), grid, dim3(256), lds, st, a); break;
     }
 }
-void launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
-    dim3 grid((a.JT + 7) / 8, (a.IT + 15) / 16, nsplit);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(512), 131072, st, a);
+void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st) {      // jw = 2: 16-wave blocks (256 out-features)
+    dim3 grid((a.JT + 8 * jw - 1) / (8 * jw), (a.IT + 15) / 16, nsplit);
+    if (jw == 2) hipLaunchKernelGGL((wgrad_kernel<1, 16>), grid, dim3(1024), 131072, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, 8>), grid, dim3(512), 131072, st, a);
 }
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
-    hipLaunchKernelGGL(prep_rows_kernel, grid1((size_t)Bp * Xp, 256), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
+    const int nchunk = Xp / 8;
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3(a.Mp / 64), dim3(64 * (a.Dp / 8)), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }

@@ -338,7 +338,10 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R,
 // ---------------------------------------------------------------- backward pieces
 int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp) {
     const int chunks = Rp / 128;
-    const int blocks = ((L.JT + 7) / 8) * ((L.IT + 15) / 16);
+    // wide j-blocks (256 out-features per block) halve the re-reads of the A operand; worth it once the
+    // row count is large enough to fill the chip with row splits
+    const int jw = (chunks >= 64 && L.JT >= 32) ? 2 : 1;
+    const int blocks = ((L.JT + 8 * jw - 1) / (8 * jw)) * ((L.IT + 15) / 16);
     int nsplit = std::max(1, std::min(chunks, 256 / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
@@ -350,7 +353,7 @@ int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int 
     WgradArgs a;
     a.AT = AT; a.IT = L.IT; a.GT = GT; a.JT = L.JT; a.Mp = Rp; a.rows_per_split = cps * 128;
     a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB);
-    launch_wgrad(a, nsplit, m->stream);
+    launch_wgrad(a, nsplit, jw, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -430,7 +433,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = ptr<uint16_t>(m->zT[0]); s.ldT = Mp;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
-        s.lq_dreg = two ? nullptr : lqd;   // tasks/task02.py:63-65 (cheap; always available)
+        const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
+        s.lq_dreg = want_dreg ? lqd : nullptr;
         launch_sample(s, st);
     }
     if (two) {
@@ -508,7 +512,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.head = nullptr;
             a.cz_on = 0.f;
         }
-        a.lq_dreg = two ? nullptr : lqd;
+        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
         a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
