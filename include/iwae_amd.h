@@ -134,6 +134,18 @@ int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t c
 /* IWAE.sample(z): decoder only, src/iwae1.py:168-178 (z [n,D_last]) -> probs [n, x_dim] */
 int iwae_decode(iwae_handle h, const float* z, int32_t n, float* probs);
 
+/* Data pipeline on the device (main.py:59-65,117-120 + src/utils.py:26-27): the grey-level training set
+ * stays resident in HBM as uint8 [n, x_dim]; every epoch gets a visiting order (tf.data shuffle) and a
+ * fresh dynamic binarisation, x = 1 iff (philox(seed, epoch, image, pixel/4) >> 8) < floor(g*2^24/255 + 0.5),
+ * i.e. Bernoulli(g/255), one draw per image per epoch like the reference's per-epoch bernoullisample.
+ * iwae_train_step_dataset takes rows [start, start+B) of the current order; gather + binarise are fused
+ * into the input kernel, no host traffic.  iwae_dataset_get_batch returns the same batch for inspection. */
+int iwae_dataset_upload(iwae_handle h, const uint8_t* gray, int32_t n);
+int iwae_dataset_begin_epoch(iwae_handle h, uint32_t epoch, const int32_t* order /* NULL keeps the order */, int32_t n);
+int iwae_dataset_get_batch(iwae_handle h, int32_t start, int32_t B, float* x_out);
+int iwae_train_step_dataset(iwae_handle h, int32_t start, int32_t B, int32_t k, float beta, float lr, int32_t objective,
+                            iwae_scalars* scalars);
+
 /* HIP-event timing of the dominant kernels on the handle's stream (used by bench.py's roofline
  * object): enable, run steps, then read the average launch duration.  name is one of "out_bwd"
  * (decoder output layer backward), "bernoulli_fwd" (output layer + log-likelihood), "wgrad_out". */

@@ -55,6 +55,10 @@ SYMBOLS = {
     "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "iwae_eval_llh": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), _P]),
     "iwae_decode": (C.c_int, [_P, _P, C.c_int32, _P]),
+    "iwae_dataset_upload": (C.c_int, [_P, _P, C.c_int32]),
+    "iwae_dataset_begin_epoch": (C.c_int, [_P, C.c_uint32, _P, C.c_int32]),
+    "iwae_dataset_get_batch": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "iwae_train_step_dataset": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.POINTER(Scalars)]),
     "iwae_enable_timing": (C.c_int, [_P, C.c_int32]),
     "iwae_kernel_time": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "iwae_debug_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

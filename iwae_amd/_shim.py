@@ -123,6 +123,30 @@ class BaseIWAE:
         optimizer.iterations += 1
         return self._result(raw)
 
+    # ---- device-resident data pipeline (main.py:59-65,117-120 on the GPU) -----------------------
+    def set_dataset(self, X_gray):
+        """Keep the grey-level training set in HBM (uint8; float data in [0,1] is quantised to 1/255 steps)."""
+        X_gray = np.asarray(X_gray)
+        if X_gray.dtype != np.uint8:
+            X_gray = np.clip(np.rint(X_gray.reshape(X_gray.shape[0], -1) * 255.0), 0, 255).astype(np.uint8)
+        self._net.dataset_upload(X_gray.reshape(X_gray.shape[0], -1))
+
+    def begin_epoch(self, epoch, order=None):
+        """New dynamic binarisation (keyed by the epoch) and visiting order (tf.data shuffle) for this epoch."""
+        self._net.dataset_begin_epoch(epoch, order)
+
+    def train_step_dataset(self, start, batch_size, n_samples, beta, optimizer, objective="vae_elbo"):
+        if objective not in self.scalar_keys and objective != "dreg":
+            raise KeyError(objective)
+        raw = self._net.train_step_dataset(start, batch_size, int(n_samples), float(beta), float(optimizer.learning_rate), objective)
+        optimizer.iterations += 1
+        res = {k: as_tensor(raw[k]) for k in self.scalar_keys if k in raw}
+        # the means write_to_tensorboard logs (src/iwae1.py:228-232), already reduced on the device
+        names = ("lpxz1", "lpz1z2", "lpz2") if self.n_layers == 2 else ("lpxz", "lpz", "lqzx")
+        for key, src in zip(names, ("mean_lpxz", "mean_lpz", "mean_lqzx")):
+            res[key] = as_tensor(raw[src])
+        return res
+
     def eval_llh(self, x, n_samples=5000, chunk=0):
         """The test-set loop of main.py:170-184 in one call (mean of per-image iwae_elbo at B=1)."""
         return self._net.eval_llh(np.asarray(x, dtype=np.float32), n_samples, chunk)

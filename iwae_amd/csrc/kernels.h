@@ -117,6 +117,8 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st);
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st);
+void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
+                            uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf, hipStream_t st);
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
 void launch_lse(const LseArgs& a, hipStream_t st);

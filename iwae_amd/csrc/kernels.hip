@@ -1017,6 +1017,44 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, i
     }
 }
 
+// Fused batch gather + dynamic binarisation (main.py:117-120 + src/utils.py:26-27 done per batch on the
+// device): row b of the batch is image idx[start+b] of the uint8 dataset resident in HBM; pixel f is
+// 1 iff (philox(seed, epoch, image, f/4)[f%4] >> 8) < T(gray), T(g) = floor(g * 2^24 / 255 + 0.5), i.e.
+// Bernoulli(gray/255) with an integer threshold (bit-exactly reproducible on the host).  Keyed by
+// (epoch, image): one binarisation per image per epoch, as in the reference.  Same block shape and
+// outputs as prep_rows_kernel (P-layout, T-layout) + optional float32 copy.
+__global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp,
+                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 64 + lane;
+    const int nchunk = Xp / 8;
+    if (b >= Bp) return;
+    const int img = (b < B) ? order[start + b] : 0;
+    for (int c = blockIdx.y * 4 + (threadIdx.x >> 6); c < nchunk; c += gridDim.y * 4) {
+        const int t = c >> 2, qq = c & 3;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f0 = 32 * t + 16 * h + 4 * qq;
+            uint32_t r[4];
+            philox4x32_10((uint32_t)img, 0x42494E41u /* 'BINA' */, (uint32_t)(f0 >> 2), epoch, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float bit = 0.0f;
+                if (b < B && f0 + i < X) {
+                    const uint32_t g = data[(size_t)img * X + f0 + i];
+                    const uint32_t thr = (uint32_t)(((uint64_t)g * 16777216ull * 2ull + 255ull) / 510ull);   // floor(g*2^24/255 + 0.5)
+                    bit = ((r[i] >> 8) < thr) ? 1.0f : 0.0f;
+                    if (xf) xf[(size_t)b * X + f0 + i] = bit;
+                }
+                v[4 * h + i] = bit;
+                if (XT) XT[(size_t)(f0 + i) * Bp + b] = (uint16_t)(pack2(bit, 0.0f) & 0xffffu);
+            }
+        }
+        if (b < B) *(uint4*)(XP + (size_t)b * Xp + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
 // z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T).
 // block = 64 data rows (lanes) x Dp/8 waves, wave c owns the 8 features of P-layout chunk c:
 // the T-layout store is a full 128 B line per feature, the row sums go through LDS.
@@ -1513,6 +1551,12 @@ void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st) {     
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
     const int nchunk = Xp / 8;
     hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
+}
+void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
+                            uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf, hipStream_t st) {
+    const int nchunk = Xp / 8;
+    hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
+                       Bp, seed, epoch, XP, XT, xf);
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3(a.Mp / 64), dim3(64 * (a.Dp / 8)), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }

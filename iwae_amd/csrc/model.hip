@@ -95,8 +95,16 @@ struct iwae_model {
     BlockWs wenc1, wenc2, wdec2;
     MlpWs wdec1;
     DevBuf scratch;            // exports
+    // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
+    DevBuf ds_data, ds_order;
+    int ds_N = 0;
+    uint32_t ds_epoch = 0;
+    int ds_start = -1;         // >= 0: the next forward gathers + binarises rows ds_start.. from the dataset instead of reading x
     DevBuf stamps;             // diagnostic (IWAE_STAMPS=1)
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
+    // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool timing = false;
     std::vector<hipEvent_t> ev_start[3], ev_stop[3];   // 0 out_bwd, 1 bernoulli fwd, 2 wgrad(out)
     size_t ev_used[3] = {0, 0, 0};
@@ -267,18 +275,19 @@ int refresh_images(iwae_model* m) {   // rebuild bf16 A-images from the fp32 mas
 
 struct ScopedTimer {     // records a start/stop event pair around a launch when timing is enabled
     iwae_model* m; int id; bool on;
-    ScopedTimer(iwae_model* m_, int id_) : m(m_), id(id_), on(m_->timing) {
+    hipStream_t ts;
+    ScopedTimer(iwae_model* m_, int id_, hipStream_t s_ = nullptr) : m(m_), id(id_), on(m_->timing), ts(s_ ? s_ : m_->stream) {
         if (!on) return;
         if (m->ev_used[id] == m->ev_start[id].size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             m->ev_start[id].push_back(a); m->ev_stop[id].push_back(b);
         }
-        (void)hipEventRecord(m->ev_start[id][m->ev_used[id]], m->stream);
+        (void)hipEventRecord(m->ev_start[id][m->ev_used[id]], ts);
     }
     ~ScopedTimer() {
         if (!on) return;
-        (void)hipEventRecord(m->ev_stop[id][m->ev_used[id]], m->stream);
+        (void)hipEventRecord(m->ev_stop[id][m->ev_used[id]], ts);
         m->ev_used[id] += 1;
     }
 };
@@ -336,7 +345,8 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R,
 }
 
 // ---------------------------------------------------------------- backward pieces
-int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp) {
+int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp, hipStream_t st = nullptr) {
+    if (!st) st = m->stream;
     const int chunks = Rp / 128;
     // wide j-blocks (256 out-features per block) halve the re-reads of the A operand; worth it once the
     // row count is large enough to fill the chip with row splits
@@ -353,7 +363,7 @@ int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int 
     WgradArgs a;
     a.AT = AT; a.IT = L.IT; a.GT = GT; a.JT = L.JT; a.Mp = Rp; a.rows_per_split = cps * 128;
     a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB);
-    launch_wgrad(a, nsplit, jw, m->stream);
+    launch_wgrad(a, nsplit, jw, st);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -396,7 +406,8 @@ int copy_out(iwae_model* m, void* dst, const void* src, size_t bytes) {
 // ---------------------------------------------------------------- the forward pass
 int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd,
                  const iwae_tensors* want) {
-    if (!x || B <= 0 || k <= 0) return fail(IWAE_ERR_ARG, "forward: need x, B > 0, k > 0");
+    const bool from_ds = m->ds_start >= 0;
+    if ((!x && !from_ds) || B <= 0 || k <= 0) return fail(IWAE_ERR_ARG, "forward: need x, B > 0, k > 0");
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
@@ -405,10 +416,17 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     hipStream_t st = m->stream;
     m->user_eps = eps != nullptr;
     if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
-    CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
     CHK(ensure(m->xP, (size_t)Bp * Xp * 2, st));
     CHK(ensure(m->xT, (size_t)Bp * Xp * 2, st));
-    launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), st);
+    if (from_ds) {
+        // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
+        launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xp, Bp, m->cfg.seed,
+                               m->ds_epoch, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), nullptr, st);
+        m->ds_start = -1;
+    } else {
+        CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
+        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), st);
+    }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
     CHK(block_alloc(m, m->enc1, m->wenc1, B, Bp, bwd, false));
@@ -554,11 +572,16 @@ int backward_impl(iwae_model* m, int objective) {
             { ScopedTimer tm(m, 0); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
-    { ScopedTimer tm(m, 2); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp)); }
+    // slabs must exist before the fork (ensure() may synchronise / reallocate): size them on the main stream
+    // by running the decoder weight gradients on the side stream, ordered behind the producers by events.
     CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
-    CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp));
+    HIPCHK(hipEventRecord(m->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    { ScopedTimer tm(m, 2, m->side); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp, m->side)); }
+    CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp, m->side));
+    CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp, m->side));
+    HIPCHK(hipEventRecord(m->ev_join, m->side));
     CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, Mp, nullptr, nullptr, nullptr, ptr<float>(w.dz)));
-    CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp));
 
     const float* dz1 = ptr<float>(w.dz);
     if (two) {
@@ -598,6 +621,7 @@ int backward_impl(iwae_model* m, int objective) {
         launch_latent_bwd(a, st);
     }
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), B, Bp, false));
+    HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
     if (m->descs_dirty) CHK(build_descs(m));
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, st);
     HIPCHK(hipGetLastError());
@@ -716,6 +740,9 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     }
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     m->own_stream = true;
+    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
         add_mlp3(m, m->dec1, "dec", m->D[0], m->H[0], m->X);
@@ -763,7 +790,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->xT, &m->epsbuf, &m->zP[0], &m->zP[1], &m->zT[0], &m->zT[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->dzsum,
-                      &m->dzdir, &m->scratch};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
     for (BlockWs* w : bw) {
@@ -786,6 +813,9 @@ void iwae_destroy(iwae_handle m) {
         for (hipEvent_t e : m->ev_start[i]) (void)hipEventDestroy(e);
         for (hipEvent_t e : m->ev_stop[i]) (void)hipEventDestroy(e);
     }
+    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -974,6 +1004,58 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     HIPCHK(hipStreamSynchronize(st));
     m->have_forward = false;
     return IWAE_OK;
+}
+
+int iwae_dataset_upload(iwae_handle m, const uint8_t* gray, int32_t n) {
+    if (!m || !gray || n <= 0) return fail(IWAE_ERR_ARG, "dataset_upload: bad argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(ensure(m->ds_data, (size_t)n * m->X, m->stream));
+    CHK(ensure(m->ds_order, (size_t)n * 4, m->stream));
+    HIPCHK(hipMemcpyAsync(m->ds_data.p, gray, (size_t)n * m->X, hipMemcpyDefault, m->stream));
+    std::vector<int32_t> ident(n);
+    for (int i = 0; i < n; ++i) ident[i] = i;
+    HIPCHK(hipMemcpyAsync(m->ds_order.p, ident.data(), (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->ds_N = n;
+    m->ds_epoch = 0;
+    return IWAE_OK;
+}
+
+int iwae_dataset_begin_epoch(iwae_handle m, uint32_t epoch, const int32_t* order, int32_t n) {
+    if (!m || m->ds_N <= 0) return fail(IWAE_ERR_STATE, "dataset_begin_epoch: no dataset uploaded");
+    if (order) {
+        if (n != m->ds_N) return fail(IWAE_ERR_ARG, "dataset_begin_epoch: order must have one entry per image");
+        for (int i = 0; i < n; ++i)
+            if (order[i] < 0 || order[i] >= m->ds_N) return fail(IWAE_ERR_ARG, "dataset_begin_epoch: index out of range");
+        HIPCHK(hipMemcpyAsync(m->ds_order.p, order, (size_t)n * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    m->ds_epoch = epoch;
+    return IWAE_OK;
+}
+
+int iwae_dataset_get_batch(iwae_handle m, int32_t start, int32_t B, float* x_out) {
+    if (!m || !x_out || m->ds_N <= 0 || start < 0 || B <= 0 || start + B > m->ds_N) return fail(IWAE_ERR_ARG, "dataset_get_batch: bad range");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    const int Bp = round_up(B, 128);
+    CHK(ensure(m->xP, (size_t)Bp * m->Xp32 * 2, m->stream));
+    CHK(ensure(m->scratch, (size_t)B * m->X * 4, m->stream));
+    launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), start, m->ds_N, B, m->X, m->Xp32, Bp, m->cfg.seed, m->ds_epoch,
+                           ptr<uint16_t>(m->xP), nullptr, ptr<float>(m->scratch), m->stream);
+    HIPCHK(hipMemcpyAsync(x_out, m->scratch.p, (size_t)B * m->X * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->have_forward = false;
+    return IWAE_OK;
+}
+
+int iwae_train_step_dataset(iwae_handle m, int32_t start, int32_t B, int32_t k, float beta, float lr, int32_t objective, iwae_scalars* scalars) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    if (m->ds_N <= 0) return fail(IWAE_ERR_STATE, "train_step_dataset: no dataset uploaded");
+    if (start < 0 || B <= 0 || start + B > m->ds_N) return fail(IWAE_ERR_ARG, "train_step_dataset: batch range outside the dataset");
+    m->ds_start = start;
+    int rc = iwae_train_step(m, nullptr, B, k, beta, lr, objective, nullptr, scalars, nullptr);
+    m->ds_start = -1;
+    return rc;
 }
 
 int iwae_enable_timing(iwae_handle m, int32_t enable) {

@@ -202,6 +202,30 @@ class NativeModel:
         check(self.lib.iwae_decode(self.h, z.ctypes.data, z.shape[0], out.ctypes.data))
         return out
 
+    # ---- resident dataset (device-side shuffle order + dynamic binarisation) -------------------
+    def dataset_upload(self, gray_u8):
+        g = np.ascontiguousarray(gray_u8, dtype=np.uint8).reshape(-1, self.x_dim)
+        check(self.lib.iwae_dataset_upload(self.h, g.ctypes.data, g.shape[0]))
+        self.n_data = g.shape[0]
+
+    def dataset_begin_epoch(self, epoch, order=None):
+        if order is None:
+            check(self.lib.iwae_dataset_begin_epoch(self.h, int(epoch), None, 0))
+        else:
+            o = np.ascontiguousarray(order, dtype=np.int32)
+            check(self.lib.iwae_dataset_begin_epoch(self.h, int(epoch), o.ctypes.data, o.size))
+
+    def dataset_get_batch(self, start, B):
+        out = np.empty((B, self.x_dim), dtype=np.float32)
+        check(self.lib.iwae_dataset_get_batch(self.h, int(start), int(B), out.ctypes.data))
+        return out
+
+    def train_step_dataset(self, start, B, k, beta=1.0, lr=1e-3, objective="iwae_elbo", scalars=True):
+        s = Scalars()
+        check(self.lib.iwae_train_step_dataset(self.h, int(start), int(B), int(k), float(beta), float(lr), OBJECTIVES[objective],
+                                               C.byref(s) if scalars else None))
+        return self._scalars_dict(s) if scalars else {}
+
     def enable_timing(self, on=True):
         check(self.lib.iwae_enable_timing(self.h, 1 if on else 0))
 

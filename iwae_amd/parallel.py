@@ -8,6 +8,8 @@ naturally because the loss is a mean over images (src/iwae1.py:120-134):
 
 Noise is keyed by the GLOBAL image index (batch_offset), so N ranks draw the same eps as 1 rank.
 The helpers take plain torch tensors so the host logic is testable on CPU with gloo."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,7 +24,7 @@ def shard_bounds(n, rank, world_size):
 
 def allreduce_sum_(flat, group=None):
     """In-place sum of the flat gradient over ranks; one message, not one per tensor."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("IWAE_BENCH_FORCE_DIST")):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 

@@ -89,11 +89,14 @@ def main(argv=None):
     # ---- binarize the test data once (main.py:108)
     Xtest = utils.bernoullisample(Xtest)
 
+    # ---- the training set stays in HBM; shuffling order comes from the host RNG, binarisation and the
+    #      batch gather run on the device (the reference re-binarises 47M pixels on the host every epoch)
+    model.set_dataset(Xtrain)
+
     start = time.time()
     for epoch in range(epochs):
-        # ---- binarize the training data at the start of each epoch (main.py:117-120)
-        Xtrain_binarized = utils.bernoullisample(Xtrain)
-        perm = np.random.permutation(Ntrain)
+        # ---- binarize the training data at the start of each epoch + shuffle (main.py:117-120)
+        model.begin_epoch(epoch, np.random.permutation(Ntrain))
 
         if args.epochs == -1 and epoch in learning_rate_dict:
             new_learning_rate = learning_rate_dict[epoch]
@@ -103,16 +106,15 @@ def main(argv=None):
 
         for _step, lo in enumerate(range(0, Ntrain, batch_size)):
             step = _step + steps_pr_epoch * epoch
-            x_batch = Xtrain_binarized[perm[lo:lo + batch_size]]
             beta = 1.0
-            res = model.train_step(x_batch, n_samples, beta, optimizer, objective=objective)
+            res = model.train_step_dataset(lo, min(batch_size, Ntrain - lo), n_samples, beta, optimizer, objective=objective)
 
             if step % 200 == 0:
                 test_res = model.val_step(Xtest, n_samples, beta)
                 row = {"split": "train", **model.write_to_tensorboard(res, step)}
                 row_t = {"split": "test", **model.write_to_tensorboard(test_res, step)}
                 if log_w is None:
-                    log_w = csv.DictWriter(log_f, fieldnames=list(row.keys()))
+                    log_w = csv.DictWriter(log_f, fieldnames=list(row_t.keys()), restval="", extrasaction="ignore")
                     log_w.writeheader()
                 log_w.writerow(row)
                 log_w.writerow(row_t)

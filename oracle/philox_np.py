@@ -54,3 +54,22 @@ def device_eps(seed, step, B, k, D, stream=0, batch_offset=0):
                   rb * np.cos(2 * np.pi * u[3]), rb * np.sin(2 * np.pi * u[3])], axis=-1)   # [B,k,nd4,4]
     n = n.reshape(B, k, nd4 * 4)[:, :, :D]
     return n.transpose(1, 0, 2)
+
+
+def device_binarize(seed, epoch, gray_u8, image_ids):
+    """Bit-exact restatement of gather_binarize_kernel: rows = images `image_ids` of the uint8 dataset,
+    x = 1 iff (philox(counter = (image, 'BINA', pixel/4, epoch), key = seed)[pixel%4] >> 8) < floor(g*2^24/255 + 0.5)
+    (the reference's per-epoch np.random.binomial(1, g/255), src/utils.py:26-27, with an integer threshold)."""
+    gray_u8 = np.asarray(gray_u8, dtype=np.uint8)
+    ids = np.asarray(image_ids, dtype=np.int64)
+    X = gray_u8.shape[1]
+    nd4 = (X + 3) // 4
+    c0 = np.broadcast_to(ids[:, None].astype(np.uint32), (ids.size, nd4))
+    c1 = np.full((ids.size, nd4), 0x42494E41, dtype=np.uint32)
+    c2 = np.broadcast_to(np.arange(nd4, dtype=np.uint32)[None, :], (ids.size, nd4))
+    c3 = np.full((ids.size, nd4), epoch, dtype=np.uint32)
+    r = philox4x32_10(c0, c1, c2, c3, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.stack([x >> np.uint32(8) for x in r], axis=-1).reshape(ids.size, nd4 * 4)[:, :X].astype(np.uint64)
+    g = gray_u8[ids].astype(np.uint64)
+    thr = (g * np.uint64(16777216 * 2) + np.uint64(255)) // np.uint64(510)
+    return (u < thr).astype(np.float32)

@@ -120,3 +120,16 @@ def test_device_eps_is_standard_normal_and_split_invariant():
     # rows are keyed by the global image index: a shard with batch_offset reproduces the slice
     e2 = philox_np.device_eps(123, 5, 16, 50, 100, batch_offset=32)
     np.testing.assert_array_equal(e[:, 32:48], e2)
+
+
+def test_device_binarize_restatement_is_bernoulli_of_grey_level():
+    """src/utils.py:26-27 semantics: P(x=1) = g/255; one draw per (epoch, image); integer thresholds."""
+    g = np.tile(np.arange(256, dtype=np.uint8), (400, 1))           # 400 images x 256 "pixels" = all grey levels
+    x = philox_np.device_binarize(123, 3, g, np.arange(400))
+    assert set(np.unique(x)) <= {0.0, 1.0}
+    assert x[:, 0].sum() == 0 and x[:, 255].sum() == 400              # g=0 never fires, g=255 always
+    np.testing.assert_allclose(x.mean(0), np.arange(256) / 255.0, atol=0.09)
+    assert abs(x.mean() - 0.5) < 0.01
+    np.testing.assert_array_equal(x, philox_np.device_binarize(123, 3, g, np.arange(400)))      # deterministic
+    assert (x != philox_np.device_binarize(123, 4, g, np.arange(400))).mean() > 0.2                 # new epoch, new draw
+    np.testing.assert_array_equal(x[[7, 2]], philox_np.device_binarize(123, 3, g, [7, 2]))       # keyed by image id
