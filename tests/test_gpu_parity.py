@@ -50,6 +50,9 @@ CASES_1L = [  # (B, k, objective, beta, n_hidden, n_latent, x_dim)
     (3, 130, "iwae_elbo", 1.0, 200, 100, 784),      # k > 64: strided wave reduction over k
     (5, 3, "iwae_elbo", 0.7, 16, 4, 48),            # tiny dims (padding paths), task01-like small latent
     (3, 2, "vae_elbo", 1.0, 64, 2, 784),            # 2-D latent of tasks/task01.py
+    (5, 4, "iwae_elbo", 1.0, 128, 32, 784),         # hidden 128: the KT=4 instantiations of every MFMA kernel
+    (2, 3, "iwae_elbo", 1.0, 256, 128, 784),        # hidden 256 / latent 128: generic (run-time KT) fallbacks, largest dims
+    (300, 2, "iwae_elbo", 1.0, 200, 100, 784),      # ragged row count (600 rows: partial 128-row tile)
 ]
 
 
