@@ -653,19 +653,21 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 // Registers per wave: 56 (g2) + 16 + 56 (dg2 half) + ~50 instead of ~350, so DMA issue, MFMA and
 // the sigmoid epilogue of the two co-resident waves overlap.
 // ---------------------------------------------------------------------------------
-template <int KTC, bool STAMPS>
-__global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
+template <int KTC, int PAIRS, bool STAMPS>     // PAIRS wave pairs per workgroup (32 rows each); 2 waves per SIMD on the CU either way
+__global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     if (STAMPS) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int KT = KTC, MT2 = 2 * KTC, MH = KTC;
+    constexpr int KT = KTC, MH = KTC, NWV = 2 * PAIRS;
+    // ONE weight image per pixel group serves both products: the W^T blocks (pixels x hidden) are read row-wise
+    // (ds_read_b128) for the logits and column-wise through the hardware-transposing ds_read_b64_tr_b16 for dg2.
     constexpr int u1 = KT * 4096 + 1024;           // W^T group incl. its bias block
-    constexpr int unit = u1 + 2 * MT2 * 1024;      // + W k-group
-    char* const xch = smem + 2 * unit;             // [pair 4][half 2][g 2][1 KiB] dl fragments
+    constexpr int unit = u1;
+    char* const xch = smem + 2 * unit;             // [pair][half 2][g 2][1 KiB] dl fragments
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = wave >> 1, half = wave & 1;
     const int rho = lane & 15, q = lane >> 4;
-    const int r0 = (blockIdx.x * 4 + pair) * 32;
+    const int r0 = (blockIdx.x * PAIRS + pair) * 32;
     int row[2], bidx[2];
     bool valid[2];
     float gx[2];
@@ -677,20 +679,22 @@ __global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
         gx[g] = valid[g] ? a.gx[row[g]] : 0.0f;
     }
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    // transposing read: lane 4q'+p of quad q supplies the address of pixel row 4q+q', hidden columns 4p..4p+3
+    // (an 8-byte piece of the row's 16-byte chunk p); lane i of the quad receives hidden column i for 4 pixels
+    const int tr_off = (4 * q + (rho >> 2)) * 64 + (((rho & 3) ^ hperm(q)) * 16);
     const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
 
     // the two weight images of a group are one contiguous LDS unit of NP 1 KiB DMA pieces; wave w moves
     // pieces w, w+8, ...  Piece i of the next group is issued between the MFMAs of the current one.
-    constexpr int NP1 = u1 / 1024, NP = unit / 1024;
+    constexpr int NP = unit / 1024;
     auto dma_piece = [&](int ng, int buf, int idx) {
-        const int p = wave + 8 * idx;                 // wave-uniform
+        const int p = wave + NWV * idx;               // wave-uniform
         if (p < NP) {
-            const char* src = (p < NP1) ? a.img1 + (size_t)ng * u1 + (size_t)p * 1024
-                                        : a.img2 + (size_t)ng * 2 * MT2 * 1024 + (size_t)(p - NP1) * 1024;
+            const char* src = a.img1 + (size_t)ng * u1 + (size_t)p * 1024;
             glds16(src + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * unit) + (uint32_t)p * 1024u)));
         }
     };
-    constexpr int NIDX = (NP + 7) / 8;
+    constexpr int NIDX = (NP + NWV - 1) / NWV;
     auto stage = [&](int ng, int buf) {
 #pragma unroll
         for (int idx = 0; idx < NIDX; ++idx) dma_piece(ng, buf, idx);
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
         OB_STAMP(3)
         const char* l1 = smem + buf * unit + a_off + (2 * half) * 1024;          // this half's two pixel tiles
         const char* lbias = smem + buf * unit + KT * 4096 + (32 * half) * 4;
-        const char* l2 = smem + buf * unit + u1 + a_off + (MH * half) * 1024;    // this half's hidden tiles
+        const char* l2 = smem + buf * unit + tr_off;                                 // transposed view of the same image
 
         f32x4 acc[2][2];
 #pragma unroll
@@ -809,7 +813,15 @@ __global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
         }
 
         lds_pipeline<2 * MH, 8>(
-            [&](int i) { return *(const uint4*)(l2 + ((i / MH) * MT2 + (i % MH)) * 1024); },
+            [&](int i) {       // A fragment (hidden tile mt, pixel k-step kk) = two transposed 4x16 blocks of pixel tiles 2kk, 2kk+1
+                const int kk = i / MH, mt = MH * half + (i % MH);        // mt wave-uniform: hidden k-step mt>>1, half mt&1
+                typedef __attribute__((ext_vector_type(4))) short v4s;
+                const char* p0 = l2 + ((mt >> 1) * 4 + 2 * kk) * 1024 + 8 * (mt & 1);
+                const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+                const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 1024));
+                const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
+                return make_uint4(lo.x, lo.y, hi.x, hi.y);
+            },
             [&](int i, const uint4& av) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) acc2[i % MH][g] = mfma16(av, (i / MH) ? bf2[1][g] : bf2[0][g], acc2[i % MH][g]);
@@ -848,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void out_bwd_pair_kernel(OutBwdArgs a) {
     OB_STAMP(7)
     if (STAMPS && a.stamps && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NWV + wave) * 8 + i] = tsum[i];
     }
 }
 
@@ -1529,18 +1541,24 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     }
 }
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
-    const size_t lds = 2 * ((size_t)a.KT * 8192 + 1024);
-    dim3 grid((a.M + 127) / 128);
+    // pair kernel: one W^T image per pixel group, double buffered, + 4 KiB of dl exchange per pair.  Two 4-wave
+    // workgroups (64 rows each) per CU instead of one 8-wave workgroup: the two are not in lockstep, so one's
+    // MFMA phase overlaps the other's sigmoid epilogue / DMA.
+    constexpr int PAIRS = 2;
+    const size_t ldsp = 2 * ((size_t)a.KT * 4096 + 1024) + (size_t)PAIRS * 4096;
+    dim3 gridp(a.ldT / (PAIRS * 32));      // the PADDED row count (multiple of 128): T-layout pad columns are written as zeros
     if (a.stamps) {   // diagnostic build
-        hipLaunchKernelGGL((out_bwd_pair_kernel<7, true>), grid, dim3(512), lds + 16384, st, a);
+        hipLaunchKernelGGL((out_bwd_pair_kernel<7, PAIRS, true>), gridp, dim3(PAIRS * 128), 2 * ((size_t)7 * 4096 + 1024) + (size_t)PAIRS * 4096, st, a);
         return;
     }
-    const size_t lds2 = lds + 16384;     // + dl exchange area of the pair kernel
     switch (a.KT) {
-        case 7: hipLaunchKernelGGL((out_bwd_pair_kernel<7, false>), grid, dim3(512), lds2, st, a); break;
-        case 4: hipLaunchKernelGGL((out_bwd_pair_kernel<4, false>), grid, dim3(512), lds2, st, a); break;
-        case 2: hipLaunchKernelGGL((out_bwd_pair_kernel<2, false>), grid, dim3(512), lds2, st, a); break;
-        default: hipLaunchKernelGGL((out_bwd_kernel<0, false>), grid, dim3(256), lds, st, a); break;
+        case 7: hipLaunchKernelGGL((out_bwd_pair_kernel<7, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        case 4: hipLaunchKernelGGL((out_bwd_pair_kernel<4, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        case 2: hipLaunchKernelGGL((out_bwd_pair_kernel<2, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        default: {   // run-time hidden width: generic 4-wave kernel with both weight images
+            const size_t lds = 2 * ((size_t)a.KT * 8192 + 1024);
+            hipLaunchKernelGGL((out_bwd_kernel<0, false>), dim3((a.M + 127) / 128), dim3(256), lds, st, a);
+        }
     }
 }
 void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st) {      // jw = 2: 16-wave blocks (256 out-features)

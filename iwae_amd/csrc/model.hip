@@ -566,7 +566,7 @@ int backward_impl(iwae_model* m, int objective) {
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DLT = ptr<uint16_t>(w.dlT); a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = ptr<uint16_t>(w.d2T);
         if (m->want_stamps && L.KT == 7) {
-            CHK(ensure(m->stamps, (size_t)(Mp / 128) * 8 * 8 * 8, st));
+            CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
             { ScopedTimer tm(m, 0); launch_out_bwd(a, st); }
@@ -1133,7 +1133,7 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
         ents.insert(ents.end(), e2.begin(), e2.end());
     }
     if (strcmp(name, "stamps") == 0) {   // diagnostic: [waves][8] phase cycle sums of out_bwd, as float
-        const int nw = (Mp / 128) * 8;
+        const int nw = (Mp / 64) * 4;
         if (rows) *rows = nw;
         if (cols) *cols = 8;
         if (!out) return IWAE_OK;
