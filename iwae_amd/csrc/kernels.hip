@@ -1395,29 +1395,42 @@ __global__ void add3_kernel(float* out, const float* a0, const float* a1, const 
 // gradient slab reduce and Adam (+ bf16 A-image refresh)
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad) {
-    // block = 64 consecutive gradient elements x 4 split groups; partial sums meet in LDS
-    __shared__ float red[4][64];
+    // block = 64 groups of 4 consecutive out-features (float4 loads) x 4 split groups; partial sums meet in LDS.
+    // A group never straddles a weight row: rblock counts are computed per row of 4-float groups (Nout4 = ceil(Nout/4)).
+    __shared__ float4 red[4][64];
     int l = 0;
     while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].rblock_begin) ++l;
     const LayerDesc L = layers[l];
-    const int e = ((int)blockIdx.x - L.rblock_begin) * 64 + (threadIdx.x & 63);
+    const int n4 = (L.Nout + 3) >> 2;                       // float4 groups per weight row
+    const int g = ((int)blockIdx.x - L.rblock_begin) * 64 + (threadIdx.x & 63);
     const int sg = threadIdx.x >> 6;
-    const int nW = L.Kin * L.Nout;
-    float s = 0.0f;
-    if (e < nW) {
-        const int i = e / L.Nout, j = e % L.Nout;
-        const float* p = L.slabW + (size_t)i * L.slab_ld + L.joff + j;
-        for (int sp = sg; sp < L.nsplit; sp += 4) s += p[(size_t)sp * L.slab_stride];
-    } else if (e < nW + L.Nout) {
-        const float* p = L.slabB + L.joff + (e - nW);
-        for (int sp = sg; sp < L.nsplit; sp += 4) s += p[(size_t)sp * L.slab_ld];
+    const int ngroups = (L.Kin + 1) * n4;                   // Kin weight rows + 1 bias row
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = 0, j = 0;
+    const bool ok = g < ngroups;
+    if (ok) {
+        i = g / n4;
+        j = (g - i * n4) * 4;
+        const bool is_b = i == L.Kin;
+        const float* p = is_b ? (L.slabB + L.joff + j) : (L.slabW + (size_t)i * L.slab_ld + L.joff + j);
+        const size_t stride = is_b ? (size_t)L.slab_ld : L.slab_stride;
+        // slab rows start 16-byte aligned (joff, slab_ld multiples of 16 floats): float4 loads; columns >= Nout are pads (zeros / ignored)
+#pragma unroll 4
+        for (int sp = sg; sp < L.nsplit; sp += 4) {
+            const float4 v = *(const float4*)(p + (size_t)sp * stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
     red[sg][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sg == 0 && e < nW + L.Nout) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (e < nW) grad[L.offW + e] = s;
-        else grad[L.offb + (e - nW)] = s;
+    if (sg == 0 && ok) {
+        const int t = threadIdx.x;
+        float r[4] = {red[0][t].x + red[1][t].x + red[2][t].x + red[3][t].x, red[0][t].y + red[1][t].y + red[2][t].y + red[3][t].y,
+                      red[0][t].z + red[1][t].z + red[2][t].z + red[3][t].z, red[0][t].w + red[1][t].w + red[2][t].w + red[3][t].w};
+        float* dst = (i == L.Kin) ? (grad + L.offb + j) : (grad + L.offW + (size_t)i * L.Nout + j);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (j + c < L.Nout) dst[c] = r[c];
     }
 }
 

@@ -255,7 +255,7 @@ int build_descs(iwae_model* m) {
         d.block_begin = blocks;
         d.rblock_begin = rblocks;
         blocks += (d.Kin * d.Nout + d.Nout + 255) / 256;
-        rblocks += (d.Kin * d.Nout + d.Nout + 63) / 64;
+        rblocks += ((d.Kin + 1) * ((d.Nout + 3) / 4) + 63) / 64;     // float4 groups: (Kin weight rows + bias row) x ceil(Nout/4)
     }
     m->elem_blocks = blocks;
     m->reduce_blocks = rblocks;
