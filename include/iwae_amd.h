@@ -131,7 +131,8 @@ int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /*
  * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
 int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);
 
-/* IWAE.sample(z): decoder only, src/iwae1.py:168-178 (z [n,D_last]) -> probs [n, x_dim] */
+/* IWAE.sample(z): decoder only -> probs [n, x_dim].  1-layer: src/iwae1.py:168-178, z [n,D1].  2-layer:
+ * src/iwae2.py:184-196, z = z2 [n,D2]: z1 ~ p(z1|z2) is drawn on the device (Philox), then decoded. */
 int iwae_decode(iwae_handle h, const float* z, int32_t n, float* probs);
 
 /* Data pipeline on the device (main.py:59-65,117-120 + src/utils.py:26-27): the grey-level training set

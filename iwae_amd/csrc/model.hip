@@ -986,17 +986,36 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
 
 int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     if (!m || !z || !probs || n <= 0) return fail(IWAE_ERR_ARG, "decode: bad argument");
-    if (m->cfg.n_layers != 1) return fail(IWAE_ERR_ARG, "decode: 1-layer model only (use the Python shim's sample for 2 layers)");
     HIPCHK(hipSetDevice(m->cfg.device));
     hipStream_t st = m->stream;
-    const int np = round_up(n, 128), D = m->D[0], Dp = m->Dp[0], Hp = m->dec1[0].Np32, Xp = m->Xp32;
+    const bool two = m->cfg.n_layers == 2;
+    const int np = round_up(n, 128), D0 = m->D[0], Dp0 = m->Dp[0], Hp = m->dec1[0].Np32, Xp = m->Xp32;
     MlpWs& w = m->wdec1;
-    CHK(copy_in(m, m->xin, z, (size_t)n * D * 4));
-    CHK(ensure(m->zP[0], (size_t)np * Dp * 2, st));
+    const int Din = two ? m->D[1] : D0, Dinp = two ? m->Dp[1] : Dp0;       // the caller's z is the LAST latent (z for 1 layer, z2 for 2)
+    CHK(copy_in(m, m->xin, z, (size_t)n * Din * 4));
+    CHK(ensure(m->zP[0], (size_t)np * Dp0 * 2, st));
     CHK(ensure(w.g1P, (size_t)np * Hp * 2, st));
     CHK(ensure(w.g2P, (size_t)np * Hp * 2, st));
     CHK(ensure(m->scratch, (size_t)np * Xp * 4, st));
-    launch_prep_rows(ptr<float>(m->xin), n, D, Dp, np, ptr<uint16_t>(m->zP[0]), nullptr, st);
+    if (two) {
+        // src/iwae2.py:184-196: pz1z2 = decode_z2_to_z1(z2); z1 = pz1z2.sample(); logits = decode_z1_to_x(z1)
+        CHK(ensure(m->zP[1], (size_t)np * Dinp * 2, st));
+        launch_prep_rows(ptr<float>(m->xin), n, Din, Dinp, np, ptr<uint16_t>(m->zP[1]), nullptr, st);
+        CHK(block_alloc(m, m->dec2, m->wdec2, n, np, false, false));
+        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), n, np));
+        for (int i = 0; i < 2; ++i) CHK(ensure(m->rows[i], (size_t)np * 4, st));
+        SampleArgs s;
+        memset(&s, 0, sizeof(s));
+        s.head = ptr<float>(m->wdec2.head); s.ldH = 2 * Dp0; s.Dp = Dp0; s.D = D0; s.head_per_row = 1;
+        s.M = n; s.Mp = np; s.k = 1; s.B = n;
+        s.eps.user = nullptr; s.eps.B = n; s.eps.seed = m->cfg.seed; s.eps.row_offset = 0; s.eps.step = m->noise_step; s.eps.stream = 2;
+        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = nullptr; s.ldT = np;
+        s.lp_prior = ptr<float>(m->rows[0]); s.lq = ptr<float>(m->rows[1]); s.lq_dreg = nullptr;
+        launch_sample(s, st);
+        m->noise_step += 1;
+    } else {
+        launch_prep_rows(ptr<float>(m->xin), n, D0, Dp0, np, ptr<uint16_t>(m->zP[0]), nullptr, st);
+    }
     CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, np, ptr<uint16_t>(w.g1P), nullptr, nullptr, 0));
     CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, np, ptr<uint16_t>(w.g2P), nullptr, nullptr, 0));
     CHK(dense_fwd(m, m->dec1[2], EPI_SIGMOID, ptr<uint16_t>(w.g2P), n, np, nullptr, nullptr, ptr<float>(m->scratch), Xp));

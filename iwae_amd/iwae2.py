@@ -1,5 +1,7 @@
 """Reference API of src/iwae2.py (two stochastic layers, src/iwae2.py:99-182)."""
-from ._shim import BaseIWAE, _Sub
+import numpy as np
+
+from ._shim import BaseIWAE, _Sub, as_tensor
 
 
 class IWAE(BaseIWAE):
@@ -13,3 +15,9 @@ class IWAE(BaseIWAE):
 
     def val_step(self, x, n_samples, beta, outputs=None):
         return self.call(x, n_samples, beta, outputs=outputs)
+
+    def sample(self, z2):
+        """src/iwae2.py:184-196: z1 ~ p(z1|z2), probs = sigmoid(decoder(z1)), x_sample ~ Bernoulli(probs)."""
+        probs = self._net.decode(np.asarray(z2, dtype=np.float32))
+        x_sample = (np.random.random_sample(probs.shape) < probs).astype(np.float32)
+        return as_tensor(x_sample), as_tensor(probs)

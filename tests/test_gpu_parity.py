@@ -185,6 +185,23 @@ def test_decode_matches_oracle(gpu):
     m.close()
 
 
+def test_decode_2layer_matches_oracle_mean_path(gpu):
+    """src/iwae2.py:184-196 with the device's own z1 draw: probs = sigmoid(dec1(mu_p + sigma_p * eps)), eps = Philox stream 2."""
+    x, P, eps = MG.inputs(2, [200, 100], [100, 50], 784, 4, 2, 66)
+    m = _model(2, [200, 100], [100, 50])
+    m.set_params(O.flatten_params(P))
+    z2 = np.random.default_rng(1).standard_normal((21, 50)).astype(np.float32)
+    m.set_step(4, 0)
+    probs = m.decode(z2)
+    dec2 = O._Block(P[8:12], O.bf16_round)
+    mup, sigp = dec2.fwd(O.bf16_round(z2))
+    e = philox_np.device_eps(123, 4, 21, 1, 100, stream=2)[0]
+    dec1 = O._MLP3(P[12:15], O.bf16_round)
+    ref = O.sigmoid(dec1.fwd(O.bf16_round(mup + sigp * e)))
+    assert probs.shape == (21, 784) and np.max(np.abs(probs - ref)) < 2e-2
+    m.close()
+
+
 # ---------------------------------------------------------------- full-size properties (BASELINE configs[1])
 @pytest.fixture(scope="module")
 def big(gpu):

@@ -60,6 +60,8 @@ def test_iwae2_and_dreg_api(gpu):
         m2.train_step(x, 4, 1.0, opt, objective="vae_elbo_kl")                   # src/iwae2.py:154-173
     full = m2(x, 4, outputs="all")
     assert full["z1"].shape == (4, 12, 100) and full["z2"].shape == (4, 12, 50) and full["snis_z2"].shape == (12, 50)
+    xs, probs = m2.sample(np.random.randn(9, 50).astype(np.float32))            # src/iwae2.py:184-196
+    assert xs.shape == (9, 784) and probs.shape == (9, 784) and 0 <= probs.min() and probs.max() <= 1 and np.isfinite(probs).all()
     md = task02.IWAEDReG(200, 100)
     r = md.train_step(x, 4, 1.0, Adam(1e-3, epsilon=1e-4))
     assert "inference_loss" in r and "iwae_elbo" in r and "vae_elbo" not in r    # tasks/task02.py:78-85
