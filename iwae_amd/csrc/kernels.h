@@ -44,7 +44,8 @@ struct OutBwdArgs {
     const float* gx;                  // [M] dLoss/dlpxz
     const uint16_t* XB; int ldXB; int k;
     int M, KT, NG;
-    uint16_t* DLT; int ldT;           // dlogits, T-layout [Xp32][ldT]
+    uint16_t* DLT; int ldT;           // dlogits, T-layout [Xp32][ldT] (legacy weight-gradient path) or null
+    uint16_t* DLP;                    // dlogits, P-layout [M][Xp32] or null
     uint16_t* DPP; uint16_t* DPT;     // dpre of the last hidden layer, P [M][32*KT] and T [32*KT][ldT]
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
 };
@@ -55,6 +56,15 @@ struct WgradArgs {
     int Mp, rows_per_split;
     float* slabW;                     // [nsplit][IT*16][JT*16]
     float* slabB;                     // [nsplit][JT*16]
+};
+
+struct WgradPArgs {
+    const uint16_t* X; int ldX; int IT;     // layer input, P-layout [rows][ldX]; IT = ldX/16 i-tiles
+    const uint16_t* G; int ldG; int JT;     // dpre of layer output, P-layout [rows][ldG]
+    int M, rows_per_split;                  // valid rows; rows per split (multiple of 64)
+    float* slabW;                           // [nsplit][IT*16][JT*16]
+    float* slabB;                           // [nsplit][JT*16]
+    const char* zero;                       // >= 512 B of zeros (source of rows >= M and of unused slots)
 };
 
 struct SampleArgs {
@@ -116,6 +126,7 @@ struct LayerDesc {
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st);
+void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf, hipStream_t st);

@@ -498,13 +498,19 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     uint32_t stT[2][8];
+    uint4 stP[2][2];
     int st_ng = -1;
     auto emit_stores = [&]() {
         if (st_ng < 0) return;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int fbase = 64 * st_ng + 32 * p;
-            if (fbase < a.Xp32) {
+            if (fbase < a.Xp32 && a.DLP) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (valid[g]) *(uint4*)(a.DLP + (size_t)row[g] * a.Xp32 + fbase + 8 * q) = stP[p][g];
+            }
+            if (fbase < a.Xp32 && a.DLT) {
                 char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -575,6 +581,7 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
                         v[g][j] = d;
                     }
                     bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
+                    stP[p][g] = bf2[p][g];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) stT[p][j] = pack2(v[0][j], v[1][j]);
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
                         make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
             }
             char* tb = (char*)a.DPT + (size_t)(ks * 32) * a.ldT * 2;
+            if (a.DPT)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
@@ -728,11 +736,17 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     uint32_t stT[8];
+    uint4 stP[2];
     int st_ng = -1;
     auto emit_stores = [&]() {
         if (st_ng < 0) return;
         const int fbase = 64 * st_ng + 32 * half;
-        if (fbase < a.Xp32) {
+        if (fbase < a.Xp32 && a.DLP) {       // dl in P-layout: the lane's 8 features of this 32-pixel step are one 16-byte chunk
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (valid[g]) *(uint4*)(a.DLP + (size_t)row[g] * a.Xp32 + fbase + 8 * q) = stP[g];
+        }
+        if (fbase < a.Xp32 && a.DLT) {
             char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -794,6 +808,8 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) stT[j] = pack2(v[0][j], v[1][j]);
+            stP[0] = own[0];
+            stP[1] = own[1];
         };
         if (64 * ng + 32 * half + 32 <= a.Xdim) dl_body(std::false_type{});
         else dl_body(std::true_type{});
@@ -853,6 +869,7 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
                 *(uint2*)(a.DPP + (size_t)row[g] * a.ldG + (mt >> 1) * 32 + 8 * q + 4 * (mt & 1)) = make_uint2(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]));
         }
         char* tb = (char*)a.DPT + (size_t)(mt * 16) * a.ldT * 2;
+        if (a.DPT)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *(uint32_t*)(tb + (size_t)i * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][i] : 0.0f, valid[1] ? v[1][i] : 0.0f);
@@ -998,6 +1015,127 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradArgs a) {
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt[w] * 16 + rho] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// wgradp_kernel: weight gradient straight from the ROW-major P-layout activations (no T-layout copies):
+//   out[i][j] = sum_r X[r][i] * G[r][j],   X: bf16 [rows][ldX], G: bf16 [rows][ldG]  (both P-layout)
+// The contraction index (data row) is the strided one in memory, so both MFMA operands are produced by the
+// hardware-transposing LDS read: per 64-row chunk the X tile (<=256 features) and the G strip (NW*16
+// features) are DMA'd row-major into LDS (16-byte slot s of row r lands at slot s ^ ((r&3)<<2), the swizzle
+// is applied on the per-lane SOURCE address), and a fragment is two ds_read_b64_tr_b16 (4 rows x 16 features
+// each; 2-way bank conflict by construction: every lane uses one half of a 16-byte slot).  P-layout's feature
+// permutation is undone for free by which 8-byte piece a lane addresses.  Rows >= M read a zero line.
+// grid = (j-blocks of NW*16 features, i-blocks of 256 features, row splits); fp32 slabs as before.
+// ---------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int XT_BYTES = 64 * 512;                 // X tile: 64 rows x 512 B (256 features)
+    constexpr int GROW = NW * 32;                      // G strip row bytes (512 for 16 waves, 256 for 8)
+    constexpr int GT_BYTES = 64 * GROW;
+    constexpr int BUF = XT_BYTES + GT_BYTES;
+    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, NPC = XP + GP, NIDX = (NPC + NW - 1) / NW;
+    typedef __attribute__((ext_vector_type(4))) short v4s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
+    const int it0 = blockIdx.y * 16;
+    const int nit = min(16, a.IT - it0);
+    const int jt = blockIdx.x * NW + wave;
+    const bool jvalid = jt < a.JT;
+    const int split = blockIdx.z;
+    const int rbeg = split * a.rows_per_split;
+    const int rend = min(a.M, rbeg + a.rows_per_split);
+    const int nchunk = (rend - rbeg + 63) / 64;
+    const int xcol0 = it0 * 16, gcol0 = blockIdx.x * NW * 16;       // first feature (= P position, both multiples of 32) of the tiles
+
+    // one DMA piece = 1 KiB of LDS = 2 X rows (32 slots each) or 1024/GROW G rows
+    auto dma_piece = [&](int c, int buf, int idx) {
+        const int pc = wave + NW * idx;               // wave-uniform
+        if (pc >= NPC) return;
+        const int r0 = rbeg + c * 64;
+        const char* src;
+        if (pc < XP) {
+            const int rl = 2 * pc + (lane >> 5), s = lane & 31;
+            const int cch = s ^ ((rl & 3) << 2);                          // source 16-byte chunk of this LDS slot
+            const int col = xcol0 + cch * 8;
+            const bool ok = (r0 + rl) < rend && col < a.ldX;
+            src = ok ? (const char*)a.X + ((size_t)(r0 + rl) * a.ldX + col) * 2 : a.zero + (lane & 31) * 16;
+        } else {
+            constexpr int SPR = GROW / 16, RPP = 1024 / GROW;            // slots per row, rows per piece
+            const int rl = RPP * (pc - XP) + lane / SPR, s = lane % SPR;
+            const int cch = s ^ ((rl & 3) << 2);
+            const int col = gcol0 + cch * 8;
+            const bool ok = (r0 + rl) < rend && col < a.ldG;
+            src = ok ? (const char*)a.G + ((size_t)(r0 + rl) * a.ldG + col) * 2 : a.zero + (lane & 31) * 16;
+        }
+        glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * BUF) + (uint32_t)pc * 1024u)));
+    };
+
+    f32x4 acc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+    if (nchunk > 0) {
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, 0, idx);
+    }
+    // lane-constant parts of the transposing-read addresses: row 4q+q' of a 16-row half-step, piece p
+    const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
+    const int jl = wave, gslot = ((4 * (jl >> 1)) ^ (qp << 2)) + p;      // G strip: local tile jl -> chunk 4*(jl>>1)+p, half jl&1
+
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        wait_all_vmem();
+        __syncthreads();
+        const bool more = c + 1 < nchunk;
+        int dma_idx = 0;
+        auto dma_next = [&]() {
+            if (more && dma_idx < NIDX) dma_piece(c + 1, buf ^ 1, dma_idx);
+            ++dma_idx;
+        };
+        const char* xb = smem + buf * BUF + xrow_off + p * 16;
+        const char* gb = smem + buf * BUF + XT_BYTES + grow_off + gslot * 16 + 8 * (jl & 1);
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            // B fragment: 8 data rows (two 4-row blocks) of this wave's 16 G features
+            const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs) * GROW));
+            const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs + 16) * GROW));
+            const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
+            const uint4 g = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+            bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
+            lds_pipeline<16, 3>(
+                [&](int i) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
+                    const char* p0 = xb + (32 * rs) * 512 + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
+                    const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+                    const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 16 * 512));
+                    const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
+                    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+                },
+                [&](int i, const uint4& av) { if (i < nit) acc[i] = mfma16(av, g, acc[i]); },
+                [&](int i) { if (i == 0 || i == 8) dma_next(); });
+        }
+        while (dma_idx < NIDX) dma_next();
+    }
+
+    // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
+    if (jvalid) {
+        float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            if (it < nit) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + l16] = acc[it][ii];
+            }
+        }
+        if (blockIdx.y == 0) {
+            float v = bsum;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + l16] = v;
         }
     }
 }
@@ -1322,10 +1460,12 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
     }
+    if (a.DHT) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a.DHT[(size_t)(f0 + i) * a.Bp + b] = (uint16_t)(pack2(dmu[i], 0.0f) & 0xffffu);
-        a.DHT[(size_t)(a.Dp + f0 + i) * a.Bp + b] = (uint16_t)(pack2(dsg[i], 0.0f) & 0xffffu);
+        for (int i = 0; i < 4; ++i) {
+            a.DHT[(size_t)(f0 + i) * a.Bp + b] = (uint16_t)(pack2(dmu[i], 0.0f) & 0xffffu);
+            a.DHT[(size_t)(a.Dp + f0 + i) * a.Bp + b] = (uint16_t)(pack2(dsg[i], 0.0f) & 0xffffu);
+        }
     }
 }
 
@@ -1374,10 +1514,12 @@ __global__ void gauss_bwd_kernel(GaussBwdArgs a) {
         *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
         if (a.mode == 0) *(float4*)(a.dz_direct + (size_t)row * a.ldDZ + f0) = make_float4(dzd[0], dzd[1], dzd[2], dzd[3]);
     }
+    if (a.DHT) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        a.DHT[(size_t)(f0 + i) * a.ldT + row] = (uint16_t)(pack2(dm[i], 0.0f) & 0xffffu);
-        a.DHT[(size_t)(a.Dp + f0 + i) * a.ldT + row] = (uint16_t)(pack2(ds[i], 0.0f) & 0xffffu);
+        for (int i = 0; i < 4; ++i) {
+            a.DHT[(size_t)(f0 + i) * a.ldT + row] = (uint16_t)(pack2(dm[i], 0.0f) & 0xffffu);
+            a.DHT[(size_t)(a.Dp + f0 + i) * a.ldT + row] = (uint16_t)(pack2(ds[i], 0.0f) & 0xffffu);
+        }
     }
 }
 
@@ -1578,6 +1720,11 @@ void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st) {     
     dim3 grid((a.JT + 8 * jw - 1) / (8 * jw), (a.IT + 15) / 16, nsplit);
     if (jw == 2) hipLaunchKernelGGL((wgrad_kernel<1, 16>), grid, dim3(1024), 131072, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, 8>), grid, dim3(512), 131072, st, a);
+}
+void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
+    dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);
+    if (nw == 16) hipLaunchKernelGGL(wgradp_kernel<16>, grid, dim3(1024), 2 * (64 * 512 + 64 * 512), st, a);
+    else hipLaunchKernelGGL(wgradp_kernel<8>, grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
 }
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
     const int nchunk = Xp / 8;

@@ -62,7 +62,7 @@ struct BlockWs {   // activations / gradients of one BasicBlock applied to R row
     DevBuf h1P, h1T, h2P, h2T, head, dheadP, dheadT, d2P, d2T, d1P, d1T, dx;
 };
 struct MlpWs {     // decode_z_to_x applied to M rows
-    DevBuf g1P, g1T, g2P, g2T, dlT, d2P, d2T, d1P, d1T, dz;
+    DevBuf g1P, g1T, g2P, g2T, dlT, dlP, d2P, d2T, d1P, d1T, dz;
 };
 
 }  // namespace
@@ -98,6 +98,9 @@ struct iwae_model {
     // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
     DevBuf ds_data, ds_order;
     int ds_N = 0;
+    int wg_target16 = 256;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid)
+    bool use_t = false;        // IWAE_WGRAD_T=1: legacy weight-gradient path reading T-layout copies
+    char* d_zero = nullptr;    // 1 KiB of zeros (wgradp_kernel's source for rows >= M)
     uint32_t ds_epoch = 0;
     int ds_start = -1;         // >= 0: the next forward gathers + binarises rows ds_start.. from the dataset instead of reading x
     DevBuf stamps;             // diagnostic (IWAE_STAMPS=1)
@@ -338,8 +341,8 @@ int block_alloc(iwae_model* m, Linear* blk, BlockWs& w, int R, int Rp, bool bwd,
 }
 
 int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R, int Rp) {
-    CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.h1T), nullptr, 0));
-    CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h2T), nullptr, 0));
+    CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, Rp, ptr<uint16_t>(w.h1P), m->use_t ? ptr<uint16_t>(w.h1T) : nullptr, nullptr, 0));
+    CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, Rp, ptr<uint16_t>(w.h2P), m->use_t ? ptr<uint16_t>(w.h2T) : nullptr, nullptr, 0));
     CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, Rp, nullptr, nullptr, ptr<float>(w.head), blk[2].Np32));
     return IWAE_OK;
 }
@@ -368,6 +371,31 @@ int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int 
     return IWAE_OK;
 }
 
+// weight gradient from the P-layout operands (wgradp_kernel); XP/GP row-major bf16, `rows` valid rows
+int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr) {
+    if (!st) st = m->stream;
+    const int chunks = (rows + 63) / 64;
+    const int nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
+    const int blocks = ((L.JT + nw - 1) / nw) * ((L.IT + 15) / 16);
+    // one workgroup per CU is the measured optimum (k=50,B=1024: 64 -> 0.501, 128 -> 0.425, 256 -> 0.406, 384 -> 0.443,
+    // 512 -> 0.455 ms/step): fewer leaves CUs idle, more pays a full fp32 slab (write + read back) per extra split
+    const int target = (nw == 16) ? m->wg_target16 : 256;
+    int nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
+    const int cps = (chunks + nsplit - 1) / nsplit;
+    nsplit = (chunks + cps - 1) / cps;
+    const size_t needW = (size_t)nsplit * L.IT * 16 * L.JT * 16 * 4, needB = (size_t)nsplit * L.JT * 16 * 4;
+    void* oldW = L.slabW.p; void* oldB = L.slabB.p;
+    CHK(ensure(L.slabW, needW, m->stream));
+    CHK(ensure(L.slabB, needB, m->stream));
+    if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
+    WgradPArgs a;
+    a.X = XP; a.ldX = L.Kp32; a.IT = L.IT; a.G = GP; a.ldG = L.Np32; a.JT = L.JT; a.M = rows; a.rows_per_split = cps * 64;
+    a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero;
+    launch_wgradp(a, nsplit, nw, st);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
 // dX (times tanh' of the stored activation, or raw fp32) of a layer: X = dpre of the layer's outputs
 int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, int rowsP, const uint16_t* ACT, uint16_t* YP, uint16_t* YT, float* YF) {
     DenseArgs a;
@@ -382,7 +410,16 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, int rowsP, 
     return IWAE_OK;
 }
 
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inT, int R, int Rp, bool need_dx) {
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inT, const uint16_t* inP, int R, int Rp, bool need_dx) {
+    if (!m->use_t) {
+        CHK(wgradp(m, blk[2], ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.dheadP), R));
+        CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr, nullptr));
+        CHK(wgradp(m, blk[1], ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d2P), R));
+        CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr, nullptr));
+        CHK(wgradp(m, blk[0], inP, ptr<uint16_t>(w.d1P), R));
+        if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, Rp, nullptr, nullptr, nullptr, ptr<float>(w.dx)));
+        return IWAE_OK;
+    }
     CHK(wgrad(m, blk[2], ptr<uint16_t>(w.h2T), ptr<uint16_t>(w.dheadT), Rp));
     CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d2T), nullptr));
     CHK(wgrad(m, blk[1], ptr<uint16_t>(w.h1T), ptr<uint16_t>(w.d2T), Rp));
@@ -421,11 +458,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), nullptr, st);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), m->use_t ? ptr<uint16_t>(m->xT) : nullptr, nullptr, st);
         m->ds_start = -1;
     } else {
         CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
-        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), ptr<uint16_t>(m->xT), st);
+        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), m->use_t ? ptr<uint16_t>(m->xT) : nullptr, st);
     }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
@@ -448,7 +485,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
-        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = ptr<uint16_t>(m->zT[0]); s.ldT = Mp;
+        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = m->use_t ? ptr<uint16_t>(m->zT[0]) : nullptr; s.ldT = Mp;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
@@ -465,7 +502,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc2.head); s.ldH = 2 * m->Dp[1]; s.Dp = m->Dp[1]; s.D = m->D[1]; s.head_per_row = 1;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 1);
-        s.ZP = ptr<uint16_t>(m->zP[1]); s.ZT = ptr<uint16_t>(m->zT[1]); s.ldT = Mp;
+        s.ZP = ptr<uint16_t>(m->zP[1]); s.ZT = m->use_t ? ptr<uint16_t>(m->zT[1]) : nullptr; s.ldT = Mp;
         s.lp_prior = t2; s.lq = t4; s.lq_dreg = nullptr;
         launch_sample(s, st);
         CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
@@ -485,8 +522,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     CHK(ensure(w.g1T, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.g2P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.g2T, (size_t)Mp * Hp * 2, st));
-    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, Mp, ptr<uint16_t>(w.g1P), bwd ? ptr<uint16_t>(w.g1T) : nullptr, nullptr, 0));
-    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, Mp, ptr<uint16_t>(w.g2P), bwd ? ptr<uint16_t>(w.g2T) : nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, Mp, ptr<uint16_t>(w.g1P), (bwd && m->use_t) ? ptr<uint16_t>(w.g1T) : nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, Mp, ptr<uint16_t>(w.g2P), (bwd && m->use_t) ? ptr<uint16_t>(w.g2T) : nullptr, nullptr, 0));
     {
         Linear& L = m->dec1[2];
         DenseArgs a;
@@ -550,7 +587,7 @@ int backward_impl(iwae_model* m, int objective) {
     hipStream_t st = m->stream;
     MlpWs& w = m->wdec1;
     const int Hp = m->dec1[0].Np32;
-    CHK(ensure(w.dlT, (size_t)Mp * Xp * 2, st));
+    CHK(ensure(m->use_t ? w.dlT : w.dlP, (size_t)Mp * Xp * 2, st));
     CHK(ensure(w.d2P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.d2T, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
@@ -564,7 +601,8 @@ int backward_impl(iwae_model* m, int objective) {
         a.Xdim = X; a.Xp32 = Xp;
         a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
         a.M = M; a.KT = L.KT; a.NG = L.MG;
-        a.DLT = ptr<uint16_t>(w.dlT); a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = ptr<uint16_t>(w.d2T);
+        a.DLT = m->use_t ? ptr<uint16_t>(w.dlT) : nullptr; a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = m->use_t ? ptr<uint16_t>(w.d2T) : nullptr;
+        a.DLP = m->use_t ? nullptr : ptr<uint16_t>(w.dlP);
         if (m->want_stamps && L.KT == 7) {
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
@@ -574,12 +612,18 @@ int backward_impl(iwae_model* m, int objective) {
     }
     // slabs must exist before the fork (ensure() may synchronise / reallocate): size them on the main stream
     // by running the decoder weight gradients on the side stream, ordered behind the producers by events.
-    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
+    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), m->use_t ? ptr<uint16_t>(w.d1T) : nullptr, nullptr));
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    { ScopedTimer tm(m, 2, m->side); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp, m->side)); }
-    CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp, m->side));
-    CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp, m->side));
+    if (m->use_t) {
+        { ScopedTimer tm(m, 2, m->side); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp, m->side)); }
+        CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp, m->side));
+        CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp, m->side));
+    } else {
+        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side)); }
+        CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
+        CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
+    }
     HIPCHK(hipEventRecord(m->ev_join, m->side));
     CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, Mp, nullptr, nullptr, nullptr, ptr<float>(w.dz)));
 
@@ -595,17 +639,17 @@ int backward_impl(iwae_model* m, int objective) {
         g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
         g.dz_direct = ptr<float>(m->dzdir); g.ldDZ = m->Dp[0];
         g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
-        g.DHP = ptr<uint16_t>(m->wdec2.dheadP); g.DHT = ptr<uint16_t>(m->wdec2.dheadT); g.ldT = Mp;
+        g.DHP = ptr<uint16_t>(m->wdec2.dheadP); g.DHT = m->use_t ? ptr<uint16_t>(m->wdec2.dheadT) : nullptr; g.ldT = Mp;
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zT[1]), M, Mp, true));
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zT[1]), ptr<uint16_t>(m->zP[1]), M, Mp, true));
         memset(&g, 0, sizeof(g));
         g.mode = 1; g.G = ptr<float>(m->gx);
         g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
         g.dz_in = ptr<float>(m->wdec2.dx); g.ldDZ = m->Dp[1];
         g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
-        g.DHP = ptr<uint16_t>(m->wenc2.dheadP); g.DHT = ptr<uint16_t>(m->wenc2.dheadT); g.ldT = Mp;
+        g.DHP = ptr<uint16_t>(m->wenc2.dheadP); g.DHT = m->use_t ? ptr<uint16_t>(m->wenc2.dheadT) : nullptr; g.ldT = Mp;
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zT[0]), M, Mp, true));
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(m->zP[0]), M, Mp, true));
         launch_add3(ptr<float>(m->dzsum), ptr<float>(w.dz), ptr<float>(m->dzdir), ptr<float>(m->wenc2.dx), (size_t)M * m->Dp[0], st);
         dz1 = ptr<float>(m->dzsum);
     }
@@ -617,10 +661,10 @@ int backward_impl(iwae_model* m, int objective) {
         a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
         a.B = B; a.Bp = Bp; a.k = k;
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
-        a.DHP = ptr<uint16_t>(m->wenc1.dheadP); a.DHT = ptr<uint16_t>(m->wenc1.dheadT);
+        a.DHP = ptr<uint16_t>(m->wenc1.dheadP); a.DHT = m->use_t ? ptr<uint16_t>(m->wenc1.dheadT) : nullptr;
         launch_latent_bwd(a, st);
     }
-    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), B, Bp, false));
+    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), ptr<uint16_t>(m->xP), B, Bp, false));
     HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
     if (m->descs_dirty) CHK(build_descs(m));
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, st);
@@ -731,6 +775,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     iwae_model* m = new iwae_model();
     m->cfg = *cfg;
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
+    m->use_t = getenv("IWAE_WGRAD_T") != nullptr;
+    if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
 
     m->X = cfg->x_dim;
     m->Xp32 = round_up(cfg->x_dim, 32);
@@ -764,6 +810,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipMemset(m->grad, 0, nb));
     HIPCHK(hipMemset(m->mom, 0, nb));
     HIPCHK(hipMemset(m->vel, 0, nb));
+    HIPCHK(hipMalloc((void**)&m->d_zero, 1024));
+    HIPCHK(hipMemset(m->d_zero, 0, 1024));
     HIPCHK(hipMalloc((void**)&m->d_scalars, SC_COUNT * 4));
     HIPCHK(hipMemset(m->d_scalars, 0, SC_COUNT * 4));
     HIPCHK(hipHostMalloc((void**)&m->h_scalars, SC_COUNT * 4));
@@ -799,7 +847,7 @@ void iwae_destroy(iwae_handle m) {
     }
     {
         MlpWs* w = &m->wdec1;
-        DevBuf* bb[] = {&w->g1P, &w->g1T, &w->g2P, &w->g2T, &w->dlT, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dz};
+        DevBuf* bb[] = {&w->g1P, &w->g1T, &w->g2P, &w->g2T, &w->dlT, &w->dlP, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dz};
         for (DevBuf* b : bb) free_buf(*b);
     }
     if (m->param) (void)hipFree(m->param);
@@ -807,6 +855,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->mom) (void)hipFree(m->mom);
     if (m->vel) (void)hipFree(m->vel);
     if (m->d_descs) (void)hipFree(m->d_descs);
+    if (m->d_zero) (void)hipFree(m->d_zero);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);
     for (int i = 0; i < 3; ++i) {
