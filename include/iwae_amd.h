@@ -148,8 +148,10 @@ int iwae_train_step_dataset(iwae_handle h, int32_t start, int32_t B, int32_t k, 
                             iwae_scalars* scalars);
 
 /* HIP-event timing of the dominant kernels on the handle's stream (used by bench.py's roofline
- * object): enable, run steps, then read the average launch duration.  name is one of "out_bwd"
- * (decoder output layer backward), "bernoulli_fwd" (output layer + log-likelihood), "wgrad_out". */
+ * object): enable, run steps, then read the average launch duration.  enable = n > 0 brackets the
+ * kernels of every n-th step (an event record costs a few us of stream bubble, so bench.py samples
+ * rather than timing every launch); 0 switches it off.  name is one of "out_bwd" (decoder output
+ * layer backward), "bernoulli_fwd" (output layer + log-likelihood), "wgrad_out". */
 int iwae_enable_timing(iwae_handle h, int32_t enable);
 int iwae_kernel_time(iwae_handle h, const char* name, double* avg_us, int64_t* launches);
 

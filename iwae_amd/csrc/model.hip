@@ -107,8 +107,10 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool timing = false;
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+    int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
+    int64_t timing_calls = 0;
+    bool time_this = false;
     std::vector<hipEvent_t> ev_start[3], ev_stop[3];   // 0 out_bwd, 1 bernoulli fwd, 2 wgrad(out)
     size_t ev_used[3] = {0, 0, 0};
     bool want_stamps = false;
@@ -279,7 +281,7 @@ int refresh_images(iwae_model* m) {   // rebuild bf16 A-images from the fp32 mas
 struct ScopedTimer {     // records a start/stop event pair around a launch when timing is enabled
     iwae_model* m; int id; bool on;
     hipStream_t ts;
-    ScopedTimer(iwae_model* m_, int id_, hipStream_t s_ = nullptr) : m(m_), id(id_), on(m_->timing), ts(s_ ? s_ : m_->stream) {
+    ScopedTimer(iwae_model* m_, int id_, hipStream_t s_ = nullptr) : m(m_), id(id_), on(m_->time_this), ts(s_ ? s_ : m_->stream) {
         if (!on) return;
         if (m->ev_used[id] == m->ev_start[id].size()) {
             hipEvent_t a, b;
@@ -448,6 +450,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
+    m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
     hipStream_t st = m->stream;
@@ -610,18 +613,24 @@ int backward_impl(iwae_model* m, int objective) {
             { ScopedTimer tm(m, 0); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
-    // slabs must exist before the fork (ensure() may synchronise / reallocate): size them on the main stream
-    // by running the decoder weight gradients on the side stream, ordered behind the producers by events.
-    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), m->use_t ? ptr<uint16_t>(w.d1T) : nullptr, nullptr));
+    // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
+    // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
+    // first decoder layer's gradient additionally waits for dpre1 (second event).
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     if (m->use_t) {
+        CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
+        HIPCHK(hipEventRecord(m->ev_fork2, st));
         { ScopedTimer tm(m, 2, m->side); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp, m->side)); }
         CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp, m->side));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
         CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp, m->side));
     } else {
         { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side)); }
+        CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr, nullptr));
+        HIPCHK(hipEventRecord(m->ev_fork2, st));
         CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
         CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
     }
     HIPCHK(hipEventRecord(m->ev_join, m->side));
@@ -788,6 +797,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->own_stream = true;
     HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
@@ -864,6 +874,7 @@ void iwae_destroy(iwae_handle m) {
     }
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -1129,7 +1140,9 @@ int iwae_train_step_dataset(iwae_handle m, int32_t start, int32_t B, int32_t k, 
 int iwae_enable_timing(iwae_handle m, int32_t enable) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     HIPCHK(hipStreamSynchronize(m->stream));
-    m->timing = enable != 0;
+    m->timing = enable > 0 ? enable : 0;
+    m->timing_calls = 0;
+    m->time_this = false;
     for (int i = 0; i < 3; ++i) m->ev_used[i] = 0;
     return IWAE_OK;
 }

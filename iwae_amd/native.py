@@ -226,8 +226,9 @@ class NativeModel:
                                                C.byref(s) if scalars else None))
         return self._scalars_dict(s) if scalars else {}
 
-    def enable_timing(self, on=True):
-        check(self.lib.iwae_enable_timing(self.h, 1 if on else 0))
+    def enable_timing(self, every=1):
+        """every = n > 0: bracket the dominant kernels of every n-th step with HIP events; 0 / False: off."""
+        check(self.lib.iwae_enable_timing(self.h, int(every)))
 
     def kernel_time(self, name):
         us, cnt = C.c_double(), C.c_int64()
