@@ -13,12 +13,14 @@ enum { PB_LME = 0, PB_MEAN, PB_EQ14, PB_KL, PB_PX, PB_T1, PB_T2, PB_DREG, PB_COU
 enum { SC_VAE_ELBO = 0, SC_VAE_ELBO_KL, SC_IWAE_ELBO, SC_IWAE_EQ14, SC_INFERENCE_LOSS, SC_MEAN_LPXZ, SC_MEAN_T1, SC_MEAN_T2, SC_KL, SC_COUNT = 16 };
 
 struct EpsSrc {
-    const float* user;     // [k][B][D] host-supplied draws (reference order) or null -> Philox
-    int B;
-    uint64_t seed;
-    uint64_t row_offset;   // global index of this rank's first data row (batch_offset * k)
-    uint32_t step;
-    uint32_t stream;       // 0: first latent layer, 1: second
+    const float* user = nullptr;     // [k][B][D] host-supplied draws (reference order) or null -> Philox
+    const float* cache = nullptr;    // [rows][ldC] draws eps_gen_kernel made ahead of the step (Philox costs ~40 quarter-rate
+    int ldC = 0;                     //   integer multiplies per 4 draws; re-reading 16 B is cheaper than redrawing) or null
+    int B = 0;
+    uint64_t seed = 0;
+    uint64_t row_offset = 0;   // global index of this rank's first data row (batch_offset * k)
+    uint32_t step = 0;
+    uint32_t stream = 0;       // 0: first latent layer, 1: second
 };
 
 struct DenseArgs {
@@ -28,7 +30,6 @@ struct DenseArgs {
     int M, KT, MG, mg_per_block;
     int Np32;                         // out-features that are stored (multiple of 32)
     uint16_t* YP; int ldYP;           // bf16 P-layout out
-    uint16_t* YT; int ldT;            // bf16 T-layout out [Np32][ldT] (optional)
     float* YF; int ldYF;              // fp32 natural out
     const uint16_t* ACT; int ldACT;   // EPI_DX: stored activation of the out-features (P-layout)
     // EPI_BERN
@@ -44,18 +45,9 @@ struct OutBwdArgs {
     const float* gx;                  // [M] dLoss/dlpxz
     const uint16_t* XB; int ldXB; int k;
     int M, KT, NG;
-    uint16_t* DLT; int ldT;           // dlogits, T-layout [Xp32][ldT] (legacy weight-gradient path) or null
     uint16_t* DLP;                    // dlogits, P-layout [M][Xp32] or null
-    uint16_t* DPP; uint16_t* DPT;     // dpre of the last hidden layer, P [M][32*KT] and T [32*KT][ldT]
+    uint16_t* DPP;                    // dpre of the last hidden layer, P-layout [M][32*KT]
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
-};
-
-struct WgradArgs {
-    const uint16_t* AT; int IT;       // layer input, T-layout [IT*16][Mp]
-    const uint16_t* GT; int JT;       // dpre of layer output, T-layout [JT*16][Mp]
-    int Mp, rows_per_split;
-    float* slabW;                     // [nsplit][IT*16][JT*16]
-    float* slabB;                     // [nsplit][JT*16]
 };
 
 struct WgradPArgs {
@@ -71,7 +63,7 @@ struct SampleArgs {
     const float* head; int ldH; int Dp; int D; int head_per_row;
     int M, Mp, k, B;
     EpsSrc eps;
-    uint16_t* ZP; uint16_t* ZT; int ldT;
+    uint16_t* ZP;
     float* lp_prior; float* lq; float* lq_dreg;
 };
 
@@ -99,7 +91,7 @@ struct LatentBwdArgs {
     EpsSrc eps;
     int B, Bp, k;
     float kmu, ksig;
-    uint16_t* DHP; uint16_t* DHT;     // dhead bf16: P [B][2Dp], T [2Dp][Bp]
+    uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp]
 };
 
 struct GaussBwdArgs {
@@ -110,7 +102,7 @@ struct GaussBwdArgs {
     const float* dz_in; float* dz_direct; int ldDZ;
     EpsSrc eps;
     int M, Mp, k;
-    uint16_t* DHP; uint16_t* DHT; int ldT;
+    uint16_t* DHP;
 };
 
 struct LayerDesc {
@@ -125,11 +117,11 @@ struct LayerDesc {
 
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
-void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st);
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
-void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st);
+void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf, hipStream_t st);
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);
+void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st);
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
 void launch_lse(const LseArgs& a, hipStream_t st);
@@ -144,7 +136,6 @@ void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t s
 void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st);
 void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st);
 void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hipStream_t st);
-void launch_unpack_t(const uint16_t* T, int rows, int F, int ldT, float* out, hipStream_t st);
 void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st);
 
 }  // namespace iwae

@@ -132,7 +132,10 @@ __device__ __forceinline__ void normal4(uint64_t grow, uint32_t d4, uint32_t str
 }
 // 4 consecutive eps values for features 4*d4 .. 4*d4+3 of data row (b,s)
 __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int d4, int D, float n[4]) {
-    if (e.user) {
+    if (e.cache) {
+        const float4 v = *(const float4*)(e.cache + (size_t)row * e.ldC + 4 * d4);
+        n[0] = v.x; n[1] = v.y; n[2] = v.z; n[3] = v.w;
+    } else if (e.user) {
         const float* p = e.user + ((size_t)s * e.B + b) * D + 4 * d4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) n[i] = (4 * d4 + i < D) ? p[i] : 0.0f;
@@ -143,7 +146,7 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 
 // ---------------------------------------------------------------------------------
 // dense_kernel: Y^T[out][rows] = W^T-image x X^T, one wave = 32 data rows (2 column groups of
-// 16, rows interleaved r0+2*rho+g so a T-layout store packs two adjacent rows per lane).
+// 16, rows interleaved r0+2*rho+g).
 // Weights (and the bias of the group, as a trailing 1 KiB block) stream through LDS one
 // 64-out-feature group (x <=8 k-steps) at a time, double buffered with global_load_lds; the
 // data operand lives in registers for K <= 256.  Software pipeline per group u:
@@ -216,9 +219,6 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
         for (int g = 0; g < 2; ++g) { bidx[g] = valid[g] ? row[g] / a.k : 0; sidx[g] = valid[g] ? row[g] - bidx[g] * a.k : 0; }
     }
     // lane-constant byte offsets (32-bit) next to wave-uniform 64-bit bases
-    const uint32_t prow_off[2] = {(uint32_t)(8 * q) * 2u, (uint32_t)(8 * q) * 2u};
-    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
-    (void)prow_off;
 
     auto load_pre = [&](int mg, uint4 (&pre)[2][2]) {
 #pragma unroll
@@ -235,7 +235,6 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 
     // deferred bf16 stores of the previous group
     uint4 stP[2][2];
-    uint32_t stT[2][8];
     int st_mg = -1;
     auto emit_stores = [&]() {
         if (!kPacked || st_mg < 0) return;
@@ -246,12 +245,6 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                     if (valid[g]) *(uint4*)(a.YP + (size_t)row[g] * a.ldYP + fbase + 8 * q) = stP[p][g];
-                if (a.YT) {
-                    char* tb = (char*)a.YT + (size_t)fbase * a.ldT * 2;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[p][j];
-                }
             }
         }
         st_mg = -1;
@@ -336,8 +329,6 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
                     }
                     stP[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) stT[p][j] = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
             }
             st_mg = mg;
         } else if (EPI == EPI_HEAD || EPI == EPI_F32 || EPI == EPI_SIGMOID) {
@@ -418,9 +409,9 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
 // ---------------------------------------------------------------------------------
 // out_bwd_kernel: backward of the Bernoulli output layer for one block of rows, logits
 // recomputed on the fly (never stored): per 64-pixel group
-//   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also written T-layout for dV3)
+//   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also stored, P-layout, for dV3)
 //   dg2 += dl V3^T   (the dl accumulator IS the B operand, no LDS round trip)
-// then dpre2 = dg2 * (1 - g2^2) written P- and T-layout.   (iwae1.py:74-75,111,159)
+// then dpre2 = dg2 * (1 - g2^2), P-layout.   (iwae1.py:74-75,111,159)
 // One wave per SIMD (4 waves, 32 rows each): 16x2 f32x4 accumulators for dg2 stay resident.
 // Same software pipeline as dense_kernel (x prefetched one group ahead, dl stores deferred).
 // ---------------------------------------------------------------------------------
@@ -457,7 +448,6 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
         gx[g] = valid[g] ? a.gx[row[g]] : 0.0f;
     }
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
-    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
 
     auto stage = [&](int ng, int buf) {
         char* d = smem + buf * unit;
@@ -497,7 +487,6 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    uint32_t stT[2][8];
     uint4 stP[2][2];
     int st_ng = -1;
     auto emit_stores = [&]() {
@@ -509,12 +498,6 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                     if (valid[g]) *(uint4*)(a.DLP + (size_t)row[g] * a.Xp32 + fbase + 8 * q) = stP[p][g];
-            }
-            if (fbase < a.Xp32 && a.DLT) {
-                char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[p][j];
             }
         }
         st_ng = -1;
@@ -583,8 +566,6 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
                     bf2[p][g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
                     stP[p][g] = bf2[p][g];
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) stT[p][j] = pack2(v[0][j], v[1][j]);
             }
         };
         if (64 * ng + 64 <= a.Xdim) dl_body(std::false_type{});
@@ -637,11 +618,6 @@ __global__ __launch_bounds__(256, 1) void out_bwd_kernel(OutBwdArgs a) {
                     *(uint4*)(a.DPP + (size_t)row[g] * a.ldG + ks * 32 + 8 * q) =
                         make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
             }
-            char* tb = (char*)a.DPT + (size_t)(ks * 32) * a.ldT * 2;
-            if (a.DPT)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][j] : 0.0f, valid[1] ? v[1][j] : 0.0f);
         }
     }
     OB_STAMP(7)   // final epilogue
@@ -690,7 +666,6 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
     // transposing read: lane 4q'+p of quad q supplies the address of pixel row 4q+q', hidden columns 4p..4p+3
     // (an 8-byte piece of the row's 16-byte chunk p); lane i of the quad receives hidden column i for 4 pixels
     const int tr_off = (4 * q + (rho >> 2)) * 64 + (((rho & 3) ^ hperm(q)) * 16);
-    const uint32_t t_lane_off = ((uint32_t)(4 * q) * (uint32_t)a.ldT + (uint32_t)(r0 + 2 * rho)) * 2u;
 
     // the two weight images of a group are one contiguous LDS unit of NP 1 KiB DMA pieces; wave w moves
     // pieces w, w+8, ...  Piece i of the next group is issued between the MFMAs of the current one.
@@ -735,7 +710,6 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    uint32_t stT[8];
     uint4 stP[2];
     int st_ng = -1;
     auto emit_stores = [&]() {
@@ -745,12 +719,6 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 #pragma unroll
             for (int g = 0; g < 2; ++g)
                 if (valid[g]) *(uint4*)(a.DLP + (size_t)row[g] * a.Xp32 + fbase + 8 * q) = stP[g];
-        }
-        if (fbase < a.Xp32 && a.DLT) {
-            char* tb = (char*)a.DLT + (size_t)fbase * a.ldT * 2;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                *(uint32_t*)(tb + (size_t)(16 * (j >> 2) + (j & 3)) * a.ldT * 2 + t_lane_off) = stT[j];
         }
         st_ng = -1;
     };
@@ -806,8 +774,6 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
                 }
                 own[g] = make_uint4(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]), pack2(v[g][4], v[g][5]), pack2(v[g][6], v[g][7]));
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) stT[j] = pack2(v[0][j], v[1][j]);
             stP[0] = own[0];
             stP[1] = own[1];
         };
@@ -868,11 +834,6 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
             if (valid[g])
                 *(uint2*)(a.DPP + (size_t)row[g] * a.ldG + (mt >> 1) * 32 + 8 * q + 4 * (mt & 1)) = make_uint2(pack2(v[g][0], v[g][1]), pack2(v[g][2], v[g][3]));
         }
-        char* tb = (char*)a.DPT + (size_t)(mt * 16) * a.ldT * 2;
-        if (a.DPT)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *(uint32_t*)(tb + (size_t)i * a.ldT * 2 + t_lane_off) = pack2(valid[0] ? v[0][i] : 0.0f, valid[1] ? v[1][i] : 0.0f);
     }
     OB_STAMP(7)
     if (STAMPS && a.stamps && lane == 0) {
@@ -882,145 +843,7 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 }
 
 // ---------------------------------------------------------------------------------
-// wgrad_kernel: dW[i][j] (+db[j]) partial sums over a range of data rows.
-//   out[i][j] = sum_r AT[i][r] * GT[j][r]      (both operands T-layout, r contiguous)
-// grid = (j-blocks of 128, i-blocks of 256, row splits); 8 waves, wave w owns j-tile w of the
-// block and all <=16 i-tiles (16 accumulator tiles).  Per 128-row chunk the shared A operand is
-// DMA'd into LDS in fragment order (the bank swizzle is applied on the per-lane SOURCE address,
-// the LDS image stays lane-linear), double buffered; each wave's own G fragments are loaded a
-// chunk ahead.  Partials go to fp32 slabs (deterministic, no atomics).
-// ---------------------------------------------------------------------------------
-template <int JW, int NW>     // JW j-tiles per wave, NW waves: the block covers NW*JW j-tiles, A is re-read JT/(NW*JW) times
-__global__ __launch_bounds__(NW * 64, NW / 4) void wgrad_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 x [rs 4][it 16][1 KiB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rho = lane & 15, q = lane >> 4;
-    const int it0 = blockIdx.y * 16;
-    const int nit = min(16, a.IT - it0);
-    const int split = blockIdx.z;
-    const int rbeg = split * a.rows_per_split;
-    const int rend = min(a.Mp, rbeg + a.rows_per_split);
-    const int nchunk = (rend - rbeg + 127) / 128;
-    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
-    int jt[JW];
-    bool jvalid[JW];
-    size_t gsrc_lane[JW];
-#pragma unroll
-    for (int w = 0; w < JW; ++w) {
-        jt[w] = (blockIdx.x * NW + wave) * JW + w;
-        jvalid[w] = jt[w] < a.JT;
-        gsrc_lane[w] = ((size_t)(min(jt[w], a.JT - 1) * 16 + rho) * a.Mp + (size_t)q * 8) * 2;
-    }
-    // DMA source of this lane inside a 16-feature x 32-row fragment block: LDS slot (lane&3) of
-    // feature row (lane>>2) must receive the rows 8*q_src .. 8*q_src+7
-    const int di = lane >> 2, dq = (lane & 3) ^ hperm((lane >> 2) >> 2);
-    const size_t asrc_lane = ((size_t)di * a.Mp + (size_t)dq * 8) * 2;
-
-    auto load_g1 = [&](int c, int w, int rs) {
-        return *(const uint4*)((const char*)a.GT + gsrc_lane[w] + (size_t)(rbeg + c * 128 + rs * 32) * 2);
-    };
-    auto dma_piece = [&](int c, int buf, int idx) {
-        const int blk = wave + NW * idx;      // blk = rs * nit + it  (wave-uniform)
-        if (blk < 4 * nit) {
-            const int rs = blk / nit, it = blk - rs * nit, r = rbeg + c * 128;
-            const char* src = (const char*)a.AT + ((size_t)(it0 + it) * 16 * a.Mp + (size_t)(r + rs * 32)) * 2 + asrc_lane;
-            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * 65536) + (uint32_t)(rs * 16 + it) * 1024u)));
-        }
-    };
-
-    f32x4 acc[16][JW];
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-        for (int w = 0; w < JW; ++w) acc[t][w] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float bsum[JW];
-#pragma unroll
-    for (int w = 0; w < JW; ++w) bsum[w] = 0.0f;
-    uint4 gcur[JW][4];     // G fragments of the current chunk; refilled in place for the next one as soon as a row-step is done
-    if (nchunk > 0) {
-#pragma unroll
-        for (int idx = 0; idx < 64 / NW; ++idx) dma_piece(0, 0, idx);
-#pragma unroll
-        for (int w = 0; w < JW; ++w)
-#pragma unroll
-            for (int rs = 0; rs < 4; ++rs) gcur[w][rs] = load_g1(0, w, rs);
-    }
-
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        wait_all_vmem();
-        __syncthreads();
-        const bool more = c + 1 < nchunk;
-        // the next chunk's A tile is DMA'd piece by piece between the MFMAs below
-        int dma_idx = 0;
-        auto dma_next = [&]() {
-            if (more) dma_piece(c + 1, buf ^ 1, dma_idx);
-            ++dma_idx;
-        };
-        const char* lb = smem + buf * 65536 + a_off;
-#pragma unroll
-        for (int rs = 0; rs < 4; ++rs) {
-#pragma unroll
-            for (int w = 0; w < JW; ++w) {
-                const uint4 g = gcur[w][rs];
-                bsum[w] += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
-            }
-            auto use = [&](int i, const uint4& av) {
-#pragma unroll
-                for (int w = 0; w < JW; ++w) acc[i][w] = mfma16(av, gcur[w][rs], acc[i][w]);
-            };
-            if (NW == 16) {           // one code path keeps the 128-register budget of the 16-wave block
-                lds_pipeline<16, 3>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); },
-                                    [&](int i, const uint4& av) { if (i < nit) use(i, av); },
-                                    [&](int i) { if (i == 0) dma_next(); });
-            } else if (nit == 14) {   // hidden width 200 -> 224: straight-line, pipelined LDS reads
-                lds_pipeline<14, 7>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
-                                    [&](int i) { if (i == 0 || i == 7) dma_next(); });
-            } else if (nit == 16) {
-                lds_pipeline<16, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
-                                    [&](int i) { if (i == 0 || i == 8) dma_next(); });
-            } else if (nit == 8) {
-                lds_pipeline<8, 8>([&](int i) { return *(const uint4*)(lb + (rs * 16 + i) * 1024); }, use,
-                                   [&](int i) { if (i == 0) dma_next(); });
-            } else {
-                dma_next();
-                dma_next();
-#pragma unroll
-                for (int it = 0; it < 16; ++it)
-                    if (it < nit) use(it, *(const uint4*)(lb + (rs * 16 + it) * 1024));
-            }
-            if (more) {
-#pragma unroll
-                for (int w = 0; w < JW; ++w) gcur[w][rs] = load_g1(c + 1, w, rs);
-            }
-        }
-        while (dma_idx < 64 / NW) dma_next();      // 4*nit <= 64 pieces
-    }
-
-    // D: lane(col j = rho, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
-    float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
-#pragma unroll
-    for (int w = 0; w < JW; ++w) {
-        if (!jvalid[w]) continue;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            if (it < nit) {
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt[w] * 16 + rho] = acc[it][w][ii];
-            }
-        }
-        if (blockIdx.y == 0) {
-            float v = bsum[w];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt[w] * 16 + rho] = v;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// wgradp_kernel: weight gradient straight from the ROW-major P-layout activations (no T-layout copies):
+// wgradp_kernel: weight gradient straight from the ROW-major P-layout activations (no feature-major copies):
 //   out[i][j] = sum_r X[r][i] * G[r][j],   X: bf16 [rows][ldX], G: bf16 [rows][ldG]  (both P-layout)
 // The contraction index (data row) is the strided one in memory, so both MFMA operands are produced by the
 // hardware-transposing LDS read: per 64-row chunk the X tile (<=256 features) and the G strip (NW*16
@@ -1143,9 +966,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
 // ---------------------------------------------------------------------------------
 // elementwise / reduction kernels
 // ---------------------------------------------------------------------------------
-// x fp32 [B][X] -> bf16 P-layout [B][Xp] and T-layout [Xp][Bp] (pads written as zero).
+// x fp32 [B][X] -> bf16 P-layout [B][Xp] (pads written as zero).
 // block = 64 rows (lanes) x 4 chunk-waves; a thread converts one 8-feature P chunk of one row.
-__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT) {
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 64 + lane;
     const int nchunk = Xp / 8;
@@ -1158,10 +981,6 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, i
             const int f0 = 32 * t + 16 * h + 4 * qq;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[4 * h + i] = (b < B && f0 + i < X) ? x[(size_t)b * X + f0 + i] : 0.0f;
-            if (XT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) XT[(size_t)(f0 + i) * Bp + b] = (uint16_t)(pack2(v[4 * h + i], 0.0f) & 0xffffu);
-            }
         }
         if (b < B) *(uint4*)(XP + (size_t)b * Xp + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
@@ -1172,9 +991,9 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, i
 // 1 iff (philox(seed, epoch, image, f/4)[f%4] >> 8) < T(gray), T(g) = floor(g * 2^24 / 255 + 0.5), i.e.
 // Bernoulli(gray/255) with an integer threshold (bit-exactly reproducible on the host).  Keyed by
 // (epoch, image): one binarisation per image per epoch, as in the reference.  Same block shape and
-// outputs as prep_rows_kernel (P-layout, T-layout) + optional float32 copy.
+// output as prep_rows_kernel (P-layout) + optional float32 copy.
 __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp,
-                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf) {
+                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, float* xf) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 64 + lane;
     const int nchunk = Xp / 8;
@@ -1198,60 +1017,78 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
                     if (xf) xf[(size_t)b * X + f0 + i] = bit;
                 }
                 v[4 * h + i] = bit;
-                if (XT) XT[(size_t)(f0 + i) * Bp + b] = (uint16_t)(pack2(bit, 0.0f) & 0xffffu);
             }
         }
         if (b < B) *(uint4*)(XP + (size_t)b * Xp + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
 }
 
-// z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P (+T).
-// block = 64 data rows (lanes) x Dp/8 waves, wave c owns the 8 features of P-layout chunk c:
-// the T-layout store is a full 128 B line per feature, the row sums go through LDS.
-__global__ void sample_kernel(SampleArgs a) {
-    __shared__ float red[3][16][64];
-    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6, nc = a.Dp / 8;
-    const int row = blockIdx.x * 64 + lane;
+// The N(0,1) draws of one latent layer for a whole step, fp32 [rows][ld] (4 per thread).  They depend on nothing but
+// the counters, so the host launches this on the side stream at the top of the step: the ~40 quarter-rate integer
+// multiplies per Philox call run in the shadow of the (small, latency-bound) encoder forward.
+__global__ __launch_bounds__(256) void eps_gen_kernel(EpsSrc e, int M, int nd4, int ld, float* out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * nd4) return;
+    const int row = (int)(idx / nd4), d4 = (int)(idx - (size_t)row * nd4);
+    float n[4];
+    normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
+    *(float4*)(out + (size_t)row * ld + 4 * d4) = make_float4(n[0], n[1], n[2], n[3]);
+}
+
+// z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P-layout.
+// wave = 16 data rows x 4 quads.  In every 32-feature step t lane (r, q) owns P-layout chunk 4t+q, i.e. features
+// 32t+4q..+3 and 32t+16+4q..+3: float4 loads of eps / mu / sigma, one 16-byte store per step, and the row sums
+// meet across the 4 quads with two shuffles -- no LDS, no barrier, 800 small blocks instead of 800 of 1024 threads.
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + r;
     const bool valid = row < a.M;
-    const int b = valid ? row / a.k : 0, s = valid ? row - b * a.k : 0;
-    const float* hd = a.head + (size_t)(a.head_per_row ? (valid ? row : 0) : b) * a.ldH;
+    const int rowc = valid ? row : a.M - 1;        // loads come from a clamped row, results are masked
+    const int b = rowc / a.k, s = rowc - b * a.k;
+    const float* hd = a.head + (size_t)(a.head_per_row ? rowc : b) * a.ldH;
     float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
-    const int t = c >> 2, qq = c & 3;
-    float z8[8];
+    const int nt = a.Dp / 32;
+    for (int t = 0; t < nt; ++t) {
+        float z8[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int f0 = 32 * t + 16 * h + 4 * qq;
-        float e[4];
-        eps4(a.eps, b, s, row, f0 >> 2, a.D, e);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = f0 + i;
-            float z = 0.0f;
-            if (valid && f < a.D) {
-                const float mu = hd[f], sg = hd[a.Dp + f];
-                z = mu + sg * e[i];                                  // iwae1.py:59
-                lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
-                const float u = (z - mu) / sg;
-                lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
-                if (a.lq_dreg) {                                     // tasks/task02.py:63-65
-                    const float s2 = sg + 1e-6f, u2 = (z - mu) / s2;
-                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
-                }
+        for (int h = 0; h < 2; ++h) {
+            const int f0 = 32 * t + 16 * h + 4 * q;
+            float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float4 mu4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sg4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            if (f0 < a.D) {
+                eps4(a.eps, b, s, rowc, f0 >> 2, a.D, e);
+                mu4 = *(const float4*)(hd + f0);
+                sg4 = *(const float4*)(hd + a.Dp + f0);
             }
-            z8[4 * h + i] = z;
-            if (a.ZT) a.ZT[(size_t)f * a.ldT + row] = (uint16_t)(pack2(z, 0.0f) & 0xffffu);
+            const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float z = 0.0f;
+                if (f0 + i < a.D) {
+                    const float mu = muv[i], sg = sgv[i];
+                    z = mu + sg * e[i];                                  // iwae1.py:59
+                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
+                    const float u = (z - mu) * __builtin_amdgcn_rcpf(sg);
+                    lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
+                    if (a.lq_dreg) {                                     // tasks/task02.py:63-65
+                        const float s2 = sg + 1e-6f, u2 = (z - mu) * __builtin_amdgcn_rcpf(s2);
+                        lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
+                    }
+                }
+                z8[4 * h + i] = z;
+            }
         }
+        if (valid)
+            *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * (4 * t + q)) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
     }
-    if (valid)
-        *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * c) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
-    red[0][c][lane] = lp; red[1][c][lane] = lq; red[2][c][lane] = lq2;
-    __syncthreads();
-    if (c == 0 && valid) {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-        for (int i = 0; i < nc; ++i) { s0 += red[0][i][lane]; s1 += red[1][i][lane]; s2 += red[2][i][lane]; }
-        if (a.lp_prior) a.lp_prior[row] = s0;
-        a.lq[row] = s1;
-        if (a.lq_dreg) a.lq_dreg[row] = s2;
+    lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+    lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
+    lq2 += __shfl_xor(lq2, 16); lq2 += __shfl_xor(lq2, 32);
+    if (q == 0 && valid) {
+        if (a.lp_prior) a.lp_prior[row] = lp;
+        a.lq[row] = lq;
+        if (a.lq_dreg) a.lq_dreg[row] = lq2;
     }
 }
 
@@ -1420,21 +1257,40 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             mu[i] = ok ? a.head[(size_t)b * a.ldH + f0 + i] : 0.0f;
             sgm[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
         }
-        for (int s = sg; s < a.k; s += SG) {
-            const int row = b * a.k + s;
-            const float4 dz = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
-            const float4 cf = a.cf[row];
-            float e[4];
-            eps4(a.eps, b, s, row, f4, a.D, e);
-            const float dzv[4] = {dz.x, dz.y, dz.z, dz.w};
+        float rs2[4], rsg[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (f0 + i < a.D) {
-                    const float z = mu[i] + sgm[i] * e[i];
-                    const float s2 = sgm[i] + 1e-6f;
-                    const float t = cf.x * dzv[i] + cf.y * z + cf.z * (z - mu[i]) / (s2 * s2);
-                    dmu[i] += t;
-                    dsg[i] += t * e[i] + cf.w / sgm[i];
+        for (int i = 0; i < 4; ++i) {
+            const float s2 = sgm[i] + 1e-6f;
+            rs2[i] = 1.0f / (s2 * s2);
+            rsg[i] = 1.0f / sgm[i];
+        }
+        // the sample loop is latency-bound (3 dependent-free loads, little math): keep UN iterations' loads in flight
+        constexpr int UN = 4;
+        for (int s0 = sg; s0 < a.k; s0 += UN * SG) {
+            float4 dz[UN], cf[UN];
+            float e[UN][4];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int s = s0 + u * SG;
+                const bool ok = s < a.k;
+                const int sc = ok ? s : a.k - 1;          // clamped, weighted by 0 below
+                const int row = b * a.k + sc;
+                dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
+                cf[u] = a.cf[row];
+                if (!ok) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                eps4(a.eps, b, sc, row, f4, a.D, e[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float dzv[4] = {dz[u].x, dz[u].y, dz[u].z, dz[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (f0 + i < a.D) {
+                        const float z = mu[i] + sgm[i] * e[u][i];
+                        const float t = cf[u].x * dzv[i] + cf[u].y * z + cf[u].z * (z - mu[i]) * rs2[i];
+                        dmu[i] += t;
+                        dsg[i] += t * e[u][i] + cf[u].w * rsg[i];
+                    }
                 }
             }
         }
@@ -1459,13 +1315,6 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
     if (b < a.B) {
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
-    }
-    if (a.DHT) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a.DHT[(size_t)(f0 + i) * a.Bp + b] = (uint16_t)(pack2(dmu[i], 0.0f) & 0xffffu);
-            a.DHT[(size_t)(a.Dp + f0 + i) * a.Bp + b] = (uint16_t)(pack2(dsg[i], 0.0f) & 0xffffu);
-        }
     }
 }
 
@@ -1513,13 +1362,6 @@ __global__ void gauss_bwd_kernel(GaussBwdArgs a) {
         *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dm[0], dm[1]), pack2(dm[2], dm[3]));
         *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
         if (a.mode == 0) *(float4*)(a.dz_direct + (size_t)row * a.ldDZ + f0) = make_float4(dzd[0], dzd[1], dzd[2], dzd[3]);
-    }
-    if (a.DHT) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a.DHT[(size_t)(f0 + i) * a.ldT + row] = (uint16_t)(pack2(dm[i], 0.0f) & 0xffffu);
-            a.DHT[(size_t)(a.Dp + f0 + i) * a.ldT + row] = (uint16_t)(pack2(ds[i], 0.0f) & 0xffffu);
-        }
     }
 }
 
@@ -1649,12 +1491,6 @@ __global__ void unpack_p_kernel(const uint16_t* P, int rows, int F, int Fp, floa
     const int r = idx / F, f = idx % F;
     out[idx] = __uint_as_float((uint32_t)P[(size_t)r * Fp + p_pos(f)] << 16);
 }
-__global__ void unpack_t_kernel(const uint16_t* T, int rows, int F, int ldT, float* out) {   // T-layout bf16 -> [rows][F] fp32
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * F) return;
-    const int r = idx / F, f = idx % F;
-    out[idx] = __uint_as_float((uint32_t)T[(size_t)f * ldT + r] << 16);
-}
 __global__ void eps_dump_kernel(EpsSrc e, int B, int k, int D, float* out) {   // [k][B][D]
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int nd4 = (D + 3) / 4;
@@ -1701,7 +1537,7 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     // MFMA phase overlaps the other's sigmoid epilogue / DMA.
     constexpr int PAIRS = 2;
     const size_t ldsp = 2 * ((size_t)a.KT * 4096 + 1024) + (size_t)PAIRS * 4096;
-    dim3 gridp(a.ldT / (PAIRS * 32));      // the PADDED row count (multiple of 128): T-layout pad columns are written as zeros
+    dim3 gridp((a.M + PAIRS * 32 - 1) / (PAIRS * 32));
     if (a.stamps) {   // diagnostic build
         hipLaunchKernelGGL((out_bwd_pair_kernel<7, PAIRS, true>), gridp, dim3(PAIRS * 128), 2 * ((size_t)7 * 4096 + 1024) + (size_t)PAIRS * 4096, st, a);
         return;
@@ -1716,27 +1552,26 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
         }
     }
 }
-void launch_wgrad(const WgradArgs& a, int nsplit, int jw, hipStream_t st) {      // jw = 2: 16-wave blocks (256 out-features)
-    dim3 grid((a.JT + 8 * jw - 1) / (8 * jw), (a.IT + 15) / 16, nsplit);
-    if (jw == 2) hipLaunchKernelGGL((wgrad_kernel<1, 16>), grid, dim3(1024), 131072, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<1, 8>), grid, dim3(512), 131072, st, a);
-}
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
     dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);
     if (nw == 16) hipLaunchKernelGGL(wgradp_kernel<16>, grid, dim3(1024), 2 * (64 * 512 + 64 * 512), st, a);
     else hipLaunchKernelGGL(wgradp_kernel<8>, grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
 }
-void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, uint16_t* XT, hipStream_t st) {
+void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st) {
     const int nchunk = Xp / 8;
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, B, X, Xp, Bp, XP, XT);
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, B, X, Xp, Bp, XP);
 }
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, uint16_t* XT, float* xf, hipStream_t st) {
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st) {
     const int nchunk = Xp / 8;
     hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
-                       Bp, seed, epoch, XP, XT, xf);
+                       Bp, seed, epoch, XP, xf);
 }
-void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3(a.Mp / 64), dim3(64 * (a.Dp / 8)), 0, st, a); }
+void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st) {
+    const int nd4 = (D + 3) / 4;
+    hipLaunchKernelGGL(eps_gen_kernel, grid1((size_t)M * nd4, 256), dim3(256), 0, st, e, M, nd4, ld, out);
+}
+void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
@@ -1769,9 +1604,6 @@ void launch_snis(const float* z, const float* wn, int B, int k, int D, float* ou
 }
 void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hipStream_t st) {
     hipLaunchKernelGGL(unpack_p_kernel, grid1((size_t)rows * F, 256), dim3(256), 0, st, P, rows, F, Fp, out);
-}
-void launch_unpack_t(const uint16_t* T, int rows, int F, int ldT, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(unpack_t_kernel, grid1((size_t)rows * F, 256), dim3(256), 0, st, T, rows, F, ldT, out);
 }
 void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st) {
     hipLaunchKernelGGL(eps_dump_kernel, grid1((size_t)B * k * ((D + 3) / 4), 256), dim3(256), 0, st, e, B, k, D, out);

@@ -17,8 +17,9 @@
 // P-layout  (bf16 [rows][Fp], Fp = round_up(F,32)): features stored in ownership
 //           order so a lane's 8 values of one k-step are 16 contiguous bytes:
 //           position(f) = 32*(f/32) + 8*((f%16)/4) + 4*((f%32)/16) + f%4.
-// T-layout  (bf16 [Fp][Mp]): feature-major, natural feature index, row index
-//           contiguous; the weight-gradient GEMM reads both operands from it.
+//           Every activation and activation-gradient lives in HBM in this one layout; the
+//           weight-gradient GEMM (reduction over rows) transposes 4x4 blocks on the way out of
+//           LDS with ds_read_b64_tr_b16 instead of keeping feature-major copies.
 // A-image   (bf16 weights as the MFMA A operand, already in LDS order): 1 KiB blocks
 //           of 16 out-features x 32 in-features; lane(rr,q) reads 16 B at
 //           rr*64 + ((q ^ hp(rr>>2))*16), which is bank-conflict-free for

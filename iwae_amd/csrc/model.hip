@@ -59,10 +59,10 @@ struct Linear {
 };
 
 struct BlockWs {   // activations / gradients of one BasicBlock applied to R rows
-    DevBuf h1P, h1T, h2P, h2T, head, dheadP, dheadT, d2P, d2T, d1P, d1T, dx;
+    DevBuf h1P, h2P, head, dheadP, d2P, d1P, dx;
 };
 struct MlpWs {     // decode_z_to_x applied to M rows
-    DevBuf g1P, g1T, g2P, g2T, dlT, dlP, d2P, d2T, d1P, d1T, dz;
+    DevBuf g1P, g2P, dlP, d2P, d1P, dz;
 };
 
 }  // namespace
@@ -89,7 +89,7 @@ struct iwae_model {
     int B = 0, k = 0, M = 0, Mp = 0, Bp = 0;
     float beta = 1.0f;
     bool have_forward = false, user_eps = false;
-    DevBuf xin, xP, xT, epsbuf, zP[2], zT[2];
+    DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
     DevBuf logw, wn, gx, cf, per_b, dzsum, dzdir;
     BlockWs wenc1, wenc2, wdec2;
@@ -99,7 +99,15 @@ struct iwae_model {
     DevBuf ds_data, ds_order;
     int ds_N = 0;
     int wg_target16 = 256;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid)
-    bool use_t = false;        // IWAE_WGRAD_T=1: legacy weight-gradient path reading T-layout copies
+    // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling and
+    // backward kernels.  A training step draws the NEXT step's noise on the side stream behind its weight gradients
+    // (speculating step+1, same batch shape), so the Philox work runs in the shadow of the encoder backward and is
+    // ordered by the join the main stream performs anyway; a forward whose counters do not match the speculation
+    // draws on its own stream first.  Two buffers: the prefetch never overwrites what this step still reads.
+    DevBuf epsc[2][2];          // [parity][layer]
+    struct EpsTag { bool valid = false; uint32_t step = 0; uint64_t row_offset = 0; int M = 0; } eps_tag[2];
+    int epsc_par = 0;
+    const float* epsc_ptr[2] = {nullptr, nullptr};
     char* d_zero = nullptr;    // 1 KiB of zeros (wgradp_kernel's source for rows >= M)
     uint32_t ds_epoch = 0;
     int ds_start = -1;         // >= 0: the next forward gathers + binarises rows ds_start.. from the dataset instead of reading x
@@ -300,6 +308,8 @@ struct ScopedTimer {     // records a start/stop event pair around a launch when
 EpsSrc eps_src(iwae_model* m, int layer) {
     EpsSrc e;
     e.user = nullptr;
+    e.cache = m->epsc_ptr[layer];
+    e.ldC = m->Dp[layer];
     if (m->user_eps) e.user = ptr<float>(m->epsbuf) + (layer == 0 ? 0 : (size_t)m->k * m->B * m->D[0]);
     e.B = m->B;
     e.seed = m->cfg.seed;
@@ -310,13 +320,13 @@ EpsSrc eps_src(iwae_model* m, int layer) {
 }
 
 // ---------------------------------------------------------------- forward pieces
-int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, int rowsP, uint16_t* YP, uint16_t* YT, float* YF, int ldYF) {
+int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, uint16_t* YP, float* YF, int ldYF) {
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
     a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
     a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32;
-    a.YP = YP; a.ldYP = L.Np32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = ldYF;
+    a.YP = YP; a.ldYP = L.Np32; a.YF = YF; a.ldYF = ldYF;
     launch_dense(epi, a, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -325,54 +335,26 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, i
 int block_alloc(iwae_model* m, Linear* blk, BlockWs& w, int R, int Rp, bool bwd, bool need_dx) {
     const int Hp = blk[0].Np32, N2 = blk[2].Np32;
     CHK(ensure(w.h1P, (size_t)Rp * Hp * 2, m->stream));
-    CHK(ensure(w.h1T, (size_t)Rp * Hp * 2, m->stream));
     CHK(ensure(w.h2P, (size_t)Rp * Hp * 2, m->stream));
-    CHK(ensure(w.h2T, (size_t)Rp * Hp * 2, m->stream));
     CHK(ensure(w.head, (size_t)Rp * N2 * 4, m->stream));
     if (bwd) {
         CHK(ensure(w.dheadP, (size_t)Rp * N2 * 2, m->stream));
-        CHK(ensure(w.dheadT, (size_t)Rp * N2 * 2, m->stream));
         CHK(ensure(w.d2P, (size_t)Rp * Hp * 2, m->stream));
-        CHK(ensure(w.d2T, (size_t)Rp * Hp * 2, m->stream));
         CHK(ensure(w.d1P, (size_t)Rp * Hp * 2, m->stream));
-        CHK(ensure(w.d1T, (size_t)Rp * Hp * 2, m->stream));
         if (need_dx) CHK(ensure(w.dx, (size_t)Rp * blk[0].Kp32 * 4, m->stream));
     }
     (void)R;
     return IWAE_OK;
 }
 
-int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R, int Rp) {
-    CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, Rp, ptr<uint16_t>(w.h1P), m->use_t ? ptr<uint16_t>(w.h1T) : nullptr, nullptr, 0));
-    CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, Rp, ptr<uint16_t>(w.h2P), m->use_t ? ptr<uint16_t>(w.h2T) : nullptr, nullptr, 0));
-    CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, Rp, nullptr, nullptr, ptr<float>(w.head), blk[2].Np32));
+int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R) {
+    CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, ptr<uint16_t>(w.h1P), nullptr, 0));
+    CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, ptr<uint16_t>(w.h2P), nullptr, 0));
+    CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, nullptr, ptr<float>(w.head), blk[2].Np32));
     return IWAE_OK;
 }
 
 // ---------------------------------------------------------------- backward pieces
-int wgrad(iwae_model* m, Linear& L, const uint16_t* AT, const uint16_t* GT, int Rp, hipStream_t st = nullptr) {
-    if (!st) st = m->stream;
-    const int chunks = Rp / 128;
-    // wide j-blocks (256 out-features per block) halve the re-reads of the A operand; worth it once the
-    // row count is large enough to fill the chip with row splits
-    const int jw = (chunks >= 64 && L.JT >= 32) ? 2 : 1;
-    const int blocks = ((L.JT + 8 * jw - 1) / (8 * jw)) * ((L.IT + 15) / 16);
-    int nsplit = std::max(1, std::min(chunks, 256 / std::max(1, blocks)));
-    const int cps = (chunks + nsplit - 1) / nsplit;
-    nsplit = (chunks + cps - 1) / cps;
-    const size_t needW = (size_t)nsplit * L.IT * 16 * L.JT * 16 * 4, needB = (size_t)nsplit * L.JT * 16 * 4;
-    void* oldW = L.slabW.p; void* oldB = L.slabB.p;
-    CHK(ensure(L.slabW, needW, m->stream));
-    CHK(ensure(L.slabB, needB, m->stream));
-    if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
-    WgradArgs a;
-    a.AT = AT; a.IT = L.IT; a.GT = GT; a.JT = L.JT; a.Mp = Rp; a.rows_per_split = cps * 128;
-    a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB);
-    launch_wgrad(a, nsplit, jw, st);
-    HIPCHK(hipGetLastError());
-    return IWAE_OK;
-}
-
 // weight gradient from the P-layout operands (wgradp_kernel); XP/GP row-major bf16, `rows` valid rows
 int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr) {
     if (!st) st = m->stream;
@@ -399,35 +381,26 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
 }
 
 // dX (times tanh' of the stored activation, or raw fp32) of a layer: X = dpre of the layer's outputs
-int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, int rowsP, const uint16_t* ACT, uint16_t* YP, uint16_t* YT, float* YF) {
+int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint16_t* ACT, uint16_t* YP, float* YF) {
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.X = GP; a.ldX = L.Np32; a.img = L.imgB;
     a.split = 1 << 30;
     a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = (rows <= 8192) ? 1 : L.MG_B; a.Np32 = L.Kp32;
-    a.YP = YP; a.ldYP = L.Kp32; a.YT = YT; a.ldT = rowsP; a.YF = YF; a.ldYF = L.Kp32;
+    a.YP = YP; a.ldYP = L.Kp32; a.YF = YF; a.ldYF = L.Kp32;
     a.ACT = ACT; a.ldACT = L.Kp32;
     launch_dense(ACT ? EPI_DX : EPI_F32, a, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
 
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inT, const uint16_t* inP, int R, int Rp, bool need_dx) {
-    if (!m->use_t) {
-        CHK(wgradp(m, blk[2], ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.dheadP), R));
-        CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr, nullptr));
-        CHK(wgradp(m, blk[1], ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d2P), R));
-        CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr, nullptr));
-        CHK(wgradp(m, blk[0], inP, ptr<uint16_t>(w.d1P), R));
-        if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, Rp, nullptr, nullptr, nullptr, ptr<float>(w.dx)));
-        return IWAE_OK;
-    }
-    CHK(wgrad(m, blk[2], ptr<uint16_t>(w.h2T), ptr<uint16_t>(w.dheadT), Rp));
-    CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, Rp, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d2T), nullptr));
-    CHK(wgrad(m, blk[1], ptr<uint16_t>(w.h1T), ptr<uint16_t>(w.d2T), Rp));
-    CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, Rp, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
-    CHK(wgrad(m, blk[0], inT, ptr<uint16_t>(w.d1T), Rp));
-    if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, Rp, nullptr, nullptr, nullptr, ptr<float>(w.dx)));
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx) {
+    CHK(wgradp(m, blk[2], ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.dheadP), R));
+    CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
+    CHK(wgradp(m, blk[1], ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d2P), R));
+    CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
+    CHK(wgradp(m, blk[0], inP, ptr<uint16_t>(w.d1P), R));
+    if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
     return IWAE_OK;
 }
 
@@ -443,6 +416,22 @@ int copy_out(iwae_model* m, void* dst, const void* src, size_t bytes) {
 }
 
 // ---------------------------------------------------------------- the forward pass
+// fills eps buffer `par` with the draws of (step, current batch offset) for M data rows on stream gs
+int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs) {
+    const int Mp = round_up(M, 128);
+    iwae_model::EpsTag& tg = m->eps_tag[par];
+    tg.valid = false;
+    for (int l = 0; l < m->cfg.n_layers; ++l) {
+        CHK(ensure(m->epsc[par][l], (size_t)Mp * m->Dp[l] * 4, m->stream));
+        EpsSrc e = eps_src(m, l);
+        e.user = nullptr; e.cache = nullptr; e.step = step;
+        launch_eps_gen(e, M, m->D[l], m->Dp[l], ptr<float>(m->epsc[par][l]), gs);
+    }
+    HIPCHK(hipGetLastError());
+    tg.valid = true; tg.step = step; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
+    return IWAE_OK;
+}
+
 int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd,
                  const iwae_tensors* want) {
     const bool from_ds = m->ds_start >= 0;
@@ -455,22 +444,32 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
     hipStream_t st = m->stream;
     m->user_eps = eps != nullptr;
+    // ---- the step's N(0,1) draws: normally already there (prefetched by the previous training step), else drawn now
+    const bool keep_eps = !eps && (bwd || two);
+    m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
+    if (keep_eps) {
+        const int np = m->epsc_par ^ 1;
+        const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
+        iwae_model::EpsTag& tg = m->eps_tag[np];
+        if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) CHK(draw_eps(m, np, m->noise_step, M, st));
+        m->epsc_par = np;
+        for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
+    }
     if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
     CHK(ensure(m->xP, (size_t)Bp * Xp * 2, st));
-    CHK(ensure(m->xT, (size_t)Bp * Xp * 2, st));
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), m->use_t ? ptr<uint16_t>(m->xT) : nullptr, nullptr, st);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
         m->ds_start = -1;
     } else {
         CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
-        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), m->use_t ? ptr<uint16_t>(m->xT) : nullptr, st);
+        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), st);
     }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
     CHK(block_alloc(m, m->enc1, m->wenc1, B, Bp, bwd, false));
-    CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, Bp));
+    CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B));
 
     for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
     float* lpxz = ptr<float>(m->rows[0]);
@@ -481,14 +480,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     float* lqd = ptr<float>(m->rows[5]);
 
     // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
+    // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
-    CHK(ensure(m->zT[0], (size_t)Mp * m->Dp[0] * 2, st));
     {
         SampleArgs s;
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
-        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = m->use_t ? ptr<uint16_t>(m->zT[0]) : nullptr; s.ldT = Mp;
+        s.ZP = ptr<uint16_t>(m->zP[0]);
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
@@ -498,18 +497,17 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (two) {
         // ---- q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
         CHK(block_alloc(m, m->enc2, m->wenc2, M, Mp, bwd, true));
-        CHK(block_fwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, Mp));
+        CHK(block_fwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M));
         CHK(ensure(m->zP[1], (size_t)Mp * m->Dp[1] * 2, st));
-        CHK(ensure(m->zT[1], (size_t)Mp * m->Dp[1] * 2, st));
         SampleArgs s;
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc2.head); s.ldH = 2 * m->Dp[1]; s.Dp = m->Dp[1]; s.D = m->D[1]; s.head_per_row = 1;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 1);
-        s.ZP = ptr<uint16_t>(m->zP[1]); s.ZT = m->use_t ? ptr<uint16_t>(m->zT[1]) : nullptr; s.ldT = Mp;
+        s.ZP = ptr<uint16_t>(m->zP[1]);
         s.lp_prior = t2; s.lq = t4; s.lq_dreg = nullptr;
         launch_sample(s, st);
         CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
-        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, Mp));
+        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M));
         GaussLpArgs g;
         memset(&g, 0, sizeof(g));
         g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
@@ -522,11 +520,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     MlpWs& w = m->wdec1;
     const int Hp = m->dec1[0].Np32;
     CHK(ensure(w.g1P, (size_t)Mp * Hp * 2, st));
-    CHK(ensure(w.g1T, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.g2P, (size_t)Mp * Hp * 2, st));
-    CHK(ensure(w.g2T, (size_t)Mp * Hp * 2, st));
-    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, Mp, ptr<uint16_t>(w.g1P), (bwd && m->use_t) ? ptr<uint16_t>(w.g1T) : nullptr, nullptr, 0));
-    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, Mp, ptr<uint16_t>(w.g2P), (bwd && m->use_t) ? ptr<uint16_t>(w.g2T) : nullptr, nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
     {
         Linear& L = m->dec1[2];
         DenseArgs a;
@@ -590,11 +586,9 @@ int backward_impl(iwae_model* m, int objective) {
     hipStream_t st = m->stream;
     MlpWs& w = m->wdec1;
     const int Hp = m->dec1[0].Np32;
-    CHK(ensure(m->use_t ? w.dlT : w.dlP, (size_t)Mp * Xp * 2, st));
+    CHK(ensure(w.dlP, (size_t)Mp * Xp * 2, st));
     CHK(ensure(w.d2P, (size_t)Mp * Hp * 2, st));
-    CHK(ensure(w.d2T, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
-    CHK(ensure(w.d1T, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.dz, (size_t)Mp * m->Dp[0] * 4, st));
     {
         Linear& L = m->dec1[2];
@@ -604,8 +598,7 @@ int backward_impl(iwae_model* m, int objective) {
         a.Xdim = X; a.Xp32 = Xp;
         a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
         a.M = M; a.KT = L.KT; a.NG = L.MG;
-        a.DLT = m->use_t ? ptr<uint16_t>(w.dlT) : nullptr; a.ldT = Mp; a.DPP = ptr<uint16_t>(w.d2P); a.DPT = m->use_t ? ptr<uint16_t>(w.d2T) : nullptr;
-        a.DLP = m->use_t ? nullptr : ptr<uint16_t>(w.dlP);
+        a.DLP = ptr<uint16_t>(w.dlP); a.DPP = ptr<uint16_t>(w.d2P);
         if (m->want_stamps && L.KT == 7) {
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
@@ -618,23 +611,15 @@ int backward_impl(iwae_model* m, int objective) {
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    if (m->use_t) {
-        CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(w.d1T), nullptr));
-        HIPCHK(hipEventRecord(m->ev_fork2, st));
-        { ScopedTimer tm(m, 2, m->side); CHK(wgrad(m, m->dec1[2], ptr<uint16_t>(w.g2T), ptr<uint16_t>(w.dlT), Mp, m->side)); }
-        CHK(wgrad(m, m->dec1[1], ptr<uint16_t>(w.g1T), ptr<uint16_t>(w.d2T), Mp, m->side));
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-        CHK(wgrad(m, m->dec1[0], ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(w.d1T), Mp, m->side));
-    } else {
-        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side)); }
-        CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, Mp, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr, nullptr));
-        HIPCHK(hipEventRecord(m->ev_fork2, st));
-        CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-        CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
-    }
+    { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side)); }
+    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr));
+    HIPCHK(hipEventRecord(m->ev_fork2, st));
+    CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+    CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
+    if (!m->user_eps) CHK(draw_eps(m, m->epsc_par ^ 1, m->noise_step + 1, M, m->side));    // next step's noise (speculative)
     HIPCHK(hipEventRecord(m->ev_join, m->side));
-    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, Mp, nullptr, nullptr, nullptr, ptr<float>(w.dz)));
+    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
 
     const float* dz1 = ptr<float>(w.dz);
     if (two) {
@@ -648,17 +633,17 @@ int backward_impl(iwae_model* m, int objective) {
         g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
         g.dz_direct = ptr<float>(m->dzdir); g.ldDZ = m->Dp[0];
         g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
-        g.DHP = ptr<uint16_t>(m->wdec2.dheadP); g.DHT = m->use_t ? ptr<uint16_t>(m->wdec2.dheadT) : nullptr; g.ldT = Mp;
+        g.DHP = ptr<uint16_t>(m->wdec2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zT[1]), ptr<uint16_t>(m->zP[1]), M, Mp, true));
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true));
         memset(&g, 0, sizeof(g));
         g.mode = 1; g.G = ptr<float>(m->gx);
         g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
         g.dz_in = ptr<float>(m->wdec2.dx); g.ldDZ = m->Dp[1];
         g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
-        g.DHP = ptr<uint16_t>(m->wenc2.dheadP); g.DHT = m->use_t ? ptr<uint16_t>(m->wenc2.dheadT) : nullptr; g.ldT = Mp;
+        g.DHP = ptr<uint16_t>(m->wenc2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zT[0]), ptr<uint16_t>(m->zP[0]), M, Mp, true));
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true));
         launch_add3(ptr<float>(m->dzsum), ptr<float>(w.dz), ptr<float>(m->dzdir), ptr<float>(m->wenc2.dx), (size_t)M * m->Dp[0], st);
         dz1 = ptr<float>(m->dzsum);
     }
@@ -670,10 +655,10 @@ int backward_impl(iwae_model* m, int objective) {
         a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
         a.B = B; a.Bp = Bp; a.k = k;
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
-        a.DHP = ptr<uint16_t>(m->wenc1.dheadP); a.DHT = m->use_t ? ptr<uint16_t>(m->wenc1.dheadT) : nullptr;
+        a.DHP = ptr<uint16_t>(m->wenc1.dheadP);
         launch_latent_bwd(a, st);
     }
-    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xT), ptr<uint16_t>(m->xP), B, Bp, false));
+    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false));
     HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
     if (m->descs_dirty) CHK(build_descs(m));
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, st);
@@ -784,7 +769,6 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     iwae_model* m = new iwae_model();
     m->cfg = *cfg;
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
-    m->use_t = getenv("IWAE_WGRAD_T") != nullptr;
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
 
     m->X = cfg->x_dim;
@@ -846,18 +830,18 @@ void iwae_destroy(iwae_handle m) {
     (void)hipSetDevice(m->cfg.device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (Linear* L : all_linears(m)) free_linear(*L);
-    DevBuf* bufs[] = {&m->xin, &m->xP, &m->xT, &m->epsbuf, &m->zP[0], &m->zP[1], &m->zT[0], &m->zT[1], &m->rows[0], &m->rows[1],
+    DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->dzsum,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
     for (BlockWs* w : bw) {
-        DevBuf* bb[] = {&w->h1P, &w->h1T, &w->h2P, &w->h2T, &w->head, &w->dheadP, &w->dheadT, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dx};
+        DevBuf* bb[] = {&w->h1P, &w->h2P, &w->head, &w->dheadP, &w->d2P, &w->d1P, &w->dx};
         for (DevBuf* b : bb) free_buf(*b);
     }
     {
         MlpWs* w = &m->wdec1;
-        DevBuf* bb[] = {&w->g1P, &w->g1T, &w->g2P, &w->g2T, &w->dlT, &w->dlP, &w->d2P, &w->d2T, &w->d1P, &w->d1T, &w->dz};
+        DevBuf* bb[] = {&w->g1P, &w->g2P, &w->dlP, &w->d2P, &w->d1P, &w->dz};
         for (DevBuf* b : bb) free_buf(*b);
     }
     if (m->param) (void)hipFree(m->param);
@@ -1060,25 +1044,25 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     if (two) {
         // src/iwae2.py:184-196: pz1z2 = decode_z2_to_z1(z2); z1 = pz1z2.sample(); logits = decode_z1_to_x(z1)
         CHK(ensure(m->zP[1], (size_t)np * Dinp * 2, st));
-        launch_prep_rows(ptr<float>(m->xin), n, Din, Dinp, np, ptr<uint16_t>(m->zP[1]), nullptr, st);
+        launch_prep_rows(ptr<float>(m->xin), n, Din, Dinp, np, ptr<uint16_t>(m->zP[1]), st);
         CHK(block_alloc(m, m->dec2, m->wdec2, n, np, false, false));
-        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), n, np));
+        CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), n));
         for (int i = 0; i < 2; ++i) CHK(ensure(m->rows[i], (size_t)np * 4, st));
         SampleArgs s;
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wdec2.head); s.ldH = 2 * Dp0; s.Dp = Dp0; s.D = D0; s.head_per_row = 1;
         s.M = n; s.Mp = np; s.k = 1; s.B = n;
         s.eps.user = nullptr; s.eps.B = n; s.eps.seed = m->cfg.seed; s.eps.row_offset = 0; s.eps.step = m->noise_step; s.eps.stream = 2;
-        s.ZP = ptr<uint16_t>(m->zP[0]); s.ZT = nullptr; s.ldT = np;
+        s.ZP = ptr<uint16_t>(m->zP[0]);
         s.lp_prior = ptr<float>(m->rows[0]); s.lq = ptr<float>(m->rows[1]); s.lq_dreg = nullptr;
         launch_sample(s, st);
         m->noise_step += 1;
     } else {
-        launch_prep_rows(ptr<float>(m->xin), n, D0, Dp0, np, ptr<uint16_t>(m->zP[0]), nullptr, st);
+        launch_prep_rows(ptr<float>(m->xin), n, D0, Dp0, np, ptr<uint16_t>(m->zP[0]), st);
     }
-    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, np, ptr<uint16_t>(w.g1P), nullptr, nullptr, 0));
-    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, np, ptr<uint16_t>(w.g2P), nullptr, nullptr, 0));
-    CHK(dense_fwd(m, m->dec1[2], EPI_SIGMOID, ptr<uint16_t>(w.g2P), n, np, nullptr, nullptr, ptr<float>(m->scratch), Xp));
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, ptr<uint16_t>(w.g1P), nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, ptr<uint16_t>(w.g2P), nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[2], EPI_SIGMOID, ptr<uint16_t>(w.g2P), n, nullptr, ptr<float>(m->scratch), Xp));
     HIPCHK(hipMemcpy2DAsync(probs, (size_t)m->X * 4, m->scratch.p, (size_t)Xp * 4, (size_t)m->X * 4, n, hipMemcpyDefault, st));
     HIPCHK(hipStreamSynchronize(st));
     m->have_forward = false;
@@ -1120,7 +1104,7 @@ int iwae_dataset_get_batch(iwae_handle m, int32_t start, int32_t B, float* x_out
     CHK(ensure(m->xP, (size_t)Bp * m->Xp32 * 2, m->stream));
     CHK(ensure(m->scratch, (size_t)B * m->X * 4, m->stream));
     launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), start, m->ds_N, B, m->X, m->Xp32, Bp, m->cfg.seed, m->ds_epoch,
-                           ptr<uint16_t>(m->xP), nullptr, ptr<float>(m->scratch), m->stream);
+                           ptr<uint16_t>(m->xP), ptr<float>(m->scratch), m->stream);
     HIPCHK(hipMemcpyAsync(x_out, m->scratch.p, (size_t)B * m->X * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     m->have_forward = false;
@@ -1180,36 +1164,36 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
     if (!m || !name) return fail(IWAE_ERR_ARG, "debug_tensor: null argument");
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "debug_tensor: no forward pass yet");
     HIPCHK(hipSetDevice(m->cfg.device));
-    struct Ent { const char* nm; int kind; const DevBuf* buf; int R; int F; int Fp; int ld; };   // kind 0 P, 1 T, 2 fp32
-    const int B = m->B, M = m->M, Mp = m->Mp, Bp = m->Bp;
+    struct Ent { const char* nm; int kind; const DevBuf* buf; int R; int F; int Fp; };   // kind 0: bf16 P-layout, 2: fp32
+    const int B = m->B, M = m->M, Mp = m->Mp;
     const int H0 = m->H[0], Hp0 = m->Hp[0], D0 = m->D[0], Dp0 = m->Dp[0];
     std::vector<Ent> ents = {
-        {"x", 0, &m->xP, B, m->X, m->Xp32, 0}, {"xT", 1, &m->xT, B, m->X, m->Xp32, Bp},
-        {"enc.h1", 0, &m->wenc1.h1P, B, H0, Hp0, 0}, {"enc.h1T", 1, &m->wenc1.h1T, B, H0, Hp0, Bp},
-        {"enc.h2", 0, &m->wenc1.h2P, B, H0, Hp0, 0}, {"enc.h2T", 1, &m->wenc1.h2T, B, H0, Hp0, Bp},
-        {"enc.head", 2, &m->wenc1.head, B, 2 * Dp0, 2 * Dp0, 0},
-        {"enc.dhead", 0, &m->wenc1.dheadP, B, 2 * Dp0, 2 * Dp0, 0}, {"enc.dheadT", 1, &m->wenc1.dheadT, B, 2 * Dp0, 2 * Dp0, Bp},
-        {"enc.d2", 0, &m->wenc1.d2P, B, H0, Hp0, 0}, {"enc.d1", 0, &m->wenc1.d1P, B, H0, Hp0, 0},
-        {"z", 0, &m->zP[0], M, D0, Dp0, 0}, {"zT", 1, &m->zT[0], M, D0, Dp0, Mp},
-        {"dec.g1", 0, &m->wdec1.g1P, M, H0, Hp0, 0}, {"dec.g1T", 1, &m->wdec1.g1T, M, H0, Hp0, Mp},
-        {"dec.g2", 0, &m->wdec1.g2P, M, H0, Hp0, 0}, {"dec.g2T", 1, &m->wdec1.g2T, M, H0, Hp0, Mp},
-        {"dec.dlT", 1, &m->wdec1.dlT, M, m->X, m->Xp32, Mp},
-        {"dec.d2", 0, &m->wdec1.d2P, M, H0, Hp0, 0}, {"dec.d2T", 1, &m->wdec1.d2T, M, H0, Hp0, Mp},
-        {"dec.d1", 0, &m->wdec1.d1P, M, H0, Hp0, 0}, {"dec.d1T", 1, &m->wdec1.d1T, M, H0, Hp0, Mp},
-        {"dec.dz", 2, &m->wdec1.dz, M, Dp0, Dp0, 0},
-        {"gx", 2, &m->gx, M, 1, 1, 0}, {"wn", 2, &m->wn, M, 1, 1, 0}, {"log_w", 2, &m->logw, M, 1, 1, 0},
+        {"x", 0, &m->xP, B, m->X, m->Xp32},
+        {"enc.h1", 0, &m->wenc1.h1P, B, H0, Hp0},
+        {"enc.h2", 0, &m->wenc1.h2P, B, H0, Hp0},
+        {"enc.head", 2, &m->wenc1.head, B, 2 * Dp0, 2 * Dp0},
+        {"enc.dhead", 0, &m->wenc1.dheadP, B, 2 * Dp0, 2 * Dp0},
+        {"enc.d2", 0, &m->wenc1.d2P, B, H0, Hp0}, {"enc.d1", 0, &m->wenc1.d1P, B, H0, Hp0},
+        {"z", 0, &m->zP[0], M, D0, Dp0},
+        {"dec.g1", 0, &m->wdec1.g1P, M, H0, Hp0},
+        {"dec.g2", 0, &m->wdec1.g2P, M, H0, Hp0},
+        {"dec.dl", 0, &m->wdec1.dlP, M, m->X, m->Xp32},
+        {"dec.d2", 0, &m->wdec1.d2P, M, H0, Hp0},
+        {"dec.d1", 0, &m->wdec1.d1P, M, H0, Hp0},
+        {"dec.dz", 2, &m->wdec1.dz, M, Dp0, Dp0},
+        {"gx", 2, &m->gx, M, 1, 1}, {"wn", 2, &m->wn, M, 1, 1}, {"log_w", 2, &m->logw, M, 1, 1},
     };
     if (m->cfg.n_layers == 2) {
         const int H1 = m->H[1], Hp1 = m->Hp[1], D1 = m->D[1], Dp1 = m->Dp[1];
         std::vector<Ent> e2 = {
-            {"enc2.h1", 0, &m->wenc2.h1P, M, H1, Hp1, 0}, {"enc2.h2", 0, &m->wenc2.h2P, M, H1, Hp1, 0},
-            {"enc2.head", 2, &m->wenc2.head, M, 2 * Dp1, 2 * Dp1, 0}, {"enc2.dhead", 0, &m->wenc2.dheadP, M, 2 * Dp1, 2 * Dp1, 0},
-            {"enc2.dx", 2, &m->wenc2.dx, M, Dp0, Dp0, 0},
-            {"z2", 0, &m->zP[1], M, D1, Dp1, 0},
-            {"dec2.h1", 0, &m->wdec2.h1P, M, H1, Hp1, 0}, {"dec2.h2", 0, &m->wdec2.h2P, M, H1, Hp1, 0},
-            {"dec2.head", 2, &m->wdec2.head, M, 2 * Dp0, 2 * Dp0, 0}, {"dec2.dhead", 0, &m->wdec2.dheadP, M, 2 * Dp0, 2 * Dp0, 0},
-            {"dec2.dx", 2, &m->wdec2.dx, M, Dp1, Dp1, 0},
-            {"dz1", 2, &m->dzsum, M, Dp0, Dp0, 0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0, 0},
+            {"enc2.h1", 0, &m->wenc2.h1P, M, H1, Hp1}, {"enc2.h2", 0, &m->wenc2.h2P, M, H1, Hp1},
+            {"enc2.head", 2, &m->wenc2.head, M, 2 * Dp1, 2 * Dp1}, {"enc2.dhead", 0, &m->wenc2.dheadP, M, 2 * Dp1, 2 * Dp1},
+            {"enc2.dx", 2, &m->wenc2.dx, M, Dp0, Dp0},
+            {"z2", 0, &m->zP[1], M, D1, Dp1},
+            {"dec2.h1", 0, &m->wdec2.h1P, M, H1, Hp1}, {"dec2.h2", 0, &m->wdec2.h2P, M, H1, Hp1},
+            {"dec2.head", 2, &m->wdec2.head, M, 2 * Dp0, 2 * Dp0}, {"dec2.dhead", 0, &m->wdec2.dheadP, M, 2 * Dp0, 2 * Dp0},
+            {"dec2.dx", 2, &m->wdec2.dx, M, Dp1, Dp1},
+            {"dz1", 2, &m->dzsum, M, Dp0, Dp0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0},
         };
         ents.insert(ents.end(), e2.begin(), e2.end());
     }
@@ -1237,8 +1221,7 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
             HIPCHK(hipMemcpyAsync(out, e.buf->p, n * 4, hipMemcpyDefault, m->stream));
         } else {
             CHK(ensure(m->scratch, n * 4, m->stream));
-            if (e.kind == 0) launch_unpack_p(ptr<uint16_t>(*e.buf), e.R, e.F, e.Fp, ptr<float>(m->scratch), m->stream);
-            else launch_unpack_t(ptr<uint16_t>(*e.buf), e.R, e.F, e.ld, ptr<float>(m->scratch), m->stream);
+            launch_unpack_p(ptr<uint16_t>(*e.buf), e.R, e.F, e.Fp, ptr<float>(m->scratch), m->stream);
             HIPCHK(hipMemcpyAsync(out, m->scratch.p, n * 4, hipMemcpyDefault, m->stream));
         }
         HIPCHK(hipStreamSynchronize(m->stream));

@@ -39,17 +39,14 @@ def run(B, k, obj, n_hidden=200, n_latent=100, beta=1.0, seed=0):
     r = m.forward_backward(x, k, beta, obj, eps=eps, want=want)
     enc, dec = tape["enc"], tape["dec"]
     err("enc.h1", m.debug_tensor("enc.h1"), enc.l1.y)
-    err("enc.h1T", m.debug_tensor("enc.h1T"), enc.l1.y)
     err("enc.h2", m.debug_tensor("enc.h2"), enc.l2.y)
     head = m.debug_tensor("enc.head")
     Dp = head.shape[1] // 2
     err("mu", head[:, :n_latent], tape["mu"])
     err("sigma", head[:, Dp:Dp + n_latent], tape["sigma"])
     err("z(bf16)", m.debug_tensor("z"), rows(O.bf16_round(tape["z"])))
-    err("zT", m.debug_tensor("zT"), rows(O.bf16_round(tape["z"])))
     err("z export", r["z"], tape["z"])
     err("dec.g1", m.debug_tensor("dec.g1"), rows(dec.d1.y))
-    err("dec.g1T", m.debug_tensor("dec.g1T"), rows(dec.d1.y))
     err("dec.g2", m.debug_tensor("dec.g2"), rows(dec.d2.y))
     err("logits", r["logits"], tape["logits"])
     for nm in ("lpxz", "lpz", "lqzx"):
@@ -62,9 +59,8 @@ def run(B, k, obj, n_hidden=200, n_latent=100, beta=1.0, seed=0):
     if obj == "dreg":
         print("inference_loss got %.6f emu %.6f exact %.6f" % (r["inference_loss"], res_o["inference_loss"], res_x["inference_loss"]))
     err("gx", m.debug_tensor("gx"), rows(tape["G"]))
-    err("dec.dlT", m.debug_tensor("dec.dlT"), rows(dec.out.dpre))
+    err("dec.dl", m.debug_tensor("dec.dl"), rows(dec.out.dpre))
     err("dec.d2", m.debug_tensor("dec.d2"), rows(dec.d2.dpre))
-    err("dec.d2T", m.debug_tensor("dec.d2T"), rows(dec.d2.dpre))
     err("dec.d1", m.debug_tensor("dec.d1"), rows(dec.d1.dpre))
     dz = m.debug_tensor("dec.dz")
     err("dec.dz", dz[:, :n_latent], rows(tape["dz_dec"]))
