@@ -864,15 +864,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
     typedef __attribute__((ext_vector_type(4))) short v4s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
-    const int it0 = blockIdx.y * 16;
+    // XCD-aware block order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  Renumber
+    // so that blocks which share operands -- the j-blocks / i-blocks of one row split -- sit on ONE XCD and are
+    // dispatched back to back: the shared X tile then comes from HBM once instead of once per j-block.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
+        if ((nb & 7) == 0) {
+            const int L = bx + gx * (by + gy * bz);
+            const int V = (L & 7) * (nb >> 3) + (L >> 3);
+            bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
+        }
+    }
+    const int it0 = by * 16;
     const int nit = min(16, a.IT - it0);
-    const int jt = blockIdx.x * NW + wave;
+    const int jt = bx * NW + wave;
     const bool jvalid = jt < a.JT;
-    const int split = blockIdx.z;
+    const int split = bz;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.M, rbeg + a.rows_per_split);
     const int nchunk = (rend - rbeg + 63) / 64;
-    const int xcol0 = it0 * 16, gcol0 = blockIdx.x * NW * 16;       // first feature (= P position, both multiples of 32) of the tiles
+    const int xcol0 = it0 * 16, gcol0 = bx * NW * 16;       // first feature (= P position, both multiples of 32) of the tiles
 
     // one DMA piece = 1 KiB of LDS = 2 X rows (32 slots each) or 1024/GROW G rows
     auto dma_piece = [&](int c, int buf, int idx) {
@@ -954,7 +966,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
                     slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + l16] = acc[it][ii];
             }
         }
-        if (blockIdx.y == 0) {
+        if (by == 0) {
             float v = bsum;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
@@ -1124,6 +1136,8 @@ __global__ void lse_kernel(LseArgs a) {
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= a.B) return;
     const int k = a.k;
+    const bool single = k <= 64;          // one sample per lane: log_w stays in a register between the passes
+    float lw_reg = 0.0f;
     float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
     for (int s = lane; s < k; s += 64) {
         const int r = b * k + s;
@@ -1132,6 +1146,7 @@ __global__ void lse_kernel(LseArgs a) {
         for (int t = 0; t < 5; ++t)
             if (a.term[t]) lw += a.coef[t] * a.term[t][r];
         a.logw[r] = lw;
+        lw_reg = lw;
         m = fmaxf(m, lw);
         sum_lw += lw;
         sum_px += a.term[0][r];
@@ -1147,7 +1162,7 @@ __global__ void lse_kernel(LseArgs a) {
         sum_t2 += __shfl_xor(sum_t2, o);
     }
     float se = 0.0f;
-    for (int s = lane; s < k; s += 64) se += __expf(a.logw[b * k + s] - m);
+    for (int s = lane; s < k; s += 64) se += __expf((single ? lw_reg : a.logw[b * k + s]) - m);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
     const float inv_se = 1.0f / se;
@@ -1155,7 +1170,7 @@ __global__ void lse_kernel(LseArgs a) {
     float eq14 = 0.0f, dreg = 0.0f;
     for (int s = lane; s < k; s += 64) {
         const int r = b * k + s;
-        const float lw = a.logw[r];
+        const float lw = single ? lw_reg : a.logw[r];
         const float wn = __expf(lw - m) * inv_se;       // iwae1.py:128-131 == softmax over k (:137)
         eq14 += wn * lw;
         a.wn[r] = wn;
@@ -1203,13 +1218,16 @@ __global__ void lse_kernel(LseArgs a) {
     }
 }
 
-// single block: means over the batch -> scalars[16]
-__global__ void scalars_kernel(const float* per_b, int B, float beta, float* out) {
+// Batch means of the per-image values (the scalar entries of the reference's result dict), one 256-thread block.
+// A cross-XCD "last wave reduces" inside lse_kernel would need agent-scope release/acquire fences, i.e. an L2
+// write-back per wave (measured: 7 -> 71 us); a kernel boundary does that once, so the means are taken either by
+// this tiny kernel (forward-only calls) or by an extra block of the step's last kernel (reduce_grads_kernel).
+__device__ __forceinline__ void batch_means_block(const float* per_b, int B, float beta, float* out) {
     __shared__ float red[PB_COUNT][4];
     float acc[PB_COUNT];
 #pragma unroll
     for (int t = 0; t < PB_COUNT; ++t) acc[t] = 0.0f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x)
+    for (int b = threadIdx.x; b < B; b += 256)
 #pragma unroll
         for (int t = 0; t < PB_COUNT; ++t) acc[t] += per_b[t * B + b];
 #pragma unroll
@@ -1234,6 +1252,9 @@ __global__ void scalars_kernel(const float* per_b, int B, float beta, float* out
         out[SC_KL] = s[PB_KL];
     }
 }
+__global__ __launch_bounds__(256) void scalars_kernel(const float* per_b, int B, float beta, float* out) { batch_means_block(per_b, B, beta, out); }
+
+// single block: means over the batch -> scalars[16]
 
 // one block per image b: reduce the sample axis.  Thread (f4, sg) handles 4 latent
 // features and the samples s = sg, sg+SG, ...; partial sums meet in LDS.
@@ -1378,7 +1399,44 @@ __global__ void add3_kernel(float* out, const float* a0, const float* a1, const 
 // ---------------------------------------------------------------------------------
 // gradient slab reduce and Adam (+ bf16 A-image refresh)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad) {
+struct AdamCoef { float alpha, gscale, beta1, beta2, eps; int on; };
+
+// Keras Adam (epsilon outside the square root, main.py:93) on one element + refresh of the bf16 weight images /
+// the fp32 bias block the GEMM kernels read.  is_bias: element j of the bias, else weight (in-feature i, out-feature j).
+__device__ __forceinline__ void adam_element(const LayerDesc& L, bool is_bias, int i, int j, size_t idx, float g, bool update,
+                                             float* param, float* mom, float* vel, const AdamCoef& c) {
+    float w = param[idx];
+    if (update) {
+        g *= c.gscale;
+        const float m = c.beta1 * mom[idx] + (1.0f - c.beta1) * g;
+        const float v = c.beta2 * vel[idx] + (1.0f - c.beta2) * g * g;
+        mom[idx] = m;
+        vel[idx] = v;
+        w -= c.alpha * m / (sqrtf(v) + c.eps);
+        param[idx] = w;
+    }
+    if (is_bias) {
+        *(float*)(L.imgF + img_mg_bias_byte(L.joff + j, L.KT_F)) = w;
+    } else {
+        const uint16_t h = (uint16_t)(pack2(w, 0.0f) & 0xffffu);
+        *(uint16_t*)(L.imgF + img_mg_byte(L.joff + j, i, L.KT_F)) = h;
+        if (L.imgB) {
+            if (L.imgB_kmajor) *(uint16_t*)(L.imgB + img_k_byte(i, L.joff + j, L.MT_B)) = h;
+            else *(uint16_t*)(L.imgB + img_mg_byte(i, L.joff + j, L.KT_B)) = h;
+        }
+    }
+}
+
+// Sums the per-split fp32 slabs of every layer into the flat gradient; with c.on the Adam update of the same
+// elements follows in the same thread (single-GPU train step: no all-reduce sits between the two).
+struct MeansArgs { const float* per_b; int B; float beta; float* out; };     // per_b == null: no extra block
+
+__global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad, float* param, float* mom,
+                                                           float* vel, AdamCoef c, MeansArgs mn) {
+    if (mn.per_b && blockIdx.x == gridDim.x - 1) {      // the one extra block of the grid: batch means of this step
+        batch_means_block(mn.per_b, mn.B, mn.beta, mn.out);
+        return;
+    }
     // block = 64 groups of 4 consecutive out-features (float4 loads) x 4 split groups; partial sums meet in LDS.
     // A group never straddles a weight row: rblock counts are computed per row of 4-float groups (Nout4 = ceil(Nout/4)).
     __shared__ float4 red[4][64];
@@ -1413,45 +1471,28 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* laye
                       red[0][t].z + red[1][t].z + red[2][t].z + red[3][t].z, red[0][t].w + red[1][t].w + red[2][t].w + red[3][t].w};
         float* dst = (i == L.Kin) ? (grad + L.offb + j) : (grad + L.offW + (size_t)i * L.Nout + j);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (j + c < L.Nout) dst[c] = r[c];
+        for (int e = 0; e < 4; ++e) {
+            if (j + e < L.Nout) {
+                dst[e] = r[e];
+                if (c.on) adam_element(L, i == L.Kin, i, j + e, (size_t)(dst - grad) + e, r[e], true, param, mom, vel, c);
+            }
+        }
     }
 }
 
 // Keras Adam (main.py:93): theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps), eps = 1e-4;
 // then refresh the bf16 A-images the GEMM kernels stream (forward W^T and backward W).
-__global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, const float* grad, float* mom, float* vel,
-                            float alpha, float gscale, float beta1, float beta2, float eps, int do_update) {
+__global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, const float* grad, float* mom, float* vel, AdamCoef c) {
     int l = 0;
     while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].block_begin) ++l;
     const LayerDesc L = layers[l];
     const int e = ((int)blockIdx.x - L.block_begin) * blockDim.x + threadIdx.x;
     const int nW = L.Kin * L.Nout;
     if (e >= nW + L.Nout) return;
-    const size_t idx = (e < nW) ? (L.offW + e) : (L.offb + (e - nW));
-    float w = param[idx];
-    if (do_update) {
-        const float g = grad[idx] * gscale;
-        const float m = beta1 * mom[idx] + (1.0f - beta1) * g;
-        const float v = beta2 * vel[idx] + (1.0f - beta2) * g * g;
-        mom[idx] = m;
-        vel[idx] = v;
-        w -= alpha * m / (sqrtf(v) + eps);
-        param[idx] = w;
-    }
-    if (e >= nW) {
-        *(float*)(L.imgF + img_mg_bias_byte(L.joff + (e - nW), L.KT_F)) = w;
-    } else {
-        const int i = e / L.Nout, j = e % L.Nout;
-        const uint16_t h = (uint16_t)(pack2(w, 0.0f) & 0xffffu);
-        *(uint16_t*)(L.imgF + img_mg_byte(L.joff + j, i, L.KT_F)) = h;
-        if (L.imgB) {
-            if (L.imgB_kmajor) *(uint16_t*)(L.imgB + img_k_byte(i, L.joff + j, L.MT_B)) = h;
-            else *(uint16_t*)(L.imgB + img_mg_byte(i, L.joff + j, L.KT_B)) = h;
-        }
-    }
+    const bool is_b = e >= nW;
+    const size_t idx = is_b ? (L.offb + (e - nW)) : (L.offW + e);
+    adam_element(L, is_b, is_b ? 0 : e / L.Nout, is_b ? e - nW : e % L.Nout, idx, c.on ? grad[idx] : 0.0f, c.on != 0, param, mom, vel, c);
 }
-
 // ---------------------------------------------------------------------------------
 // exports in the reference's [k, B, ...] order (iwae1.py:141-151), debug dumps
 // ---------------------------------------------------------------------------------
@@ -1574,9 +1615,6 @@ void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
-void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
-}
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(a.Bp), dim3(256), 0, st, a);
 }
@@ -1586,12 +1624,19 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
 void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(add3_kernel, grid1(n, 256), dim3(256), 0, st, out, a0, a1, a2, n);
 }
-void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, grad);
+void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, float* param, float* mom, float* vel,
+                         float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
+    const AdamCoef c = {alpha, 1.0f, 0.9f, 0.999f, eps, fuse_adam};
+    const MeansArgs mn = {per_b, B, beta, scalars};
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn);
+}
+void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
 }
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
                  float alpha, float gscale, float eps, int do_update, hipStream_t st) {
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, alpha, gscale, 0.9f, 0.999f, eps, do_update);
+    const AdamCoef c = {alpha, gscale, 0.9f, 0.999f, eps, do_update};
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, c);
 }
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st) {
     hipLaunchKernelGGL(export_rows_kernel, grid1((size_t)B * k, 256), dim3(256), 0, st, in, B, k, out);

@@ -98,6 +98,7 @@ struct iwae_model {
     // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
     DevBuf ds_data, ds_order;
     int ds_N = 0;
+    int wg_target16_1 = 128;   // same, for layers that are a single 16-wave block wide (IWAE_WG16_1)
     int wg_target16 = 256;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid)
     // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling and
     // backward kernels.  A training step draws the NEXT step's noise on the side stream behind its weight gradients
@@ -363,7 +364,7 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
     const int blocks = ((L.JT + nw - 1) / nw) * ((L.IT + 15) / 16);
     // one workgroup per CU is the measured optimum (k=50,B=1024: 64 -> 0.501, 128 -> 0.425, 256 -> 0.406, 384 -> 0.443,
     // 512 -> 0.455 ms/step): fewer leaves CUs idle, more pays a full fp32 slab (write + read back) per extra split
-    const int target = (nw == 16) ? m->wg_target16 : 256;
+    const int target = (nw == 16) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : 256;
     int nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
@@ -402,6 +403,12 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
     CHK(wgradp(m, blk[0], inP, ptr<uint16_t>(w.d1P), R));
     if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
     return IWAE_OK;
+}
+
+bool is_device_ptr(const void* p, int device) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain host memory
+    return at.type == hipMemoryTypeDevice && at.device == device;
 }
 
 int copy_in(iwae_model* m, DevBuf& dst, const void* src, size_t bytes) {
@@ -463,8 +470,12 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                                m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
         m->ds_start = -1;
     } else {
-        CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
-        launch_prep_rows(ptr<float>(m->xin), B, X, Xp, Bp, ptr<uint16_t>(m->xP), st);
+        const float* xd = x;
+        if (!is_device_ptr(x, m->cfg.device)) {       // host batches are staged; device batches are read in place
+            CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
+            xd = ptr<float>(m->xin);
+        }
+        launch_prep_rows(xd, B, X, Xp, Bp, ptr<uint16_t>(m->xP), st);
     }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
@@ -571,7 +582,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
         launch_lse(a, st);
-        launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
+        // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
+        if (!bwd) launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
     }
     HIPCHK(hipGetLastError());
     m->have_forward = true;
@@ -579,7 +591,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
 }
 
 // ---------------------------------------------------------------- the backward pass
-int backward_impl(iwae_model* m, int objective) {
+float adam_alpha(iwae_model* m, float lr) {      // keras Adam: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); advances t
+    m->adam_t += 1;
+    const double t = (double)m->adam_t;
+    return (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+}
+
+// fused_lr >= 0: the optimizer update runs inside the slab reduction (single-GPU train step); < 0: gradient only
+int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "backward without forward");
     const bool two = m->cfg.n_layers == 2;
     const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
@@ -661,7 +680,9 @@ int backward_impl(iwae_model* m, int objective) {
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false));
     HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
     if (m->descs_dirty) CHK(build_descs(m));
-    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, st);
+    const bool fuse = fused_lr >= 0.0f;
+    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+                        fuse ? adam_alpha(m, fused_lr) : 0.0f, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -738,9 +759,7 @@ int check_objective(iwae_model* m, int objective) {
 
 int adam_impl(iwae_model* m, float lr, float gscale) {
     if (m->descs_dirty) CHK(build_descs(m));
-    m->adam_t += 1;
-    const double t = (double)m->adam_t;
-    const float alpha = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    const float alpha = adam_alpha(m, lr);
     launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gscale, 1e-4f, 1, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -770,6 +789,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->cfg = *cfg;
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
+    if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 
     m->X = cfg->x_dim;
     m->Xp32 = round_up(cfg->x_dim, 32);
@@ -988,9 +1008,13 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(check_objective(m, objective));
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
-    CHK(backward_impl(m, objective));
-    CHK(fetch_outputs(m, nullptr, want));   // tensors refer to the pre-update forward (src/iwae1.py:162)
-    CHK(adam_impl(m, lr, 1.0f));
+    if (want) {
+        CHK(backward_impl(m, objective));
+        CHK(fetch_outputs(m, nullptr, want));   // tensors refer to the pre-update forward (src/iwae1.py:162)
+        CHK(adam_impl(m, lr, 1.0f));
+    } else {
+        CHK(backward_impl(m, objective, lr));   // Adam fused into the gradient reduction
+    }
     CHK(fetch_outputs(m, scalars, nullptr));
     m->noise_step += 1;
     return IWAE_OK;

@@ -48,7 +48,11 @@ class DataParallelStep:
     def step(self, x_devptr, b_local, k, beta, lr, objective_id, global_batch_offset=0):
         """x_devptr: this rank's shard, already resident in HBM ([b_local, x_dim] float32)."""
         self.net.set_step(self.step_idx, global_batch_offset + self.rank * b_local)
-        self.net.forward_backward_devptr(x_devptr, b_local, k, beta, objective_id)
-        allreduce_sum_(self.grad, self.group)
-        self.net.adam_step(lr, 1.0 / self.world)
+        if self.world == 1 and not os.environ.get("IWAE_BENCH_FORCE_DIST"):
+            # nothing to exchange: the library's own train step (Adam fused into the gradient reduction)
+            self.net.train_step_devptr(x_devptr, b_local, k, beta, lr, objective_id)
+        else:
+            self.net.forward_backward_devptr(x_devptr, b_local, k, beta, objective_id)
+            allreduce_sum_(self.grad, self.group)
+            self.net.adam_step(lr, 1.0 / self.world)
         self.step_idx += 1
