@@ -59,6 +59,13 @@ struct WgradPArgs {
     const char* zero;                       // >= 512 B of zeros (source of rows >= M and of unused slots)
 };
 
+struct WgradPGroup {                        // up to 3 independent 8-wave weight gradients in one launch
+    WgradPArgs a[3];
+    int n;
+    int gx[3], gy[3];                       // j-blocks / i-blocks of each
+    int zbeg[4];                            // first blockIdx.z of each (zbeg[n] = total)
+};
+
 struct SampleArgs {
     const float* head; int ldH; int Dp; int D; int head_per_row;
     int M, Mp, k, B;
@@ -118,6 +125,7 @@ struct LayerDesc {
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
+void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);

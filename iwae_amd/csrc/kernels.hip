@@ -854,7 +854,7 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 // grid = (j-blocks of NW*16 features, i-blocks of 256 features, row splits); fp32 slabs as before.
 // ---------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
+__device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int XT_BYTES = 64 * 512;                 // X tile: 64 rows x 512 B (256 features)
     constexpr int GROW = NW * 32;                      // G strip row bytes (512 for 16 waves, 256 for 8)
@@ -864,18 +864,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
     typedef __attribute__((ext_vector_type(4))) short v4s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
-    // XCD-aware block order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  Renumber
-    // so that blocks which share operands -- the j-blocks / i-blocks of one row split -- sit on ONE XCD and are
-    // dispatched back to back: the shared X tile then comes from HBM once instead of once per j-block.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {
-        const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
-        if ((nb & 7) == 0) {
-            const int L = bx + gx * (by + gy * bz);
-            const int V = (L & 7) * (nb >> 3) + (L >> 3);
-            bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
-        }
-    }
     const int it0 = by * 16;
     const int nit = min(16, a.IT - it0);
     const int jt = bx * NW + wave;
@@ -973,6 +961,30 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
             if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + l16] = v;
         }
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
+    // XCD-aware block order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  Renumber
+    // so that blocks which share operands -- the j-blocks / i-blocks of one row split -- sit on ONE XCD and are
+    // dispatched back to back: the shared X tile then comes from HBM once instead of once per j-block.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int gx = gridDim.x, gy = gridDim.y, nb = gx * gy * (int)gridDim.z;
+    if ((nb & 7) == 0) {
+        const int L = bx + gx * (by + gy * bz);
+        const int V = (L & 7) * (nb >> 3) + (L >> 3);
+        bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
+    }
+    wgradp_body<NW>(a, bx, by, bz);
+}
+
+// Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
+// each and latency-bound): blockIdx.z runs over the concatenated row splits of the layers.
+__global__ __launch_bounds__(512, 2) void wgradp_group_kernel(WgradPGroup g) {
+    int l = 0;
+    while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
+    if ((int)blockIdx.x >= g.gx[l] || (int)blockIdx.y >= g.gy[l]) return;
+    wgradp_body<8>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1592,6 +1604,11 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((out_bwd_kernel<0, false>), dim3((a.M + 127) / 128), dim3(256), lds, st, a);
         }
     }
+}
+void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
+    int mx = 0, my = 0;
+    for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
+    hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), 2 * (64 * 512 + 64 * 256), st, g);
 }
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
     dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);

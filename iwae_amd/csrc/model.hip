@@ -356,16 +356,17 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R)
 }
 
 // ---------------------------------------------------------------- backward pieces
-// weight gradient from the P-layout operands (wgradp_kernel); XP/GP row-major bf16, `rows` valid rows
-int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr) {
-    if (!st) st = m->stream;
+// weight gradient from the P-layout operands (wgradp_kernel); XP/GP row-major bf16, `rows` valid rows.
+// wgradp_plan sizes the row splits and the slabs and fills the argument block; nw = waves per block (8 / 16).
+int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, WgradPArgs& a, int& nsplit, int& nw) {
     const int chunks = (rows + 63) / 64;
-    const int nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
+    nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
     const int blocks = ((L.JT + nw - 1) / nw) * ((L.IT + 15) / 16);
-    // one workgroup per CU is the measured optimum (k=50,B=1024: 64 -> 0.501, 128 -> 0.425, 256 -> 0.406, 384 -> 0.443,
-    // 512 -> 0.455 ms/step): fewer leaves CUs idle, more pays a full fp32 slab (write + read back) per extra split
+    // one workgroup per CU is the measured optimum for the wide output layer (k=50,B=1024: 64 -> 0.501, 128 -> 0.425,
+    // 256 -> 0.406, 384 -> 0.443, 512 -> 0.455 ms/step): fewer leaves CUs idle, more pays a full fp32 slab (write +
+    // read back) per extra split; the single-block-wide hidden layers run next to other kernels and prefer 128
     const int target = (nw == 16) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : 256;
-    int nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
+    nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
     const size_t needW = (size_t)nsplit * L.IT * 16 * L.JT * 16 * 4, needB = (size_t)nsplit * L.JT * 16 * 4;
@@ -373,10 +374,16 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
     CHK(ensure(L.slabW, needW, m->stream));
     CHK(ensure(L.slabB, needB, m->stream));
     if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
-    WgradPArgs a;
     a.X = XP; a.ldX = L.Kp32; a.IT = L.IT; a.G = GP; a.ldG = L.Np32; a.JT = L.JT; a.M = rows; a.rows_per_split = cps * 64;
     a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero;
-    launch_wgradp(a, nsplit, nw, st);
+    return IWAE_OK;
+}
+
+int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr) {
+    WgradPArgs a;
+    int nsplit = 1, nw = 8;
+    CHK(wgradp_plan(m, L, XP, GP, rows, a, nsplit, nw));
+    launch_wgradp(a, nsplit, nw, st ? st : m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -395,13 +402,34 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
     return IWAE_OK;
 }
 
+// backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
+// slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
 int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx) {
-    CHK(wgradp(m, blk[2], ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.dheadP), R));
     CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
-    CHK(wgradp(m, blk[1], ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d2P), R));
     CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
-    CHK(wgradp(m, blk[0], inP, ptr<uint16_t>(w.d1P), R));
     if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
+    const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
+    const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
+    Linear* ls[3] = {&blk[2], &blk[1], &blk[0]};
+    WgradPGroup g;
+    memset(&g, 0, sizeof(g));
+    int nsplit[3], nw[3];
+    bool small = true;
+    for (int i = 0; i < 3; ++i) {
+        CHK(wgradp_plan(m, *ls[i], xs[i], gs[i], R, g.a[i], nsplit[i], nw[i]));
+        small = small && nw[i] == 8;
+    }
+    if (small) {
+        g.n = 3;
+        for (int i = 0; i < 3; ++i) {
+            g.gx[i] = (ls[i]->JT + 7) / 8; g.gy[i] = (ls[i]->IT + 15) / 16;
+            g.zbeg[i + 1] = g.zbeg[i] + nsplit[i];
+        }
+        launch_wgradp_group(g, m->stream);
+    } else {
+        for (int i = 0; i < 3; ++i) launch_wgradp(g.a[i], nsplit[i], nw[i], m->stream);
+    }
+    HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
 
