@@ -46,6 +46,7 @@ struct OutBwdArgs {
     const uint16_t* XB; int ldXB; int k;
     int M, KT, NG;
     uint16_t* DLP;                    // dlogits, P-layout [M][Xp32] or null
+    const uint16_t* SP;               // s = x - sigmoid(l) kept by the forward pass, P-layout [M][Xp32]: no recompute (else null)
     uint16_t* DPP;                    // dpre of the last hidden layer, P-layout [M][32*KT]
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
 };
@@ -57,6 +58,7 @@ struct WgradPArgs {
     float* slabW;                           // [nsplit][IT*16][JT*16]
     float* slabB;                           // [nsplit][JT*16]
     const char* zero;                       // >= 512 B of zeros (source of rows >= M and of unused slots)
+    const float* rowscale;                  // optional [M]: G rows are multiplied by it (rounded to bf16) on the way in, else null
 };
 
 struct WgradPGroup {                        // up to 3 independent 8-wave weight gradients in one launch
@@ -124,6 +126,7 @@ struct LayerDesc {
 
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
+bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st);

@@ -157,7 +157,7 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 #define DENSE_UNIT 33792   // 8 k-steps x 4 KiB + 1 KiB bias block
 
 template <int EPI, int KTC>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
-__global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
+__global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
     uint4 stP[2][2];
     int st_mg = -1;
     auto emit_stores = [&]() {
-        if (!kPacked || st_mg < 0) return;
+        if (!(kPacked || EPI == EPI_BERN) || st_mg < 0) return;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int fbase = 64 * st_mg + 32 * p;
@@ -354,25 +354,44 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs a) {
         } else if (EPI == EPI_BERN) {
             // log p(x|z) = sum_j x_j l_j - softplus(l_j), softplus(l) = max(l,0) + ln2*log2(1 + 2^(-|l| log2e))  (iwae1.py:111)
             // wave-uniform branch: only the last pixel group needs masks
-            auto bern_body = [&](auto masked) {
+            // keep: the training step also stores s = x - sigmoid(l) (bf16, P-layout) -- d lpxz / d l up to the row weight,
+            // which out_bwd and the output layer's weight gradient then read instead of recomputing the logits
+            auto bern_body = [&](auto masked, auto keep) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
+                        float sv[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
-                            const float lg = log2_raw(1.0f + exp2_raw(-fabsf(l) * LOG2E_F));
-                            float term = fmaf(bf_at(pre[p][g], j), l, -fmaxf(l, 0.0f));
+                            const float xj = bf_at(pre[p][g], j);
+                            const float e = exp2_raw(-fabsf(l) * LOG2E_F), ope = 1.0f + e;      // e = exp(-|l|)
+                            const float lg = log2_raw(ope);
+                            float term = fmaf(xj, l, -fmaxf(l, 0.0f));
                             term = fmaf(-LN2_F, lg, term);
-                            if (decltype(masked)::value) term = (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim) ? term : 0.0f;
-                            rowacc[g] += term;
+                            const bool in = !decltype(masked)::value || (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim);
+                            rowacc[g] += in ? term : 0.0f;
+                            if (decltype(keep)::value) {
+                                const float r = rcp_fast(ope);                                      // sigmoid(|l|)
+                                const float sg = l >= 0.0f ? r : e * r;
+                                sv[j] = in ? xj - sg : 0.0f;
+                            }
                         }
+                        if (decltype(keep)::value)
+                            stP[p][g] = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
                     }
                 }
             };
-            if (64 * mg + 64 <= a.Xdim) bern_body(std::false_type{});
-            else bern_body(std::true_type{});
+            const bool full = 64 * mg + 64 <= a.Xdim;
+            if (a.YP) {
+                if (full) bern_body(std::false_type{}, std::true_type{});
+                else bern_body(std::true_type{}, std::true_type{});
+                st_mg = mg;
+            } else {
+                if (full) bern_body(std::false_type{}, std::false_type{});
+                else bern_body(std::true_type{}, std::false_type{});
+            }
             if (a.logits_out) {     // rare path (the reference dict's "logits"): reference [k,B,X] order
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
@@ -843,6 +862,113 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 }
 
 // ---------------------------------------------------------------------------------
+// out_bwd_s_kernel: output-layer backward when the forward pass kept s = x - sigmoid(l) (bf16, P-layout):
+//   dg2 = s W^T  (k = pixels; the B operand is s straight from HBM, one 16-byte load per k-step and column group)
+//   dpre2 = gx[row] * dg2 * (1 - g2^2)          (the row weight of the objective is applied in fp32, at the end)
+// No logits recompute, no sigmoid, no fragment exchange: half the LDS bytes and none of the VALU work of
+// out_bwd_pair_kernel.  4 waves x 32 rows; the W^T image streams through LDS one 64-pixel group at a time (same
+// image and transposing reads as the pair kernel's second product), DMA pieces issued between the MFMAs.
+// ---------------------------------------------------------------------------------
+template <int KTC>
+__global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int KT = KTC, MT = 2 * KTC;
+    constexpr int unit = KT * 4096 + 1024;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    int row[2], rowc[2];
+    bool valid[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
+    const int tr_off = (4 * q + (rho >> 2)) * 64 + (((rho & 3) ^ hperm(q)) * 16);
+
+    constexpr int NP = unit / 1024, NIDX = (NP + 3) / 4;
+    auto dma_piece = [&](int ng, int buf, int idx) {
+        const int p = wave + 4 * idx;                 // wave-uniform
+        if (p < NP)
+            glds16(a.img1 + (size_t)ng * unit + (size_t)p * 1024 + lane * 16,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * unit) + (uint32_t)p * 1024u)));
+    };
+    auto load_s = [&](int ng, uint4 (&sf)[2][2]) {   // clamped rows, zeroed by a select: no branch per load
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                sf[kk][g] = make_uint4(0, 0, 0, 0);
+                const int fbase = 64 * ng + 32 * kk;      // wave-uniform guard
+                if (fbase < a.Xp32) {
+                    const uint4 v = *(const uint4*)(a.SP + (size_t)rowc[g] * a.Xp32 + fbase + 8 * q);
+                    sf[kk][g] = valid[g] ? v : make_uint4(0, 0, 0, 0);
+                }
+            }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, 0, idx);
+    uint4 sf[2][2], sf_n[2][2];
+    load_s(0, sf);
+
+    f32x4 acc2[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int ng = 0; ng < a.NG; ++ng) {
+        const int buf = ng & 1;
+        wait_all_vmem();
+        __syncthreads();
+        const bool more = ng + 1 < a.NG;
+        if (more) load_s(ng + 1, sf_n);
+        const char* l2 = smem + buf * unit + tr_off;
+        lds_pipeline<2 * MT, 8>(
+            [&](int i) {       // A fragment (hidden tile mt, pixel k-step kk) = two transposed 4x16 blocks of pixel tiles 2kk, 2kk+1
+                const int kk = i / MT, mt = i % MT;
+                typedef __attribute__((ext_vector_type(4))) short v4s;
+                const char* p0 = l2 + ((mt >> 1) * 4 + 2 * kk) * 1024 + 8 * (mt & 1);
+                const v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+                const v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 1024));
+                const uint2 lo = __builtin_bit_cast(uint2, t0), hi = __builtin_bit_cast(uint2, t1);
+                return make_uint4(lo.x, lo.y, hi.x, hi.y);
+            },
+            [&](int i, const uint4& av) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc2[i % MT][g] = mfma16(av, (i / MT) ? sf[1][g] : sf[0][g], acc2[i % MT][g]);
+            },
+            [&](int i) { if (more && (i & 1) == 0 && (i >> 1) < NIDX) dma_piece(ng + 1, buf ^ 1, i >> 1); });
+        if (more) {
+#pragma unroll
+            for (int idx = MT; idx < NIDX; ++idx) dma_piece(ng + 1, buf ^ 1, idx);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) sf[kk][g] = sf_n[kk][g];
+    }
+
+    // dpre2 = gx * dg2 * (1 - g2^2); the lane's 8 features of hidden k-step ks are tiles 2ks (j < 4) and 2ks+1 (j >= 4)
+    float gxv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) gxv[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const uint4 y8 = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = bf_at(y8, j);
+                v[j] = gxv[g] * acc2[2 * ks + (j >> 2)][g][j & 3] * (1.0f - y * y);
+            }
+            if (valid[g])
+                *(uint4*)(a.DPP + (size_t)row[g] * a.ldG + ks * 32 + 8 * q) =
+                    make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // wgradp_kernel: weight gradient straight from the ROW-major P-layout activations (no feature-major copies):
 //   out[i][j] = sum_r X[r][i] * G[r][j],   X: bf16 [rows][ldX], G: bf16 [rows][ldG]  (both P-layout)
 // The contraction index (data row) is the strided one in memory, so both MFMA operands are produced by the
@@ -853,14 +979,14 @@ __global__ __launch_bounds__(PAIRS * 128, 2) void out_bwd_pair_kernel(OutBwdArgs
 // permutation is undone for free by which 8-byte piece a lane addresses.  Rows >= M read a zero line.
 // grid = (j-blocks of NW*16 features, i-blocks of 256 features, row splits); fp32 slabs as before.
 // ---------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool SC>     // SC: G rows carry a per-row weight (a.rowscale), staged through LDS with the tiles
 __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int XT_BYTES = 64 * 512;                 // X tile: 64 rows x 512 B (256 features)
     constexpr int GROW = NW * 32;                      // G strip row bytes (512 for 16 waves, 256 for 8)
     constexpr int GT_BYTES = 64 * GROW;
-    constexpr int BUF = XT_BYTES + GT_BYTES;
-    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, NPC = XP + GP, NIDX = (NPC + NW - 1) / NW;
+    constexpr int BUF = XT_BYTES + GT_BYTES + (SC ? 1024 : 0);
+    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, NPC = XP + GP + (SC ? 1 : 0), NIDX = (NPC + NW - 1) / NW;
     typedef __attribute__((ext_vector_type(4))) short v4s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
@@ -886,6 +1012,8 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             const int col = xcol0 + cch * 8;
             const bool ok = (r0 + rl) < rend && col < a.ldX;
             src = ok ? (const char*)a.X + ((size_t)(r0 + rl) * a.ldX + col) * 2 : a.zero + (lane & 31) * 16;
+        } else if (SC && pc == XP + GP) {                                // the chunk's 64 row weights (256 B; the pad rows of gx are finite)
+            src = lane < 16 ? (const char*)(a.rowscale + r0) + lane * 16 : a.zero + (lane & 31) * 16;
         } else {
             constexpr int SPR = GROW / 16, RPP = 1024 / GROW;            // slots per row, rows per piece
             const int rl = RPP * (pc - XP) + lane / SPR, s = lane % SPR;
@@ -927,7 +1055,13 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs) * GROW));
             const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs + 16) * GROW));
             const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
-            const uint4 g = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+            uint4 g = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+            if (SC) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row step (output layer: G = s, weight = dLoss/dlpxz)
+                const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 32 * rs + 4 * q;
+                const float4 s0 = *(const float4*)scl, s1 = *(const float4*)(scl + 16);
+                g = make_uint4(pack2(bflo(g.x) * s0.x, bfhi(g.x) * s0.y), pack2(bflo(g.y) * s0.z, bfhi(g.y) * s0.w),
+                               pack2(bflo(g.z) * s1.x, bfhi(g.z) * s1.y), pack2(bflo(g.w) * s1.z, bfhi(g.w) * s1.w));
+            }
             bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
             lds_pipeline<16, 3>(
                 [&](int i) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
@@ -963,7 +1097,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     }
 }
 
-template <int NW>
+template <int NW, bool SC>
 __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
     // XCD-aware block order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  Renumber
     // so that blocks which share operands -- the j-blocks / i-blocks of one row split -- sit on ONE XCD and are
@@ -975,7 +1109,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
         const int V = (L & 7) * (nb >> 3) + (L >> 3);
         bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
     }
-    wgradp_body<NW>(a, bx, by, bz);
+    wgradp_body<NW, SC>(a, bx, by, bz);
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
@@ -984,7 +1118,7 @@ __global__ __launch_bounds__(512, 2) void wgradp_group_kernel(WgradPGroup g) {
     int l = 0;
     while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
     if ((int)blockIdx.x >= g.gx[l] || (int)blockIdx.y >= g.gy[l]) return;
-    wgradp_body<8>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
+    wgradp_body<8, false>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1584,7 +1718,18 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
         default: launch_dense_k<0>(epi, a, grid, lds, st); break;
     }
 }
+bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
+    if (a.SP) {      // the forward pass kept s = x - sigmoid(l): one product, B operand from HBM
+        const size_t lds = 2 * ((size_t)a.KT * 4096 + 1024);
+        dim3 grid((a.M + 127) / 128);
+        switch (a.KT) {
+            case 7: hipLaunchKernelGGL(out_bwd_s_kernel<7>, grid, dim3(256), lds, st, a); return;
+            case 4: hipLaunchKernelGGL(out_bwd_s_kernel<4>, grid, dim3(256), lds, st, a); return;
+            case 2: hipLaunchKernelGGL(out_bwd_s_kernel<2>, grid, dim3(256), lds, st, a); return;
+            default: break;      // the host only asks for this mode when out_bwd_has_s_mode(KT)
+        }
+    }
     // pair kernel: one W^T image per pixel group, double buffered, + 4 KiB of dl exchange per pair.  Two 4-wave
     // workgroups (64 rows each) per CU instead of one 8-wave workgroup: the two are not in lockstep, so one's
     // MFMA phase overlaps the other's sigmoid epilogue / DMA.
@@ -1612,8 +1757,13 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
 }
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
     dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);
-    if (nw == 16) hipLaunchKernelGGL(wgradp_kernel<16>, grid, dim3(1024), 2 * (64 * 512 + 64 * 512), st, a);
-    else hipLaunchKernelGGL(wgradp_kernel<8>, grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
+    if (a.rowscale) {
+        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, true>), grid, dim3(1024), 2 * (64 * 512 + 64 * 512 + 1024), st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, true>), grid, dim3(512), 2 * (64 * 512 + 64 * 256 + 1024), st, a);
+    } else {
+        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, false>), grid, dim3(1024), 2 * (64 * 512 + 64 * 512), st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, false>), grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
+    }
 }
 void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st) {
     const int nchunk = Xp / 8;

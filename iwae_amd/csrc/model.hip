@@ -89,6 +89,8 @@ struct iwae_model {
     int B = 0, k = 0, M = 0, Mp = 0, Bp = 0;
     float beta = 1.0f;
     bool have_forward = false, user_eps = false;
+    bool allow_s_mode = true;   // IWAE_OUT_RECOMPUTE=1 switches back to recomputing the logits in out_bwd (A/B measurements)
+    bool s_mode = false;        // this step's forward kept s = x - sigmoid(l) in wdec1.dlP
     DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
     DevBuf logw, wn, gx, cf, per_b, dzsum, dzdir;
@@ -375,14 +377,16 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     CHK(ensure(L.slabB, needB, m->stream));
     if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
     a.X = XP; a.ldX = L.Kp32; a.IT = L.IT; a.G = GP; a.ldG = L.Np32; a.JT = L.JT; a.M = rows; a.rows_per_split = cps * 64;
-    a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero;
+    a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero; a.rowscale = nullptr;
     return IWAE_OK;
 }
 
-int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr) {
+int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, hipStream_t st = nullptr,
+           const float* rowscale = nullptr) {
     WgradPArgs a;
     int nsplit = 1, nw = 8;
     CHK(wgradp_plan(m, L, XP, GP, rows, a, nsplit, nw));
+    a.rowscale = rowscale;
     launch_wgradp(a, nsplit, nw, st ? st : m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -571,6 +575,12 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
         a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
         a.lpxz = lpxz;
+        // training step: keep s = x - sigmoid(l) for the backward pass (out_bwd_s_kernel, output-layer weight gradient)
+        m->s_mode = bwd && m->allow_s_mode && out_bwd_has_s_mode(L.KT);
+        if (m->s_mode) {
+            CHK(ensure(m->wdec1.dlP, (size_t)Mp * Xp * 2, st));
+            a.YP = ptr<uint16_t>(m->wdec1.dlP); a.ldYP = Xp;
+        }
         a.logits_out = nullptr;
         if (want && want->logits) {
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
@@ -584,7 +594,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // ---- log_w, log-mean-exp over k, objectives (iwae1.py:113-139)
     CHK(ensure(m->logw, (size_t)Mp * 4, st));
     CHK(ensure(m->wn, (size_t)Mp * 4, st));
-    CHK(ensure(m->gx, (size_t)Mp * 4, st));
+    {   // the row weights are also read 64 at a time by the output layer's weight gradient: pad rows must stay finite
+        const void* before = m->gx.p;
+        CHK(ensure(m->gx, (size_t)Mp * 4, st));
+        if (m->gx.p != before) HIPCHK(hipMemsetAsync(m->gx.p, 0, m->gx.cap, st));
+    }
     CHK(ensure(m->cf, (size_t)Mp * 16, st));
     CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
     {
@@ -645,7 +659,9 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         a.Xdim = X; a.Xp32 = Xp;
         a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
         a.M = M; a.KT = L.KT; a.NG = L.MG;
-        a.DLP = ptr<uint16_t>(w.dlP); a.DPP = ptr<uint16_t>(w.d2P);
+        a.DPP = ptr<uint16_t>(w.d2P);
+        if (m->s_mode) a.SP = ptr<uint16_t>(w.dlP);     // dlP holds s: one product, no recompute
+        else a.DLP = ptr<uint16_t>(w.dlP);                // recompute mode: out_bwd writes dl = gx * s there
         if (m->want_stamps && L.KT == 7) {
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
@@ -658,7 +674,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     HIPCHK(hipEventRecord(m->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side)); }
+    { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
     CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr));
     HIPCHK(hipEventRecord(m->ev_fork2, st));
     CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
@@ -816,6 +832,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     iwae_model* m = new iwae_model();
     m->cfg = *cfg;
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
+    if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
+    m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 
