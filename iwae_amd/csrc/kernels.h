@@ -35,6 +35,7 @@ struct DenseArgs {
     // EPI_BERN
     const uint16_t* XB; int ldXB; int k; int B; int Xdim;
     float* lpxz; float* logits_out;
+    unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
 struct OutBwdArgs {

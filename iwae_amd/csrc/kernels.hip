@@ -156,8 +156,27 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 // ---------------------------------------------------------------------------------
 #define DENSE_UNIT 33792   // 8 k-steps x 4 KiB + 1 KiB bias block
 
+// diagnostic build only (./build.sh with STAMPS=1): per-phase s_memtime sums per wave -> a.stamps[wave][8]
+#ifdef IWAE_DENSE_STAMPS
+#define DS_STAMP(slot)                                                                 \
+    {                                                                                  \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        ds_sum[slot] += t_ - ds_prev;                                                  \
+        ds_prev = t_;                                                                  \
+    }
+#else
+#define DS_STAMP(slot)
+#endif
+
 template <int EPI, int KTC>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
 __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(DenseArgs a) {
+#ifdef IWAE_DENSE_STAMPS
+    unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -178,6 +197,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     const size_t gbytes = img_mg_group_bytes(KT);
     constexpr bool kPacked = (EPI == EPI_TANH || EPI == EPI_DX);     // bf16 P/T outputs
     constexpr bool kPre = (EPI == EPI_DX || EPI == EPI_BERN);        // epilogue reads a global operand
+    constexpr bool kBiasInit = (EPI == EPI_BERN) && KTC > 0;         // accumulators start at the bias (single k-window: bias block is there)
 
     uint4 bfr[8][2];
     auto load_b = [&](int kw) {
@@ -254,6 +274,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     if (nkw == 1) load_b(0);
     uint4 pre[2][2], pre_n[2][2];
     if (kPre && mg0 < mg1) load_pre(mg0, pre);
+    DS_STAMP(0)      // prologue
 
     for (int mg = mg0; mg < mg1; ++mg) {
         f32x4 acc[4][2];
@@ -267,16 +288,27 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
             const int unit = (mg - mg0) * nkw + kw, buf = unit & 1;
             if (nkw > 1) load_b(kw);
             wait_all_vmem();
+            DS_STAMP(1)      // vmcnt wait
             __syncthreads();
+            DS_STAMP(2)      // barrier
             const bool more = unit + 1 < nunits;
             if (!KTC && more) stage(unit + 1, buf ^ 1);
             if (kw == 0) {
                 emit_stores();
                 if (kPre && mg + 1 < mg1) load_pre(mg + 1, pre_n);
             }
+            DS_STAMP(3)      // issue stores / prefetch loads
             const int nks = KTC ? KTC : min(8, KT - kw * 8);
             const char* lb = smem + buf * DENSE_UNIT + a_off;
             lbias = smem + buf * DENSE_UNIT + nks * 4096;
+            if (kBiasInit) {      // bias of features 16t + 4q + i is what accumulator register i of tile t starts from
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 b4 = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+                }
+            }
             if (KTC) {
                 constexpr int NF = (KTC ? KTC : 1) * 4, STEP = NF / NIDXC > 0 ? NF / NIDXC : 1;
                 lds_pipeline<NF, 8>(
@@ -305,6 +337,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
             }
         }
 
+        DS_STAMP(4)      // MFMA phase
         // ---------------- epilogue math for out-features 64*mg .. 64*mg+63 ----------------
         float4 bias4[4];   // bias of features 16t + 4q + i, from the image's bias block
 #pragma unroll
@@ -355,29 +388,39 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
             // log p(x|z) = sum_j x_j l_j - softplus(l_j), softplus(l) = max(l,0) + ln2*log2(1 + 2^(-|l| log2e))  (iwae1.py:111)
             // wave-uniform branch: only the last pixel group needs masks
             // keep: the training step also stores s = x - sigmoid(l) (bf16, P-layout) -- d lpxz / d l up to the row weight,
-            // which out_bwd and the output layer's weight gradient then read instead of recomputing the logits
+            // which out_bwd and the output layer's weight gradient then read instead of recomputing the logits.
+            // Per logit: unpack x, x-1/2, mul, exp2, add, log2 and three running sums (+ rcp, sub, copysign, sub, half a pack
+            // when s is kept).  With e = exp(-|l|) and max(l,0) = (l + |l|)/2:
+            //   x*l - softplus(l) = (x - 1/2)*l - |l|/2 - ln2*log2(1+e),   sigmoid(l) - 1/2 = copysign(1/(1+e) - 1/2, l)
+            // (packed v_pk_*_f32 forms of the same arithmetic were measured: no gain, they cost two issue slots each)
             auto bern_body = [&](auto masked, auto keep) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         float sv[8];
+                        float s_xl = 0.0f, s_al = 0.0f, s_lg = 0.0f;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const float l = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
-                            const float xj = bf_at(pre[p][g], j);
-                            const float e = exp2_raw(-fabsf(l) * LOG2E_F), ope = 1.0f + e;      // e = exp(-|l|)
-                            const float lg = log2_raw(ope);
-                            float term = fmaf(xj, l, -fmaxf(l, 0.0f));
-                            term = fmaf(-LN2_F, lg, term);
-                            const bool in = !decltype(masked)::value || (64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim);
-                            rowacc[g] += in ? term : 0.0f;
+                            float l = acc[2 * p + (j >> 2)][g][j & 3];
+                            if (!kBiasInit) l += bias_of(2 * p + (j >> 2), j & 3);
+                            const float xm = bf_at(pre[p][g], j) - 0.5f;
+                            const float ope = 1.0f + exp2_raw(-fabsf(l * LOG2E_F));      // 1 + exp(-|l|)
+                            float lg = log2_raw(ope);
+                            bool in = true;
+                            if (decltype(masked)::value) {      // pad pixels have l = 0 exactly (zero image rows, zero bias): only log2(2) to drop
+                                in = 64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim;
+                                lg = in ? lg : 0.0f;
+                            }
+                            s_lg += lg;
+                            s_al += fabsf(l);
+                            s_xl = fmaf(xm, l, s_xl);
                             if (decltype(keep)::value) {
-                                const float r = rcp_fast(ope);                                      // sigmoid(|l|)
-                                const float sg = l >= 0.0f ? r : e * r;
-                                sv[j] = in ? xj - sg : 0.0f;
+                                const float h = __builtin_copysignf(rcp_fast(ope) - 0.5f, l);    // sigmoid(l) - 1/2
+                                sv[j] = in ? xm - h : 0.0f;
                             }
                         }
+                        rowacc[g] += s_xl - 0.5f * s_al - LN2_F * s_lg;
                         if (decltype(keep)::value)
                             stP[p][g] = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
                     }
@@ -401,7 +444,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
                         for (int j = 0; j < 8; ++j) {
                             const int f = 64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3);
                             if (valid[g] && f < a.Xdim)
-                                a.logits_out[((size_t)sidx[g] * a.B + bidx[g]) * a.Xdim + f] = acc[2 * p + (j >> 2)][g][j & 3] + bias_of(2 * p + (j >> 2), j & 3);
+                                a.logits_out[((size_t)sidx[g] * a.B + bidx[g]) * a.Xdim + f] = acc[2 * p + (j >> 2)][g][j & 3] + (kBiasInit ? 0.0f : bias_of(2 * p + (j >> 2), j & 3));
                         }
             }
         }
@@ -411,6 +454,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 #pragma unroll
                 for (int g = 0; g < 2; ++g) pre[p][g] = pre_n[p][g];
         }
+        DS_STAMP(5)      // epilogue math
     }
     emit_stores();
 
@@ -423,6 +467,13 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
             if (q == 0 && valid[g]) a.lpxz[row[g]] = v;
         }
     }
+#ifdef IWAE_DENSE_STAMPS
+    DS_STAMP(6)      // tail
+    if (a.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + i] = ds_sum[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------

@@ -115,6 +115,7 @@ struct iwae_model {
     uint32_t ds_epoch = 0;
     int ds_start = -1;         // >= 0: the next forward gathers + binarises rows ds_start.. from the dataset instead of reading x
     DevBuf stamps;             // diagnostic (IWAE_STAMPS=1)
+    DevBuf dstamps; int dstamp_epi = -1, dstamp_kt = -1, dstamp_waves = 0;   // diagnostic (IWAE_DENSE_STAMPS)
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
@@ -322,6 +323,15 @@ EpsSrc eps_src(iwae_model* m, int layer) {
     return e;
 }
 
+// diagnostic (STAMPS=1 build + IWAE_DENSE_STAMPS="<epi>:<KT>"): record the phase stamps of the matching dense launch
+int attach_dense_stamps(iwae_model* m, int epi, DenseArgs& a) {
+    if (m->dstamp_epi != epi || m->dstamp_kt != a.KT || a.M < 4096) return IWAE_OK;
+    m->dstamp_waves = ((a.M + 127) / 128) * ((a.MG + a.mg_per_block - 1) / a.mg_per_block) * 4;
+    CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, m->stream));
+    a.stamps = ptr<unsigned long long>(m->dstamps);
+    return IWAE_OK;
+}
+
 // ---------------------------------------------------------------- forward pieces
 int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, uint16_t* YP, float* YF, int ldYF) {
     DenseArgs a;
@@ -330,6 +340,7 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, u
     a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
     a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32;
     a.YP = YP; a.ldYP = L.Np32; a.YF = YF; a.ldYF = ldYF;
+    CHK(attach_dense_stamps(m, epi, a));
     launch_dense(epi, a, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -401,6 +412,7 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
     a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = (rows <= 8192) ? 1 : L.MG_B; a.Np32 = L.Kp32;
     a.YP = YP; a.ldYP = L.Kp32; a.YF = YF; a.ldYF = L.Kp32;
     a.ACT = ACT; a.ldACT = L.Kp32;
+    CHK(attach_dense_stamps(m, ACT ? EPI_DX : EPI_F32, a));
     launch_dense(ACT ? EPI_DX : EPI_F32, a, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -586,6 +598,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
         }
+            CHK(attach_dense_stamps(m, EPI_BERN, a));
             { ScopedTimer tm(m, 1); launch_dense(EPI_BERN, a, st); }
         HIPCHK(hipGetLastError());
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
@@ -831,6 +844,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipSetDevice(cfg->device));
     iwae_model* m = new iwae_model();
     m->cfg = *cfg;
+    if (const char* e = getenv("IWAE_DENSE_STAMPS")) sscanf(e, "%d:%d", &m->dstamp_epi, &m->dstamp_kt);
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
@@ -898,7 +912,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->dzsum,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
     for (BlockWs* w : bw) {
@@ -1266,6 +1280,17 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
             {"dz1", 2, &m->dzsum, M, Dp0, Dp0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0},
         };
         ents.insert(ents.end(), e2.begin(), e2.end());
+    }
+    if (strcmp(name, "dense_stamps") == 0) {   // diagnostic: [waves][8] phase cycle sums of the selected dense launch
+        if (rows) *rows = m->dstamp_waves;
+        if (cols) *cols = 8;
+        if (!out) return IWAE_OK;
+        if (!m->dstamps.p) return fail(IWAE_ERR_STATE, "dense stamps not enabled (STAMPS=1 build + IWAE_DENSE_STAMPS=epi:KT)");
+        std::vector<unsigned long long> h((size_t)m->dstamp_waves * 8);
+        HIPCHK(hipStreamSynchronize(m->stream));
+        HIPCHK(hipMemcpy(h.data(), m->dstamps.p, h.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); ++i) out[i] = (float)h[i];
+        return IWAE_OK;
     }
     if (strcmp(name, "stamps") == 0) {   // diagnostic: [waves][8] phase cycle sums of out_bwd, as float
         const int nw = (Mp / 64) * 4;
