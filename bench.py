@@ -25,10 +25,22 @@ B_PER_GPU, K_SAMPLES, N_HIDDEN, N_LATENT, X_DIM = 1024, 50, 200, 100, 784
 OBJ_IWAE_ELBO = 1
 # algorithmic GEMM FLOPs of one step: 3*(473600*B + 433600*B*k) - 313600*B
 FLOP_PER_STEP = 3 * (473600 * B_PER_GPU + 433600 * B_PER_GPU * K_SAMPLES) - 313600 * B_PER_GPU
-# dominant kernel (out_bwd): logits recompute + dg2, two [M,200]x[200,784] products
-FLOP_OUT_BWD = 2 * 2 * B_PER_GPU * K_SAMPLES * N_HIDDEN * X_DIM
-TIMING_EVERY = 8
-PEAK_BF16_TFLOPS = 2500.0    # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md), no sparsity
+TIMING_EVERY = 8             # HIP events bracket the candidate kernels on every 8th step of the timed region
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain device copy reaches ~4.8 TB/s
+M_ROWS = B_PER_GPU * K_SAMPLES
+# The two heaviest kernels of the step, both below the roofline ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), i.e. HBM-bound
+# by the model.  Algorithmic bytes per data row (unpadded):
+#   bernoulli_fwd  (dense_kernel<EPI_BERN>): g2 row in (2H) + x of the image, shared by its k rows (2X/k) + s = x - sigmoid(l)
+#                  out (2X) + log p(x|z) out (4);   FLOP 2HX
+#   out_bwd        (out_bwd_s_kernel): s in (2X) + g2 in (2H) + row weight (4) + dpre2 out (2H);   FLOP 2HX
+KERNELS = {
+    "bernoulli_fwd": {"name": "dense_kernel<EPI_BERN,7,1> (decoder output layer + Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
+                      "bytes": M_ROWS * (2 * N_HIDDEN + 2.0 * X_DIM / K_SAMPLES + 2 * X_DIM + 4), "flop": 2 * M_ROWS * N_HIDDEN * X_DIM,
+                      "match": "dense_kernel<4"},
+    "out_bwd": {"name": "out_bwd_s_kernel<7> (decoder output-layer backward from the stored s)",
+                "bytes": M_ROWS * (2 * X_DIM + 2 * N_HIDDEN + 4 + 2 * N_HIDDEN), "flop": 2 * M_ROWS * N_HIDDEN * X_DIM,
+                "match": "out_bwd"},
+}
 
 
 def synthetic_batch(n, seed):
@@ -127,21 +139,23 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ob_us, ob_n = net.kernel_time("out_bwd")
+    ktimes = {k: net.kernel_time(k) for k in KERNELS}
     net.enable_timing(0)
     elbo = net.forward(x_np[lo:lo + B_PER_GPU], K_SAMPLES)["iwae_elbo"]
 
     if rank == 0:
         ms = dt * 1e3 / args.steps
         value = B_PER_GPU * world * args.steps / dt
+        dom = max(KERNELS, key=lambda k: ktimes[k][0])          # the kernel with the longest average launch
+        dom_us, dom_n = ktimes[dom]
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_out_bwd_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_kernel_traffic.json")     # PMC passes of tools/profile_bench.sh
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        ach = FLOP_OUT_BWD / (ob_us * 1e-6) / 1e12 if ob_us > 0 else 0.0
+        ach = KERNELS[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
         out = {
             "metric": "images/sec (train step) IWAE k=50 batch 1024 @1/2/4/8 GPU; test LLH@k=5000",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,10 +167,14 @@ def main():
                        "global_batch": B_PER_GPU * world, "n_samples": K_SAMPLES, "parallelism": "dp%d" % world,
                        "step_gemm_tflops": round(FLOP_PER_STEP * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3)},
-            "roofline": {"bound": "mfma", "kernel": "out_bwd_pair_kernel<7> (decoder output-layer backward, logits recomputed)",
-                         "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "avg_launch_us": round(ob_us, 2), "launches": ob_n, "flop_per_launch": FLOP_OUT_BWD},
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom]["name"],
+                         "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                         "avg_launch_us": round(dom_us, 2), "launches": dom_n,
+                         "algorithmic_bytes_per_launch": int(KERNELS[dom]["bytes"]),
+                         "flop_per_launch": KERNELS[dom]["flop"],
+                         "mfma_tflops": round(KERNELS[dom]["flop"] / (dom_us * 1e-6) / 1e12, 1) if dom_us > 0 else 0.0,
+                         "other": {k: round(v[0], 2) for k, v in ktimes.items() if k != dom}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

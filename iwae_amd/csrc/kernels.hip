@@ -155,6 +155,7 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 // so neither load latency nor store acknowledgement sits in front of a barrier.
 // ---------------------------------------------------------------------------------
 #define DENSE_UNIT 33792   // 8 k-steps x 4 KiB + 1 KiB bias block
+#define IWAE_DENSE_G1_DEFAULT 29u    // EPI bit mask of the launches that use the 8-wave x 16-row shape (see launch_dense_g1)
 
 // diagnostic build only (./build.sh with STAMPS=1): per-phase s_memtime sums per wave -> a.stamps[wave][8]
 #ifdef IWAE_DENSE_STAMPS
@@ -171,8 +172,13 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 #define DS_STAMP(slot)
 #endif
 
-template <int EPI, int KTC>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
-__global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(DenseArgs a) {
+// G = 16-row column groups per wave.  G = 2: 4 waves x 32 rows, every weight fragment read from LDS feeds two MFMAs
+// (the LDS-frugal shape).  G = 1: 8 waves x 16 rows in <= 128 registers, i.e. FOUR waves per SIMD with two workgroups
+// per CU: the epilogues here are transcendental-bound on the wave's own issue stream (exp/log/rcp at quarter rate), and
+// the only way to fill a SIMD's transcendental unit is more resident waves.
+template <int EPI, int KTC, int G>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
+__global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD
+    constexpr int NWV = (G == 2) ? 4 : 8;
 #ifdef IWAE_DENSE_STAMPS
     unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
@@ -180,14 +186,13 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int r0 = (blockIdx.x * 4 + wave) * 32;
-    int row[2];
-    bool valid[2];
+    const int r0 = (blockIdx.x * NWV + wave) * (16 * G);
+    int row[G], rowc[G];
+    bool valid[G];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; }
+    for (int g = 0; g < G; ++g) { row[g] = r0 + G * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
     // loads are issued unconditionally from a clamped row and zeroed by a select afterwards: a
     // branch per load would put a vmcnt wait behind every one of them
-    const int rowc[2] = {min(row[0], a.M - 1), min(row[1], a.M - 1)};
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     const int KT = KTC ? KTC : a.KT;
     const int nkw = KTC ? 1 : ((KT + 7) >> 3);
@@ -199,12 +204,12 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     constexpr bool kPre = (EPI == EPI_DX || EPI == EPI_BERN);        // epilogue reads a global operand
     constexpr bool kBiasInit = (EPI == EPI_BERN) && KTC > 0;         // accumulators start at the bias (single k-window: bias block is there)
 
-    uint4 bfr[8][2];
+    uint4 bfr[8][G];
     auto load_b = [&](int kw) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (KTC ? ks < KTC : kw * 8 + ks < KT) {
                     v = *(const uint4*)(a.X + (size_t)rowc[g] * a.ldX + (kw * 8 + ks) * 32 + q * 8);
@@ -218,33 +223,35 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
         const int mg = mg0 + unit / nkw, kw = unit % nkw;
         const int nks = min(8, KT - kw * 8);
         const int bytes = nks * 4096 + ((kw == nkw - 1) ? 1024 : 0);   // last window carries the bias block
-        stage_image<4>(a.img + (size_t)mg * gbytes + (size_t)kw * 8 * 4096, smem + buf * DENSE_UNIT, bytes, wave, lane);
+        stage_image<NWV>(a.img + (size_t)mg * gbytes + (size_t)kw * 8 * 4096, smem + buf * DENSE_UNIT, bytes, wave, lane);
     };
     // compile-time shapes: the group is NPC 1 KiB DMA pieces, wave w moves pieces w, w+4, ...; they are issued
     // one at a time between the MFMAs of the previous group (the per-CU L2->LDS rate, ~60-70 GB/s, is what a
     // lump of 29 pieces in front of the MFMAs would wait for)
-    constexpr int NPC = (KTC ? KTC : 1) * 4 + 1, NIDXC = (NPC + 3) / 4;
+    constexpr int NPC = (KTC ? KTC : 1) * 4 + 1, NIDXC = (NPC + NWV - 1) / NWV;
     auto dma_piece = [&](int unit, int buf, int idx) {
-        const int p = wave + 4 * idx;                 // wave-uniform
+        const int p = wave + NWV * idx;               // wave-uniform
         if (p < NPC)
             glds16(a.img + (size_t)(mg0 + unit) * gbytes + (size_t)p * 1024 + lane * 16,
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * DENSE_UNIT) + (uint32_t)p * 1024u)));
     };
 
     // EPI_BERN state
-    float rowacc[2] = {0.0f, 0.0f};
-    int bidx[2] = {0, 0}, sidx[2] = {0, 0};
+    float rowacc[G];
+    int bidx[G], sidx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { rowacc[g] = 0.0f; bidx[g] = 0; sidx[g] = 0; }
     if (EPI == EPI_BERN) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) { bidx[g] = valid[g] ? row[g] / a.k : 0; sidx[g] = valid[g] ? row[g] - bidx[g] * a.k : 0; }
+        for (int g = 0; g < G; ++g) { bidx[g] = valid[g] ? row[g] / a.k : 0; sidx[g] = valid[g] ? row[g] - bidx[g] * a.k : 0; }
     }
     // lane-constant byte offsets (32-bit) next to wave-uniform 64-bit bases
 
-    auto load_pre = [&](int mg, uint4 (&pre)[2][2]) {
+    auto load_pre = [&](int mg, uint4 (&pre)[2][G]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 pre[p][g] = make_uint4(0, 0, 0, 0);
                 const int fbase = 64 * mg + 32 * p;      // wave-uniform guards only
                 if (EPI == EPI_DX && fbase < a.Np32) pre[p][g] = *(const uint4*)(a.ACT + (size_t)rowc[g] * a.ldACT + fbase + 8 * q);
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     };
 
     // deferred bf16 stores of the previous group
-    uint4 stP[2][2];
+    uint4 stP[2][G];
     int st_mg = -1;
     auto emit_stores = [&]() {
         if (!(kPacked || EPI == EPI_BERN) || st_mg < 0) return;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
             const int fbase = 64 * st_mg + 32 * p;
             if (fbase < a.Np32) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                for (int g = 0; g < G; ++g)
                     if (valid[g]) *(uint4*)(a.YP + (size_t)row[g] * a.ldYP + fbase + 8 * q) = stP[p][g];
             }
         }
@@ -272,16 +279,16 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 
     if (nunits > 0) stage(0, 0);
     if (nkw == 1) load_b(0);
-    uint4 pre[2][2], pre_n[2][2];
+    uint4 pre[2][G], pre_n[2][G];
     if (kPre && mg0 < mg1) load_pre(mg0, pre);
     DS_STAMP(0)      // prologue
 
     for (int mg = mg0; mg < mg1; ++mg) {
-        f32x4 acc[4][2];
+        f32x4 acc[4][G];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int g = 0; g < G; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
         const char* lbias = smem;
         for (int kw = 0; kw < nkw; ++kw) {
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
                 for (int t = 0; t < 4; ++t) {
                     const float4 b4 = *(const float4*)(lbias + (16 * t + 4 * q) * 4);
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+                    for (int g = 0; g < G; ++g) acc[t][g] = (f32x4){b4.x, b4.y, b4.z, b4.w};
                 }
             }
             if (KTC) {
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
                     [&](int i) { return *(const uint4*)(lb + i * 1024); },
                     [&](int i, const uint4& av) {
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, bfr[i >> 2][g], acc[i & 3][g]);
+                        for (int g = 0; g < G; ++g) acc[i & 3][g] = mfma16(av, bfr[i >> 2][g], acc[i & 3][g]);
                     },
                     [&](int i) { if (more && i % STEP == 0 && i / STEP < NIDXC) dma_piece(unit + 1, buf ^ 1, i / STEP); });
                 if (more) {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
                         for (int t = 0; t < 4; ++t) {
                             const uint4 av = *(const uint4*)(lb + (ks * 4 + t) * 1024);
 #pragma unroll
-                            for (int g = 0; g < 2; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
+                            for (int g = 0; g < G; ++g) acc[t][g] = mfma16(av, bfr[ks][g], acc[t][g]);
                         }
                     }
                 }
@@ -347,9 +354,9 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
         if (kPacked) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                float v[2][8];
+                float v[G][8];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < G; ++g) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float x = acc[2 * p + (j >> 2)][g][j & 3];
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
                 const int f0 = 64 * mg + 16 * t + 4 * q;
                 if (f0 < a.ldYF) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < G; ++g) {
                         float op[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
+                    for (int g = 0; g < G; ++g) {
                         float sv[8];
                         float s_xl = 0.0f, s_al = 0.0f, s_lg = 0.0f;
 #pragma unroll
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
+                    for (int g = 0; g < G; ++g)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int f = 64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) pre[p][g] = pre_n[p][g];
+                for (int g = 0; g < G; ++g) pre[p][g] = pre_n[p][g];
         }
         DS_STAMP(5)      // epilogue math
     }
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
 
     if (EPI == EPI_BERN) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < G; ++g) {
             float v = rowacc[g];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256, EPI == EPI_BERN ? 2 : 1) void dense_kernel(Den
     DS_STAMP(6)      // tail
     if (a.stamps && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + i] = ds_sum[i];
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 8 + i] = ds_sum[i];
     }
 #endif
 }
@@ -1749,17 +1756,35 @@ static inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1)
 template <int KTC>
 static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     switch (epi) {
-        case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, KTC>), grid, dim3(256), lds, st, a); break;
-        case EPI_HEAD: hipLaunchKernelGGL((dense_kernel<EPI_HEAD, KTC>), grid, dim3(256), lds, st, a); break;
-        case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, KTC>), grid, dim3(256), lds, st, a); break;
-        case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, KTC>), grid, dim3(256), lds, st, a); break;
-        case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, KTC>), grid, dim3(256), lds, st, a); break;
-        case EPI_SIGMOID: hipLaunchKernelGGL((dense_kernel<EPI_SIGMOID, KTC>), grid, dim3(256), lds, st, a); break;
+        case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_HEAD: hipLaunchKernelGGL((dense_kernel<EPI_HEAD, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_SIGMOID: hipLaunchKernelGGL((dense_kernel<EPI_SIGMOID, KTC, 2>), grid, dim3(256), lds, st, a); break;
     }
+}
+// 8 waves x 16 rows (four waves per SIMD): instantiated for the large-row-count launches of the reference shapes
+static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static const char* sel = getenv("IWAE_DENSE_G1");      // tuning aid: bit mask over EPI ids (default below)
+    const unsigned mask = sel ? (unsigned)atoi(sel) : IWAE_DENSE_G1_DEFAULT;
+    if (a.M < 8192 || !((mask >> epi) & 1u)) return false;
+    if (a.KT == 7) {
+        switch (epi) {
+            case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            default: return false;
+        }
+    }
+    if (a.KT == 4 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 4, 1>), grid, dim3(512), lds, st, a); return true; }
+    return false;
 }
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     dim3 grid((a.M + 127) / 128, (a.MG + a.mg_per_block - 1) / a.mg_per_block);
     const size_t lds = 2 * DENSE_UNIT;
+    if (launch_dense_g1(epi, a, grid, lds, st)) return;
     // compile-time k-step counts for the reference model's shapes (200->224, 100->128, 50->64, head 256)
     switch (a.KT) {
         case 2: launch_dense_k<2>(epi, a, grid, lds, st); break;

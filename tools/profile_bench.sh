@@ -29,15 +29,17 @@ for k, c in agg.items():
     summ[k] = {n: sum(v) / len(v) for n, v in c.items()}
     summ[k]["dispatches"] = len(next(iter(c.values())))
 json.dump(summ, open(out + "/pmc_per_launch.json", "w"), indent=1, sort_keys=True)
-ob = [k for k in summ if "out_bwd" in k]
-if ob:
-    s = summ[ob[0]]
-    # gfx950: FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact
-    hbm = (2.0 * s.get("FETCH_SIZE", 0.0) + s.get("WRITE_SIZE", 0.0)) * 1024.0
-    json.dump({"kernel": ob[0], "FETCH_SIZE_KiB": s.get("FETCH_SIZE"), "WRITE_SIZE_KiB": s.get("WRITE_SIZE"),
-               "hbm_bytes_per_launch": hbm, "correction": "read side x2 (gfx950 FETCH_SIZE), write side exact"},
-              open(out + "/out_bwd_traffic.json", "w"), indent=1)
-    print("out_bwd HBM bytes/launch: %.1f MB (fetch %.1f KiB raw, write %.1f KiB)" % (hbm / 1e6, s.get("FETCH_SIZE", 0), s.get("WRITE_SIZE", 0)))
+# gfx950: FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact
+traffic = {}
+for short, pat in (("bernoulli_fwd", "dense_kernel<4"), ("out_bwd", "out_bwd"), ("wgrad_out", "wgradp_kernel<16, true")):
+    ks = [k for k in summ if pat in k]
+    if not ks: continue
+    v = summ[ks[0]]
+    hbm = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+    traffic[short] = {"kernel": ks[0], "FETCH_SIZE_KiB": v.get("FETCH_SIZE"), "WRITE_SIZE_KiB": v.get("WRITE_SIZE"),
+                      "hbm_bytes_per_launch": hbm, "correction": "read side x2 (gfx950 FETCH_SIZE), write side exact"}
+    print("%s HBM bytes/launch: %.1f MB (fetch %.1f KiB raw, write %.1f KiB)" % (short, hbm / 1e6, v.get("FETCH_SIZE", 0), v.get("WRITE_SIZE", 0)))
+json.dump(traffic, open(out + "/kernel_traffic.json", "w"), indent=1)
 for r in rows[:14]:
     print("%-62s calls %5s avg_us %9.2f pct %6s" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
