@@ -5,6 +5,7 @@
 
 namespace iwae {
 
+#define IWAE_DENSE_G1_DEFAULT 29u     // TANH | DX | F32 | BERN (measured: 0.339 -> 0.328 ms/step at B=1024, k=50)
 enum { EPI_TANH = 0, EPI_HEAD = 1, EPI_DX = 2, EPI_F32 = 3, EPI_BERN = 4, EPI_SIGMOID = 5 };
 enum { OBJ_VAE_ELBO = 0, OBJ_IWAE_ELBO = 1, OBJ_IWAE_EQ14 = 2, OBJ_VAE_ELBO_KL = 3, OBJ_DREG = 4 };
 // per-image reductions written by lse_kernel
@@ -28,6 +29,7 @@ struct DenseArgs {
     const char* img;                  // MG-major A-image of the weight
     int split;                        // EPI_HEAD: out-features >= split are the sigma head (exp + 1e-6)
     int M, KT, MG, mg_per_block;
+    unsigned g1_mask;                 // EPI bit mask: launches (M >= 8192) that take the 8-wave x 16-row shape
     int Np32;                         // out-features that are stored (multiple of 32)
     uint16_t* YP; int ldYP;           // bf16 P-layout out
     float* YF; int ldYF;              // fp32 natural out

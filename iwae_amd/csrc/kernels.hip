@@ -145,6 +145,40 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 }
 
 // ---------------------------------------------------------------------------------
+// Bernoulli log-likelihood of the lane's 8 logits of one 32-pixel step (accumulator tiles a0: pixels f0..f0+3,
+// a1: f0+16..f0+19, bias already in), x = the lane's 8 bf16 pixel values:
+//   returns sum_j x_j l_j - softplus(l_j)  (iwae1.py:111);  KEEP: sp = bf16 of s_j = x_j - sigmoid(l_j), the gradient of that
+//   sum wrt l_j, which the backward kernels read instead of recomputing the logits.
+// Per logit: unpack x, x-1/2, mul, exp2, add, mul and two running sums (+ rcp, sub, copysign, sub, half a pack for s).
+// With e = exp(-|l|) and max(l,0) = (l + |l|)/2:
+//   x*l - softplus(l) = (x - 1/2)*l - |l|/2 - ln2*log2(1+e),   sigmoid(l) - 1/2 = copysign(1/(1+e) - 1/2, l),
+// and sum_j log2(1+e_j) = log2(prod_j (1+e_j)): the factors lie in (1,2], so 8 logits cost seven multiplies and ONE
+// v_log instead of eight quarter-rate v_log.  MASKED: pixels >= Xdim (pads, l = 0 exactly) contribute nothing.
+// Measured (phase stamps, ablations): ~80 issue cycles per logit with s kept, transcendentals at 16 each -- this
+// epilogue, not the MFMAs, the LDS stream or the stores, is what the Bernoulli kernel's time is made of.
+// ---------------------------------------------------------------------------------
+template <bool MASKED, bool KEEP>
+__device__ __forceinline__ float bern8(const f32x4& a0, const f32x4& a1, const uint4& xb, int f0, int Xdim, uint4& sp) {
+    float s_xl = 0.0f, s_al = 0.0f, prod = 1.0f, sv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float l = (j < 4) ? a0[j & 3] : a1[j & 3];
+        const float xm = bf_at(xb, j) - 0.5f;
+        const float ope = 1.0f + exp2_raw(-fabsf(l * LOG2E_F));      // 1 + exp(-|l|)
+        const bool in = !MASKED || (f0 + 16 * (j >> 2) + (j & 3) < Xdim);
+        prod *= in ? ope : 1.0f;
+        s_al += fabsf(l);
+        s_xl = fmaf(xm, l, s_xl);
+        if (KEEP) {
+            const float h = __builtin_copysignf(rcp_fast(ope) - 0.5f, l);    // sigmoid(l) - 1/2
+            sv[j] = in ? xm - h : 0.0f;
+        }
+    }
+    if (KEEP) sp = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
+    return s_xl - 0.5f * s_al - LN2_F * log2_raw(prod);
+}
+
+// ---------------------------------------------------------------------------------
 // dense_kernel: Y^T[out][rows] = W^T-image x X^T, one wave = 32 data rows (2 column groups of
 // 16, rows interleaved r0+2*rho+g).
 // Weights (and the bias of the group, as a trailing 1 KiB block) stream through LDS one
@@ -155,7 +189,6 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 // so neither load latency nor store acknowledgement sits in front of a barrier.
 // ---------------------------------------------------------------------------------
 #define DENSE_UNIT 33792   // 8 k-steps x 4 KiB + 1 KiB bias block
-#define IWAE_DENSE_G1_DEFAULT 29u    // EPI bit mask of the launches that use the 8-wave x 16-row shape (see launch_dense_g1)
 
 // diagnostic build only (./build.sh with STAMPS=1): per-phase s_memtime sums per wave -> a.stamps[wave][8]
 #ifdef IWAE_DENSE_STAMPS
@@ -396,42 +429,18 @@ __global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ?
             // wave-uniform branch: only the last pixel group needs masks
             // keep: the training step also stores s = x - sigmoid(l) (bf16, P-layout) -- d lpxz / d l up to the row weight,
             // which out_bwd and the output layer's weight gradient then read instead of recomputing the logits.
-            // Per logit: unpack x, x-1/2, mul, exp2, add, log2 and three running sums (+ rcp, sub, copysign, sub, half a pack
-            // when s is kept).  With e = exp(-|l|) and max(l,0) = (l + |l|)/2:
-            //   x*l - softplus(l) = (x - 1/2)*l - |l|/2 - ln2*log2(1+e),   sigmoid(l) - 1/2 = copysign(1/(1+e) - 1/2, l)
-            // (packed v_pk_*_f32 forms of the same arithmetic were measured: no gain, they cost two issue slots each)
             auto bern_body = [&](auto masked, auto keep) {
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < 2; ++p)
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
-                        float sv[8];
-                        float s_xl = 0.0f, s_al = 0.0f, s_lg = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float l = acc[2 * p + (j >> 2)][g][j & 3];
-                            if (!kBiasInit) l += bias_of(2 * p + (j >> 2), j & 3);
-                            const float xm = bf_at(pre[p][g], j) - 0.5f;
-                            const float ope = 1.0f + exp2_raw(-fabsf(l * LOG2E_F));      // 1 + exp(-|l|)
-                            float lg = log2_raw(ope);
-                            bool in = true;
-                            if (decltype(masked)::value) {      // pad pixels have l = 0 exactly (zero image rows, zero bias): only log2(2) to drop
-                                in = 64 * mg + 32 * p + 16 * (j >> 2) + 4 * q + (j & 3) < a.Xdim;
-                                lg = in ? lg : 0.0f;
-                            }
-                            s_lg += lg;
-                            s_al += fabsf(l);
-                            s_xl = fmaf(xm, l, s_xl);
-                            if (decltype(keep)::value) {
-                                const float h = __builtin_copysignf(rcp_fast(ope) - 0.5f, l);    // sigmoid(l) - 1/2
-                                sv[j] = in ? xm - h : 0.0f;
-                            }
+                        f32x4 t0 = acc[2 * p][g], t1 = acc[2 * p + 1][g];
+                        if (!kBiasInit) {
+                            t0 += (f32x4){bias_of(2 * p, 0), bias_of(2 * p, 1), bias_of(2 * p, 2), bias_of(2 * p, 3)};
+                            t1 += (f32x4){bias_of(2 * p + 1, 0), bias_of(2 * p + 1, 1), bias_of(2 * p + 1, 2), bias_of(2 * p + 1, 3)};
                         }
-                        rowacc[g] += s_xl - 0.5f * s_al - LN2_F * s_lg;
-                        if (decltype(keep)::value)
-                            stP[p][g] = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
+                        rowacc[g] += bern8<decltype(masked)::value, decltype(keep)::value>(t0, t1, pre[p][g], 64 * mg + 32 * p + 4 * q, a.Xdim, stP[p][g]);
                     }
-                }
             };
             const bool full = 64 * mg + 64 <= a.Xdim;
             if (a.YP) {
@@ -1766,9 +1775,7 @@ static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, h
 }
 // 8 waves x 16 rows (four waves per SIMD): instantiated for the large-row-count launches of the reference shapes
 static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static const char* sel = getenv("IWAE_DENSE_G1");      // tuning aid: bit mask over EPI ids (default below)
-    const unsigned mask = sel ? (unsigned)atoi(sel) : IWAE_DENSE_G1_DEFAULT;
-    if (a.M < 8192 || !((mask >> epi) & 1u)) return false;
+    if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;
     if (a.KT == 7) {
         switch (epi) {
             case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, 7, 1>), grid, dim3(512), lds, st, a); return true;

@@ -89,6 +89,7 @@ struct iwae_model {
     int B = 0, k = 0, M = 0, Mp = 0, Bp = 0;
     float beta = 1.0f;
     bool have_forward = false, user_eps = false;
+    unsigned dense_g1_mask = IWAE_DENSE_G1_DEFAULT;   // IWAE_DENSE_G1=<mask> (tuning aid, kernels.h)
     bool allow_s_mode = true;   // IWAE_OUT_RECOMPUTE=1 switches back to recomputing the logits in out_bwd (A/B measurements)
     bool s_mode = false;        // this step's forward kept s = x - sigmoid(l) in wdec1.dlP
     DevBuf xin, xP, epsbuf, zP[2];
@@ -338,7 +339,7 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, u
     memset(&a, 0, sizeof(a));
     a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
     a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
-    a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32;
+    a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
     a.YP = YP; a.ldYP = L.Np32; a.YF = YF; a.ldYF = ldYF;
     CHK(attach_dense_stamps(m, epi, a));
     launch_dense(epi, a, m->stream);
@@ -409,7 +410,7 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
     memset(&a, 0, sizeof(a));
     a.X = GP; a.ldX = L.Np32; a.img = L.imgB;
     a.split = 1 << 30;
-    a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = (rows <= 8192) ? 1 : L.MG_B; a.Np32 = L.Kp32;
+    a.M = rows; a.KT = L.KT_B; a.MG = L.MG_B; a.mg_per_block = (rows <= 8192) ? 1 : L.MG_B; a.Np32 = L.Kp32; a.g1_mask = m->dense_g1_mask;
     a.YP = YP; a.ldYP = L.Kp32; a.YF = YF; a.ldYF = L.Kp32;
     a.ACT = ACT; a.ldACT = L.Kp32;
     CHK(attach_dense_stamps(m, ACT ? EPI_DX : EPI_F32, a));
@@ -584,7 +585,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         memset(&a, 0, sizeof(a));
         a.X = ptr<uint16_t>(w.g2P); a.ldX = L.Kp32; a.img = L.imgF;
         a.split = 1 << 30;
-        a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32;
+        a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
         a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
         a.lpxz = lpxz;
         // training step: keep s = x - sigmoid(l) for the backward pass (out_bwd_s_kernel, output-layer weight gradient)
@@ -848,6 +849,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
+    if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 

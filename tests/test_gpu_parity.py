@@ -111,6 +111,58 @@ def test_train_step_2layer_matches_oracle(gpu, B, k, obj, nh, nl, xd):
     m.close()
 
 
+def test_large_row_count_kernels_match_oracle(gpu):
+    """8 500 data rows: the row-count-dependent kernel choices of the full-size step (8-wave x 16-row dense shape,
+    s = x - sigmoid(l) kept by the forward pass + out_bwd_s_kernel, 16-wave row-weighted weight gradient, one grouped
+    launch for the encoder's weight gradients) against the oracle, plus the fused Adam of iwae_train_step."""
+    B, k, nh, nl, xd = 170, 50, 200, 100, 784
+    x, P, eps = MG.inputs(1, nh, nl, xd, B, k, 4242)
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
+    m = _model(1, nh, nl, xd)
+    m.set_params(O.flatten_params(P))
+    r = m.forward_backward(x, k, 1.0, "iwae_elbo", eps=eps, want=("lpxz", "lqzx"))
+    assert np.max(np.abs(r["lpxz"] - res_e["lpxz"])) < EMU_ROW_ATOL
+    assert np.max(np.abs(r["lqzx"] - res_e["lqzx"])) < EMU_ROW_ATOL
+    for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+        assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    g = m.get_grads()
+    assert max(_grad_rel_errors(g, g_e)) < EMU_GRAD_REL
+    # the same step through iwae_train_step (Adam fused into the slab reduction) lands on the same parameters
+    r2 = m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", eps=eps)
+    assert abs(r2["iwae_elbo"] - r["iwae_elbo"]) < 1e-5
+    np.testing.assert_array_equal(m.get_grads(), g)
+    ref, _, _ = O.adam_update(O.flatten_params(P), g.astype(np.float64), 0.0, 0.0, 1, 1e-3)
+    assert np.max(np.abs(m.get_params() - ref)) < 2e-6
+    m.close()
+
+
+def test_kernel_variants_agree(gpu, monkeypatch):
+    """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
+    instead of reading the stored s, and the 4-wave x 32-row dense shape instead of 8 x 16."""
+    B, k = 170, 50
+    x = O.synthetic_binarized(B, 3)
+    P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
+
+    def run(env):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        m = _model(1, 200, 100)
+        for key in env:
+            monkeypatch.delenv(key)
+        m.set_params(O.flatten_params(P))
+        m.set_step(5, 0)
+        r = m.forward_backward(x, k, 1.0, "iwae_elbo")
+        g = m.get_grads().astype(np.float64)
+        m.close()
+        return r["iwae_elbo"], g
+
+    e0, g0 = run({})
+    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}):
+        e1, g1 = run(env)
+        assert abs(e1 - e0) < 2e-3, env
+        assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
+
+
 def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m = _model(2, [200, 100], [100, 50])
     x = O.synthetic_binarized(2, 1)
