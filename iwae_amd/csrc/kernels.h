@@ -142,9 +142,10 @@ void launch_lse(const LseArgs& a, hipStream_t st);
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st);
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
 void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st);
+// Sums the slabs of reduce blocks [first_block, first_block + nblocks) of the layer table into the flat gradient.
 // per_b != null: one extra block turns the per-image values into the batch means (scalars) of the step.
-// fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread
-void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, float* param, float* mom, float* vel,
+// fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread.
+void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
                          float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,

@@ -1644,20 +1644,23 @@ __device__ __forceinline__ void adam_element(const LayerDesc& L, bool is_bias, i
 // elements follows in the same thread (single-GPU train step: no all-reduce sits between the two).
 struct MeansArgs { const float* per_b; int B; float beta; float* out; };     // per_b == null: no extra block
 
+// The grid covers reduce blocks [first_block, first_block + n) of the layer table: the whole table, or -- single-GPU
+// train step -- the decoder's layers on the side stream and the rest on the main stream (see backward_impl).
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad, float* param, float* mom,
-                                                           float* vel, AdamCoef c, MeansArgs mn) {
+                                                           float* vel, AdamCoef c, MeansArgs mn, int first_block) {
     if (mn.per_b && blockIdx.x == gridDim.x - 1) {      // the one extra block of the grid: batch means of this step
         batch_means_block(mn.per_b, mn.B, mn.beta, mn.out);
         return;
     }
+    const int bid = (int)blockIdx.x + first_block;
     // block = 64 groups of 4 consecutive out-features (float4 loads) x 4 split groups; partial sums meet in LDS.
     // A group never straddles a weight row: rblock counts are computed per row of 4-float groups (Nout4 = ceil(Nout/4)).
     __shared__ float4 red[4][64];
     int l = 0;
-    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].rblock_begin) ++l;
+    while (l + 1 < nlayers && bid >= layers[l + 1].rblock_begin) ++l;
     const LayerDesc L = layers[l];
     const int n4 = (L.Nout + 3) >> 2;                       // float4 groups per weight row
-    const int g = ((int)blockIdx.x - L.rblock_begin) * 64 + (threadIdx.x & 63);
+    const int g = (bid - L.rblock_begin) * 64 + (threadIdx.x & 63);
     const int sg = threadIdx.x >> 6;
     const int ngroups = (L.Kin + 1) * n4;                   // Kin weight rows + 1 bias row
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1874,11 +1877,11 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
 void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(add3_kernel, grid1(n, 256), dim3(256), 0, st, out, a0, a1, a2, n);
 }
-void launch_reduce_grads(const LayerDesc* layers, int nlayers, int nblocks, float* grad, float* param, float* mom, float* vel,
+void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
                          float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
     const AdamCoef c = {alpha, 1.0f, 0.9f, 0.999f, eps, fuse_adam};
     const MeansArgs mn = {per_b, B, beta, scalars};
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
 }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);

@@ -120,7 +120,14 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_fork3 = nullptr, ev_join = nullptr, ev_dec = nullptr;
+    // Single-GPU train step: the decoder's slab reduction + Adam (90 % of the slab bytes) stays on the side stream and is
+    // NOT joined at the end of the step -- nothing needs the decoder's new weights before the next step's d1 layer, so it
+    // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
+    // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
+    bool dec_pending = false;
+    bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
+    int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
     int64_t timing_calls = 0;
     bool time_this = false;
@@ -277,9 +284,15 @@ int build_descs(iwae_model* m) {
     }
     m->elem_blocks = blocks;
     m->reduce_blocks = rblocks;
+    m->early_first = -1;
+    const int d0 = m->dec1[0].sub[0];
+    if (m->dec1[0].nsub == 1 && m->dec1[1].nsub == 1 && m->dec1[2].nsub == 1 && m->dec1[1].sub[0] == d0 + 1 &&
+        m->dec1[2].sub[0] == d0 + 2 && d0 + 3 == (int)m->descs.size())
+        m->early_first = m->descs[d0].rblock_begin;
     if (!m->d_descs) HIPCHK(hipMalloc((void**)&m->d_descs, sizeof(LayerDesc) * m->descs.size()));
     HIPCHK(hipMemcpyAsync(m->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // a deferred decoder update may still be reading the old table
     m->descs_dirty = false;
     return IWAE_OK;
 }
@@ -330,6 +343,14 @@ int attach_dense_stamps(iwae_model* m, int epi, DenseArgs& a) {
     m->dstamp_waves = ((a.M + 127) / 128) * ((a.MG + a.mg_per_block - 1) / a.mg_per_block) * 4;
     CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, m->stream));
     a.stamps = ptr<unsigned long long>(m->dstamps);
+    return IWAE_OK;
+}
+
+// orders the main stream behind a deferred decoder update (and the noise prefetch in front of it) still on the side stream
+int join_side(iwae_model* m) {
+    if (!m->dec_pending) return IWAE_OK;
+    HIPCHK(hipStreamWaitEvent(m->stream, m->ev_dec, 0));
+    m->dec_pending = false;
     return IWAE_OK;
 }
 
@@ -538,6 +559,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
+    CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
     {
         SampleArgs s;
         memset(&s, 0, sizeof(s));
@@ -695,8 +717,12 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
     if (!m->user_eps) CHK(draw_eps(m, m->epsc_par ^ 1, m->noise_step + 1, M, m->side));    // next step's noise (speculative)
-    HIPCHK(hipEventRecord(m->ev_join, m->side));
     CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
+    const bool fuse = fused_lr >= 0.0f;
+    const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
+    if (m->descs_dirty) CHK(build_descs(m));
+    const bool defer = fuse && m->allow_defer && m->early_first > 0;
+    if (!defer) HIPCHK(hipEventRecord(m->ev_join, m->side));
 
     const float* dz1 = ptr<float>(w.dz);
     if (two) {
@@ -736,11 +762,22 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         launch_latent_bwd(a, st);
     }
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false));
-    HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
-    if (m->descs_dirty) CHK(build_descs(m));
-    const bool fuse = fused_lr >= 0.0f;
-    launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                        fuse ? adam_alpha(m, fused_lr) : 0.0f, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+    if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
+    if (!defer) HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
+    launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, defer ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+                        alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+    if (defer) {
+        // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, ordered behind the main
+        // stream's last kernel of this step -- hence behind dX of d1, the last reader of the decoder's weight images, and
+        // not competing with the encoder's update above -- and joined by the next user of the decoder (join_side):
+        // it runs beside the next step's encoder forward.
+        HIPCHK(hipEventRecord(m->ev_fork3, st));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork3, 0));
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+                            m->vel, alpha, 1e-4f, 1, nullptr, 0, 0.f, nullptr, m->side);
+        HIPCHK(hipEventRecord(m->ev_dec, m->side));
+        m->dec_pending = true;
+    }
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -849,6 +886,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
+    m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
@@ -861,10 +899,18 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     }
     HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     m->own_stream = true;
-    HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    {   // the side stream carries work with slack (weight gradients, next step's noise, the deferred decoder update): lowest
+        // priority, so the main stream's dependency chain gets the CUs first whenever both have workgroups ready
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = getenv("IWAE_SIDE_PRIO_NORMAL") ? 0 : least;
+        HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
+    }
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_dec, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork3, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
         add_mlp3(m, m->dec1, "dec", m->D[0], m->H[0], m->X);
@@ -910,6 +956,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
 void iwae_destroy(iwae_handle m) {
     if (!m) return;
     (void)hipSetDevice(m->cfg.device);
+    if (m->side) (void)hipStreamSynchronize(m->side);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
@@ -942,12 +989,15 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
+    if (m->ev_fork3) (void)hipEventDestroy(m->ev_fork3);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
 
 int iwae_set_stream(iwae_handle m, void* s) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->own_stream) { HIPCHK(hipStreamDestroy(m->stream)); m->own_stream = false; }
     if (s) {
@@ -961,6 +1011,7 @@ int iwae_set_stream(iwae_handle m, void* s) {
 
 int iwae_sync(iwae_handle m) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     return IWAE_OK;
 }
@@ -988,6 +1039,7 @@ int iwae_tensor_info(iwae_handle m, int32_t idx, char* name, size_t cap, int32_t
 
 int iwae_set_params(iwae_handle m, const float* flat, size_t n) {
     if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "set_params: size mismatch");
+    CHK(join_side(m));
     HIPCHK(hipMemcpyAsync(m->param, flat, n * 4, hipMemcpyDefault, m->stream));
     CHK(refresh_images(m));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -995,12 +1047,14 @@ int iwae_set_params(iwae_handle m, const float* flat, size_t n) {
 }
 int iwae_get_params(iwae_handle m, float* flat, size_t n) {
     if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "get_params: size mismatch");
+    CHK(join_side(m));
     HIPCHK(hipMemcpyAsync(flat, m->param, n * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return IWAE_OK;
 }
 int iwae_set_output_bias(iwae_handle m, const float* bias, size_t n) {
     if (!m || !bias || n != (size_t)m->X) return fail(IWAE_ERR_ARG, "set_output_bias: need x_dim values");
+    CHK(join_side(m));
     HIPCHK(hipMemcpyAsync(m->param + m->klayers.back().offb, bias, n * 4, hipMemcpyDefault, m->stream));
     CHK(refresh_images(m));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -1008,12 +1062,14 @@ int iwae_set_output_bias(iwae_handle m, const float* bias, size_t n) {
 }
 int iwae_get_grads(iwae_handle m, float* flat, size_t n) {
     if (!m || !flat || n != m->nparam) return fail(IWAE_ERR_ARG, "get_grads: size mismatch");
+    CHK(join_side(m));
     HIPCHK(hipMemcpyAsync(flat, m->grad, n * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return IWAE_OK;
 }
 int iwae_get_adam_state(iwae_handle m, float* mo, float* ve, size_t n, int64_t* step) {
     if (!m || n != m->nparam) return fail(IWAE_ERR_ARG, "get_adam_state: size mismatch");
+    CHK(join_side(m));
     if (mo) HIPCHK(hipMemcpyAsync(mo, m->mom, n * 4, hipMemcpyDefault, m->stream));
     if (ve) HIPCHK(hipMemcpyAsync(ve, m->vel, n * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -1022,6 +1078,7 @@ int iwae_get_adam_state(iwae_handle m, float* mo, float* ve, size_t n, int64_t* 
 }
 int iwae_set_adam_state(iwae_handle m, const float* mo, const float* ve, size_t n, int64_t step) {
     if (!m || !mo || !ve || n != m->nparam || step < 0) return fail(IWAE_ERR_ARG, "set_adam_state: bad argument");
+    CHK(join_side(m));
     HIPCHK(hipMemcpyAsync(m->mom, mo, n * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipMemcpyAsync(m->vel, ve, n * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
@@ -1053,6 +1110,7 @@ int iwae_forward_backward(iwae_handle m, const float* x, int32_t B, int32_t k, f
 
 int iwae_grad_devptr(iwae_handle m, void** p, size_t* n) {
     if (!m || !p || !n) return fail(IWAE_ERR_ARG, "null argument");
+    CHK(join_side(m));
     *p = m->grad;
     *n = m->nparam;
     return IWAE_OK;
@@ -1061,6 +1119,7 @@ int iwae_grad_devptr(iwae_handle m, void** p, size_t* n) {
 int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(join_side(m));
     return adam_impl(m, lr, grad_scale);
 }
 
@@ -1117,6 +1176,7 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
 int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     if (!m || !z || !probs || n <= 0) return fail(IWAE_ERR_ARG, "decode: bad argument");
     HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(join_side(m));
     hipStream_t st = m->stream;
     const bool two = m->cfg.n_layers == 2;
     const int np = round_up(n, 128), D0 = m->D[0], Dp0 = m->Dp[0], Hp = m->dec1[0].Np32, Xp = m->Xp32;
@@ -1250,6 +1310,7 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
     if (!m || !name) return fail(IWAE_ERR_ARG, "debug_tensor: null argument");
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "debug_tensor: no forward pass yet");
     HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(join_side(m));
     struct Ent { const char* nm; int kind; const DevBuf* buf; int R; int F; int Fp; };   // kind 0: bf16 P-layout, 2: fp32
     const int B = m->B, M = m->M, Mp = m->Mp;
     const int H0 = m->H[0], Hp0 = m->Hp[0], D0 = m->D[0], Dp0 = m->Dp[0];
