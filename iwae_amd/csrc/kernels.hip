@@ -238,7 +238,7 @@ __global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ?
     constexpr bool kBiasInit = (EPI == EPI_BERN) && KTC > 0;         // accumulators start at the bias (single k-window: bias block is there)
 
     uint4 bfr[8][G];
-    auto load_b = [&](int kw) {
+    auto load_b_into = [&](int kw, uint4 (&dst)[8][G]) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
@@ -248,10 +248,14 @@ __global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ?
                     v = *(const uint4*)(a.X + (size_t)rowc[g] * a.ldX + (kw * 8 + ks) * 32 + q * 8);
                     if (!valid[g]) v = make_uint4(0, 0, 0, 0);
                 }
-                bfr[ks][g] = v;
+                dst[ks][g] = v;
             }
         }
     };
+    auto load_b = [&](int kw) { load_b_into(kw, bfr); };
+    // K > 256 (several 8-k-step windows, e.g. the 784-pixel input layer): the next window's data rows are fetched while
+    // this window's MFMAs run, instead of in front of its barrier
+    uint4 bfr_n[KTC ? 1 : 8][KTC ? 1 : G];
     auto stage = [&](int unit, int buf) {
         const int mg = mg0 + unit / nkw, kw = unit % nkw;
         const int nks = min(8, KT - kw * 8);
@@ -326,13 +330,23 @@ __global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ?
         const char* lbias = smem;
         for (int kw = 0; kw < nkw; ++kw) {
             const int unit = (mg - mg0) * nkw + kw, buf = unit & 1;
-            if (nkw > 1) load_b(kw);
+            if constexpr (KTC == 0) if (nkw > 1) {
+                if (unit == 0) {
+                    load_b(kw);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                        for (int g = 0; g < G; ++g) bfr[ks][g] = bfr_n[ks][g];
+                }
+            }
             wait_all_vmem();
             DS_STAMP(1)      // vmcnt wait
             __syncthreads();
             DS_STAMP(2)      // barrier
             const bool more = unit + 1 < nunits;
             if (!KTC && more) stage(unit + 1, buf ^ 1);
+            if constexpr (KTC == 0) { if (nkw > 1 && more) load_b_into((kw + 1) % nkw, bfr_n); }
             if (kw == 0) {
                 emit_stores();
                 if (kPre && mg + 1 < mg1) load_pre(mg + 1, pre_n);
