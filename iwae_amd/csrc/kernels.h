@@ -98,6 +98,7 @@ struct LseArgs {
 
 struct LatentBwdArgs {
     const float* dz; int ldDZ;
+    const float* dz2; const float* dz3;   // optional further terms of dz (same layout), added on load; both or neither
     const float* head; int ldH; int D, Dp;
     const float4* cf;
     EpsSrc eps;
@@ -141,7 +142,6 @@ void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
 void launch_lse(const LseArgs& a, hipStream_t st);
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st);
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
-void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st);
 // Sums the slabs of reduce blocks [first_block, first_block + nblocks) of the layer table into the flat gradient.
 // per_b != null: one extra block turns the per-image values into the batch means (scalars) of the step.
 // fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread.

@@ -1334,27 +1334,37 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 // thread per data row: sum_d log N(z1; mup[row], sigp[row]) with z1 recomputed from the encoder head
 // and eps (iwae2.py:122); also the per-row gradients wrt the dec2 head when G != null is done in
 // gauss_bwd_kernel.
-__global__ void gauss_lp_kernel(GaussLpArgs a) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= a.M) return;
-    const int b = row / a.k, s = row - b * a.k;
-    const float* hz = a.zhead + (size_t)b * a.ldZH;         // generating head (per image)
-    const float* hp = a.phead + (size_t)row * a.ldPH;        // evaluating head (per row)
+__global__ __launch_bounds__(256) void gauss_lp_kernel(GaussLpArgs a) {
+    // wave = 16 data rows x 4 quads: quad q takes feature groups d4 = q, q+4, ... (float4 loads), two shuffles add them up
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + r;
+    const bool valid = row < a.M;
+    const int rowc = valid ? row : a.M - 1;
+    const int b = rowc / a.k, s = rowc - b * a.k;
+    const float* hz = a.zhead + (size_t)b * a.ldZH;           // generating head (per image)
+    const float* hp = a.phead + (size_t)rowc * a.ldPH;        // evaluating head (per row)
     float lp = 0.0f;
-    for (int d4 = 0; d4 < (a.D + 3) / 4; ++d4) {
+    const int nd4 = (a.D + 3) / 4;
+    for (int d4 = q; d4 < nd4; d4 += 4) {
         float e[4];
-        eps4(a.eps, b, s, row, d4, a.D, e);
+        eps4(a.eps, b, s, rowc, d4, a.D, e);
+        const float4 zm = *(const float4*)(hz + 4 * d4), zs = *(const float4*)(hz + a.Dzp + 4 * d4);
+        const float4 pm = *(const float4*)(hp + 4 * d4), ps = *(const float4*)(hp + a.Dpp + 4 * d4);
+        const float zmv[4] = {zm.x, zm.y, zm.z, zm.w}, zsv[4] = {zs.x, zs.y, zs.z, zs.w};
+        const float pmv[4] = {pm.x, pm.y, pm.z, pm.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = 4 * d4 + i;
-            if (f < a.D) {
-                const float z = hz[f] + hz[a.Dzp + f] * e[i];
-                const float u = (z - hp[f]) / hp[a.Dpp + f];
-                lp += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(hp[a.Dpp + f]);
+            if (4 * d4 + i < a.D) {
+                const float z = zmv[i] + zsv[i] * e[i];
+                const float u = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
+                lp += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(psv[i]);
             }
         }
     }
-    a.out[row] = lp;
+    lp += __shfl_xor(lp, 16);
+    lp += __shfl_xor(lp, 32);
+    if (q == 0 && valid) a.out[row] = lp;
 }
 
 // one wave per image b: log_w over k, logmeanexp / softmax / objective gradients (iwae1.py:113-139)
@@ -1524,6 +1534,10 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                 const int sc = ok ? s : a.k - 1;          // clamped, weighted by 0 below
                 const int row = b * a.k + sc;
                 dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
+                if (a.dz2) {      // 2-layer model: dz1 = decoder path + direct p(z1|z2) term + path through q(z2|z1)
+                    const float4 t2 = *(const float4*)(a.dz2 + (size_t)row * a.ldDZ + f0), t3 = *(const float4*)(a.dz3 + (size_t)row * a.ldDZ + f0);
+                    dz[u] = make_float4(dz[u].x + t2.x + t3.x, dz[u].y + t2.y + t3.y, dz[u].z + t2.z + t3.z, dz[u].w + t2.w + t3.w);
+                }
                 cf[u] = a.cf[row];
                 if (!ok) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 eps4(a.eps, b, sc, row, f4, a.D, e[u]);
@@ -1585,23 +1599,31 @@ __global__ void gauss_bwd_kernel(GaussBwdArgs a) {
         const float* hp = a.head + (size_t)row * a.ldH;
         float e[4];
         eps4(a.eps, b, s, row, f4, a.D, e);
+        const float4 mu4 = *(const float4*)(hp + f0), sg4 = *(const float4*)(hp + a.Dp + f0);
+        const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;      // mode 0: generating head (per image); mode 1: dz from dec2
+        if (a.mode == 0) {
+            const float* hz = a.zhead + (size_t)b * a.ldZH;
+            a4 = *(const float4*)(hz + f0); b4 = *(const float4*)(hz + a.Dzp + f0);
+        } else {
+            a4 = *(const float4*)(a.dz_in + (size_t)row * a.ldDZ + f0);
+        }
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int f = f0 + i;
-            if (f < a.D) {
-                const float mu = hp[f], sg = hp[a.Dp + f];
+            if (f0 + i < a.D) {
+                const float mu = muv[i], sg = sgv[i], rs = __builtin_amdgcn_rcpf(sg);
                 if (a.mode == 0) {
-                    const float* hz = a.zhead + (size_t)b * a.ldZH;
-                    const float z = hz[f] + hz[a.Dzp + f] * e[i];
-                    const float u = (z - mu) / sg;
-                    dm[i] = G * u / sg;
-                    ds[i] = G * (u * u - 1.0f) / sg * (sg - 1e-6f);
-                    dzd[i] = -G * u / sg;
+                    const float z = av[i] + bv[i] * e[i];
+                    const float u = (z - mu) * rs;
+                    dm[i] = G * u * rs;
+                    ds[i] = G * (u * u - 1.0f) * rs * (sg - 1e-6f);
+                    dzd[i] = -dm[i];
                 } else {
                     const float z = mu + sg * e[i];
-                    const float d = a.dz_in[(size_t)row * a.ldDZ + f] - G * z;
+                    const float d = av[i] - G * z;
                     dm[i] = d;
-                    ds[i] = (d * e[i] + G / sg) * (sg - 1e-6f);
+                    ds[i] = (d * e[i] + G * rs) * (sg - 1e-6f);
                 }
             }
         }
@@ -1614,14 +1636,6 @@ __global__ void gauss_bwd_kernel(GaussBwdArgs a) {
 }
 
 // out[row][f] = sum of up to 3 fp32 [M][ld] arrays (dz1 contributions of the 2-layer model)
-__global__ void add3_kernel(float* out, const float* a0, const float* a1, const float* a2, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float v = a0[i];
-    if (a1) v += a1[i];
-    if (a2) v += a2[i];
-    out[i] = v;
-}
 
 // ---------------------------------------------------------------------------------
 // gradient slab reduce and Adam (+ bf16 A-image refresh)
@@ -1880,16 +1894,13 @@ void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream
     hipLaunchKernelGGL(eps_gen_kernel, grid1((size_t)M * nd4, 256), dim3(256), 0, st, e, M, nd4, ld, out);
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
-void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, grid1(a.M, 128), dim3(128), 0, st, a); }
+void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(a.Bp), dim3(256), 0, st, a);
 }
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
-}
-void launch_add3(float* out, const float* a0, const float* a1, const float* a2, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(add3_kernel, grid1(n, 256), dim3(256), 0, st, out, a0, a1, a2, n);
 }
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
                          float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {

@@ -94,7 +94,7 @@ struct iwae_model {
     bool s_mode = false;        // this step's forward kept s = x - sigmoid(l) in wdec1.dlP
     DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
-    DevBuf logw, wn, gx, cf, per_b, dzsum, dzdir;
+    DevBuf logw, wn, gx, cf, per_b, dzdir;
     BlockWs wenc1, wenc2, wdec2;
     MlpWs wdec1;
     DevBuf scratch;            // exports
@@ -725,10 +725,10 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     if (!defer) HIPCHK(hipEventRecord(m->ev_join, m->side));
 
     const float* dz1 = ptr<float>(w.dz);
+    const float *dz1_b = nullptr, *dz1_c = nullptr;
     if (two) {
         // ---- p(z1|z2) head, dec2, q(z2|z1) head, enc2
         CHK(ensure(m->dzdir, (size_t)Mp * m->Dp[0] * 4, st));
-        CHK(ensure(m->dzsum, (size_t)Mp * m->Dp[0] * 4, st));
         GaussBwdArgs g;
         memset(&g, 0, sizeof(g));
         g.mode = 0; g.G = ptr<float>(m->gx);
@@ -747,13 +747,12 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         g.DHP = ptr<uint16_t>(m->wenc2.dheadP);
         launch_gauss_bwd(g, st);
         CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true));
-        launch_add3(ptr<float>(m->dzsum), ptr<float>(w.dz), ptr<float>(m->dzdir), ptr<float>(m->wenc2.dx), (size_t)M * m->Dp[0], st);
-        dz1 = ptr<float>(m->dzsum);
+        dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
     }
     {
         LatentBwdArgs a;
         memset(&a, 0, sizeof(a));
-        a.dz = dz1; a.ldDZ = m->Dp[0];
+        a.dz = dz1; a.dz2 = dz1_b; a.dz3 = dz1_c; a.ldDZ = m->Dp[0];
         a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
         a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
         a.B = B; a.Bp = Bp; a.k = k;
@@ -960,7 +959,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
-                      &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->dzsum,
+                      &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
                       &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
@@ -1340,7 +1339,7 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
             {"dec2.h1", 0, &m->wdec2.h1P, M, H1, Hp1}, {"dec2.h2", 0, &m->wdec2.h2P, M, H1, Hp1},
             {"dec2.head", 2, &m->wdec2.head, M, 2 * Dp0, 2 * Dp0}, {"dec2.dhead", 0, &m->wdec2.dheadP, M, 2 * Dp0, 2 * Dp0},
             {"dec2.dx", 2, &m->wdec2.dx, M, Dp1, Dp1},
-            {"dz1", 2, &m->dzsum, M, Dp0, Dp0}, {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0},
+            {"dz1_direct", 2, &m->dzdir, M, Dp0, Dp0},
         };
         ents.insert(ents.end(), e2.begin(), e2.end());
     }
