@@ -120,7 +120,7 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_fork3 = nullptr, ev_join = nullptr, ev_dec = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_fork3 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
     // Single-GPU train step: the decoder's slab reduction + Adam (90 % of the slab bytes) stays on the side stream and is
     // NOT joined at the end of the step -- nothing needs the decoder's new weights before the next step's d1 layer, so it
     // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
@@ -442,13 +442,22 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx) {
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side) {
     CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
     CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
     if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
     const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
     const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
     Linear* ls[3] = {&blk[2], &blk[1], &blk[0]};
+    // The weight gradients only feed the slab reduction.  For the per-sample blocks of the 2-layer model (R = B*k rows)
+    // they go to the side stream, ordered behind this block's dX chain, so the main stream's dependency chain does not
+    // wait for them; the small encoder block (R = B) stays on the main stream (it is the tail of the step anyway).
+    hipStream_t ws = m->stream;
+    if (wgrad_on_side) {
+        HIPCHK(hipEventRecord(m->ev_blk, m->stream));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0));
+        ws = m->side;
+    }
     WgradPGroup g;
     memset(&g, 0, sizeof(g));
     int nsplit[3], nw[3];
@@ -463,9 +472,9 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
             g.gx[i] = (ls[i]->JT + 7) / 8; g.gy[i] = (ls[i]->IT + 15) / 16;
             g.zbeg[i + 1] = g.zbeg[i] + nsplit[i];
         }
-        launch_wgradp_group(g, m->stream);
+        launch_wgradp_group(g, ws);
     } else {
-        for (int i = 0; i < 3; ++i) launch_wgradp(g.a[i], nsplit[i], nw[i], m->stream);
+        for (int i = 0; i < 3; ++i) launch_wgradp(g.a[i], nsplit[i], nw[i], ws);
     }
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -721,8 +730,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
-    const bool defer = fuse && m->allow_defer && m->early_first > 0;
-    if (!defer) HIPCHK(hipEventRecord(m->ev_join, m->side));
+    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two;      // (2-layer: the main stream needs the side-stream block gradients anyway)
 
     const float* dz1 = ptr<float>(w.dz);
     const float *dz1_b = nullptr, *dz1_c = nullptr;
@@ -738,7 +746,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wdec2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true));
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true, true));
         memset(&g, 0, sizeof(g));
         g.mode = 1; g.G = ptr<float>(m->gx);
         g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
@@ -746,7 +754,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wenc2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true));
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, true));
         dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
     }
     {
@@ -760,9 +768,12 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         a.DHP = ptr<uint16_t>(m->wenc1.dheadP);
         launch_latent_bwd(a, st);
     }
-    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false));
+    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
     if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
-    if (!defer) HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));      // join: decoder weight gradients are in their slabs
+    if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
+        HIPCHK(hipEventRecord(m->ev_join, m->side));
+        HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+    }
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, defer ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                         alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     if (defer) {
@@ -910,6 +921,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_dec, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork3, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_blk, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
         add_mlp3(m, m->dec1, "dec", m->D[0], m->H[0], m->X);
@@ -990,6 +1002,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
     if (m->ev_fork3) (void)hipEventDestroy(m->ev_fork3);
+    if (m->ev_blk) (void)hipEventDestroy(m->ev_blk);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
