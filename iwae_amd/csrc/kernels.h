@@ -36,7 +36,8 @@ struct DenseArgs {
     const uint16_t* ACT; int ldACT;   // EPI_DX: stored activation of the out-features (P-layout)
     // EPI_BERN
     const uint16_t* XB; int ldXB; int k; int B; int Xdim;
-    float* lpxz; float* logits_out;
+    float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]
+    float* logits_out;
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
@@ -50,6 +51,7 @@ struct OutBwdArgs {
     int M, KT, NG;
     uint16_t* DLP;                    // dlogits, P-layout [M][Xp32] or null
     const uint16_t* SP;               // s = x - sigmoid(l) kept by the forward pass, P-layout [M][Xp32]: no recompute (else null)
+    float* part; int gpb;             // SP mode, small row counts: block row y handles gpb pixel groups, fp32 partial dg2 in part[y][M][ldG]
     uint16_t* DPP;                    // dpre of the last hidden layer, P-layout [M][32*KT]
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
 };
@@ -94,6 +96,8 @@ struct LseArgs {
     float cz_on;                         // 1: prior term -z reaches dz (1-layer); 0: 2-layer (handled per row)
     const float* head; int ldH, D, Dp;   // for KL (1-layer) or null
     float* logw; float* wn; float* gx; float4* cf; float* per_b;
+    int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
+    float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
 };
 
 struct LatentBwdArgs {

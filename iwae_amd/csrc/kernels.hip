@@ -494,7 +494,7 @@ __global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ?
             float v = rowacc[g];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (q == 0 && valid[g]) a.lpxz[row[g]] = v;
+            if (q == 0 && valid[g]) a.lpxz[(size_t)blockIdx.y * a.lpxz_stride + row[g]] = v;      // stride 0: one block owns all pixel groups
         }
     }
 #ifdef IWAE_DENSE_STAMPS
@@ -984,10 +984,13 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
                 }
             }
     };
+    // small row counts: blockIdx.y takes a slice of the pixel groups and leaves its fp32 partial sums in a.part
+    const int ng0 = a.part ? (int)blockIdx.y * a.gpb : 0;
+    const int ng1 = a.part ? min(a.NG, ng0 + a.gpb) : a.NG;
 #pragma unroll
-    for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, 0, idx);
+    for (int idx = 0; idx < NIDX; ++idx) dma_piece(ng0, ng0 & 1, idx);
     uint4 sf[2][2], sf_n[2][2];
-    load_s(0, sf);
+    load_s(ng0, sf);
 
     f32x4 acc2[MT][2];
 #pragma unroll
@@ -995,11 +998,11 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int ng = 0; ng < a.NG; ++ng) {
+    for (int ng = ng0; ng < ng1; ++ng) {
         const int buf = ng & 1;
         wait_all_vmem();
         __syncthreads();
-        const bool more = ng + 1 < a.NG;
+        const bool more = ng + 1 < ng1;
         if (more) load_s(ng + 1, sf_n);
         const char* l2 = smem + buf * unit + tr_off;
         lds_pipeline<2 * MT, 8>(
@@ -1027,6 +1030,18 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
             for (int g = 0; g < 2; ++g) sf[kk][g] = sf_n[kk][g];
     }
 
+    if (a.part) {      // partial dg2 in P order (feature position ks*32 + 8q + j), finished by out_bwd_finish_kernel
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (valid[g]) {
+                    float* dst = a.part + ((size_t)blockIdx.y * a.M + row[g]) * a.ldG + ks * 32 + 8 * q;
+                    *(float4*)dst = make_float4(acc2[2 * ks][g][0], acc2[2 * ks][g][1], acc2[2 * ks][g][2], acc2[2 * ks][g][3]);
+                    *(float4*)(dst + 4) = make_float4(acc2[2 * ks + 1][g][0], acc2[2 * ks + 1][g][1], acc2[2 * ks + 1][g][2], acc2[2 * ks + 1][g][3]);
+                }
+        return;
+    }
     // dpre2 = gx * dg2 * (1 - g2^2); the lane's 8 features of hidden k-step ks are tiles 2ks (j < 4) and 2ks+1 (j >= 4)
     float gxv[2];
 #pragma unroll
@@ -1047,6 +1062,25 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
                     make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
         }
     }
+}
+
+// dpre2 = gx * (sum of the partial dg2 slices) * (1 - g2^2), elementwise in P order: one thread per 8-feature chunk
+__global__ __launch_bounds__(256) void out_bwd_finish_kernel(OutBwdArgs a, int nparts) {
+    const int nch = a.ldG / 8;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.M * nch) return;
+    const int row = (int)(idx / nch), c = (int)(idx - (size_t)row * nch);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int y = 0; y < nparts; ++y) {
+        const float* src = a.part + ((size_t)y * a.M + row) * a.ldG + 8 * c;
+        const float4 p0 = *(const float4*)src, p1 = *(const float4*)(src + 4);
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    const uint4 y8 = *(const uint4*)(a.G2 + (size_t)row * a.ldG + 8 * c);
+    const float gx = a.gx[row];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float y = bf_at(y8, j); v[j] = gx * v[j] * (1.0f - y * y); }
+    *(uint4*)(a.DPP + (size_t)row * a.ldG + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
 }
 
 // ---------------------------------------------------------------------------------
@@ -1378,15 +1412,20 @@ __global__ void lse_kernel(LseArgs a) {
     float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
     for (int s = lane; s < k; s += 64) {
         const int r = b * k + s;
-        float lw = 0.0f;
+        float px = a.term[0][r];
+        if (a.n_px_part > 1) {      // log p(x|z) as partial sums over pixel groups (small row counts): fixed order
+            for (int i = 1; i < a.n_px_part; ++i) px += a.term[0][(size_t)i * a.px_stride + r];
+            a.term0_out[r] = px;
+        }
+        float lw = a.coef[0] * px;
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int t = 1; t < 5; ++t)
             if (a.term[t]) lw += a.coef[t] * a.term[t][r];
         a.logw[r] = lw;
         lw_reg = lw;
         m = fmaxf(m, lw);
         sum_lw += lw;
-        sum_px += a.term[0][r];
+        sum_px += px;
         if (a.term[1]) sum_t1 += a.term[1][r];
         if (a.term[2]) sum_t2 += a.term[2][r];
     }
@@ -1424,7 +1463,7 @@ __global__ void lse_kernel(LseArgs a) {
         } else {                                         // iwae_elbo, iwae_eq14 (same gradient)
             G = -wn * invB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
         }
-        if (a.lq_dreg) dreg += wn * wn * (a.term[1][r] + a.term[0][r] - a.lq_dreg[r]);   // tasks/task02.py:70-73
+        if (a.lq_dreg) dreg += wn * wn * (a.term[1][r] + a.term0_out[r] - a.lq_dreg[r]);   // tasks/task02.py:70-73 (term0_out: total log p(x|z))
         a.gx[r] = G;
         a.cf[r] = cf;
     }
@@ -1836,13 +1875,16 @@ bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     if (a.SP) {      // the forward pass kept s = x - sigmoid(l): one product, B operand from HBM
         const size_t lds = 2 * ((size_t)a.KT * 4096 + 1024);
-        dim3 grid((a.M + 127) / 128);
+        const int nparts = a.part ? (a.NG + a.gpb - 1) / a.gpb : 1;
+        dim3 grid((a.M + 127) / 128, nparts);
         switch (a.KT) {
-            case 7: hipLaunchKernelGGL(out_bwd_s_kernel<7>, grid, dim3(256), lds, st, a); return;
-            case 4: hipLaunchKernelGGL(out_bwd_s_kernel<4>, grid, dim3(256), lds, st, a); return;
-            case 2: hipLaunchKernelGGL(out_bwd_s_kernel<2>, grid, dim3(256), lds, st, a); return;
-            default: break;      // the host only asks for this mode when out_bwd_has_s_mode(KT)
+            case 7: hipLaunchKernelGGL(out_bwd_s_kernel<7>, grid, dim3(256), lds, st, a); break;
+            case 4: hipLaunchKernelGGL(out_bwd_s_kernel<4>, grid, dim3(256), lds, st, a); break;
+            case 2: hipLaunchKernelGGL(out_bwd_s_kernel<2>, grid, dim3(256), lds, st, a); break;
+            default: return;      // the host only asks for this mode when out_bwd_has_s_mode(KT)
         }
+        if (a.part) hipLaunchKernelGGL(out_bwd_finish_kernel, grid1((size_t)a.M * (a.ldG / 8), 256), dim3(256), 0, st, a, nparts);
+        return;
     }
     // pair kernel: one W^T image per pixel group, double buffered, + 4 KiB of dl exchange per pair.  Two 4-wave
     // workgroups (64 rows each) per CU instead of one 8-wave workgroup: the two are not in lockstep, so one's

@@ -91,6 +91,9 @@ struct iwae_model {
     bool have_forward = false, user_eps = false;
     unsigned dense_g1_mask = IWAE_DENSE_G1_DEFAULT;   // IWAE_DENSE_G1=<mask> (tuning aid, kernels.h)
     bool allow_s_mode = true;   // IWAE_OUT_RECOMPUTE=1 switches back to recomputing the logits in out_bwd (A/B measurements)
+    DevBuf dg2_part;            // small row counts: out_bwd_s_kernel's per-pixel-group partial sums
+    int px_parts = 1;           // > 1: log p(x|z) of this forward arrives in px_part as that many partial sums per row
+    DevBuf px_part;
     bool s_mode = false;        // this step's forward kept s = x - sigmoid(l) in wdec1.dlP
     DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
@@ -617,8 +620,17 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         a.X = ptr<uint16_t>(w.g2P); a.ldX = L.Kp32; a.img = L.imgF;
         a.split = 1 << 30;
         a.M = M; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
+        // small row counts (the reference's default B = 20, k = 5): a handful of workgroups walking all 13 pixel groups
+        // in turn is 40 us of latency -- one pixel group per block instead, log p(x|z) as per-group partial sums that
+        // lse_kernel adds up in fixed order
+        m->px_parts = 1;
+        if (M < 8192 && L.MG > 1) {
+            a.mg_per_block = 1;
+            m->px_parts = L.MG;
+            CHK(ensure(m->px_part, (size_t)L.MG * Mp * 4, st));
+        }
         a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
-        a.lpxz = lpxz;
+        a.lpxz = m->px_parts > 1 ? ptr<float>(m->px_part) : lpxz; a.lpxz_stride = m->px_parts > 1 ? (size_t)Mp : 0;
         // training step: keep s = x - sigmoid(l) for the backward pass (out_bwd_s_kernel, output-layer weight gradient)
         m->s_mode = bwd && m->allow_s_mode && out_bwd_has_s_mode(L.KT);
         if (m->s_mode) {
@@ -668,6 +680,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
+        a.n_px_part = m->px_parts; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
+        if (m->px_parts > 1) a.term[0] = ptr<float>(m->px_part);
         launch_lse(a, st);
         // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
         if (!bwd) launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
@@ -706,6 +720,11 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DPP = ptr<uint16_t>(w.d2P);
         if (m->s_mode) a.SP = ptr<uint16_t>(w.dlP);     // dlP holds s: one product, no recompute
+        if (m->s_mode && M < 8192 && L.MG > 1) {         // small row counts: one pixel group per block, partial sums + finish kernel
+            a.gpb = 1;
+            CHK(ensure(m->dg2_part, (size_t)L.MG * M * L.Kp32 * 4, st));
+            a.part = ptr<float>(m->dg2_part);
+        }
         else a.DLP = ptr<uint16_t>(w.dlP);                // recompute mode: out_bwd writes dl = gx * s there
         if (m->want_stamps && L.KT == 7) {
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
@@ -972,7 +991,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
     for (BlockWs* w : bw) {
