@@ -163,6 +163,39 @@ def test_kernel_variants_agree(gpu, monkeypatch):
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
 
 
+def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
+    """iwae_train_step leaves the decoder's slab reduction + Adam on the side stream and joins it lazily (before the next
+    sampling kernel / any parameter access): scheduling only -- 25 steps with device noise must land on exactly the
+    parameters of the run that joins at the end of every step, and reads in between must see completed updates."""
+    B, k = 96, 20
+    x = O.synthetic_binarized(B, 11)
+    P = O.init_params(1, 200, 100, 3, x_mean=O.synthetic_pixel_means())
+
+    def run(env, poke):
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        m = _model(1, 200, 100)
+        for key in env:
+            monkeypatch.delenv(key)
+        m.set_params(O.flatten_params(P))
+        for t in range(25):
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=False)
+            if poke and t % 7 == 3:
+                m.get_grads()                       # entry points in between must join the pending update first
+        out = m.get_params().copy(), m.get_adam_state()
+        m.close()
+        return out
+
+    p0, (m0, v0, t0) = run({"IWAE_NO_DEFER": "1"}, False)
+    p1, (m1, v1, t1) = run({}, False)
+    p2, _ = run({}, True)
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0, p2)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(v0, v1)
+    assert t0 == t1 == 25
+
+
 def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m = _model(2, [200, 100], [100, 50])
     x = O.synthetic_binarized(2, 1)
