@@ -51,6 +51,10 @@ typedef struct {
     uint64_t seed;             /* Philox key for the reparameterisation noise (main.py:40-41 seeds TF) */
     int32_t world_size;        /* data-parallel ranks (1 = single GPU) */
     int32_t rank;
+    int32_t cond_dim;          /* 0, or C > 0: the conditional model of tasks/task05.py:101-168 (1-layer only): the encoder
+                                  sees concat(x, y), the decoder concat(z, y), y [B, C] set with iwae_set_condition
+                                  (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
+    int32_t reserved0;
 } iwae_config;
 
 /* scalar entries of the result dict (src/iwae1.py:141-144, tasks/task02.py:78-79) and the
@@ -125,6 +129,9 @@ int iwae_forward_backward(iwae_handle h, const float* x, int32_t B, int32_t k, f
                           const float* eps, iwae_scalars* scalars, const iwae_tensors* want);
 int iwae_grad_devptr(iwae_handle h, void** dev_ptr, size_t* n);
 int iwae_adam_step(iwae_handle h, float lr, float grad_scale);      /* keras Adam(lr, epsilon=1e-4), main.py:93 */
+/* conditional model (cond_dim > 0): y [n, cond_dim] (host or device) for the NEXT forward / train step / eval_llh / decode
+ * of n images -- tasks/task05.py:108-118 (y_onehot), :185-190 (sample(z, y)).  Stays set until replaced. */
+int iwae_set_condition(iwae_handle h, const float* y, int32_t n);
 int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /* Philox counter words */
 
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images

@@ -12,7 +12,7 @@ OBJECTIVES = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "
 class Config(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_hidden", C.c_int32 * 2), ("n_latent", C.c_int32 * 2),
                 ("x_dim", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
-                ("world_size", C.c_int32), ("rank", C.c_int32)]
+                ("world_size", C.c_int32), ("rank", C.c_int32), ("cond_dim", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Scalars(C.Structure):
@@ -59,6 +59,7 @@ SYMBOLS = {
     "iwae_dataset_begin_epoch": (C.c_int, [_P, C.c_uint32, _P, C.c_int32]),
     "iwae_dataset_get_batch": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "iwae_train_step_dataset": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.POINTER(Scalars)]),
+    "iwae_set_condition": (C.c_int, [_P, _P, C.c_int32]),
     "iwae_enable_timing": (C.c_int, [_P, C.c_int32]),
     "iwae_kernel_time": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "iwae_debug_tensor": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

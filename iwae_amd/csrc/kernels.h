@@ -78,6 +78,7 @@ struct SampleArgs {
     int M, Mp, k, B;
     EpsSrc eps;
     uint16_t* ZP;
+    const float* cond; int C;         // conditional model: y [B][C] goes into features D..D+C-1 of the z rows (decoder input concat(z, y))
     float* lp_prior; float* lq; float* lq_dreg;
 };
 
@@ -137,7 +138,7 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
-void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st);
+void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st);

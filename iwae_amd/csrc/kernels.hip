@@ -1241,7 +1241,8 @@ __global__ __launch_bounds__(512, 2) void wgradp_group_kernel(WgradPGroup g) {
 // ---------------------------------------------------------------------------------
 // x fp32 [B][X] -> bf16 P-layout [B][Xp] (pads written as zero).
 // block = 64 rows (lanes) x 4 chunk-waves; a thread converts one 8-feature P chunk of one row.
-__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP) {
+// cond != null: C more features per row taken from cond [B][C] (conditional model: concat(x, y), tasks/task05.py:113).
+__global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 64 + lane;
     const int nchunk = Xp / 8;
@@ -1253,7 +1254,13 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, int B, i
         for (int h = 0; h < 2; ++h) {
             const int f0 = 32 * t + 16 * h + 4 * qq;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[4 * h + i] = (b < B && f0 + i < X) ? x[(size_t)b * X + f0 + i] : 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                const int f = f0 + i;
+                float t = 0.0f;
+                if (b < B && f < X) t = x[(size_t)b * X + f];
+                else if (b < B && f < X + C) t = cond[(size_t)b * C + (f - X)];
+                v[4 * h + i] = t;
+            }
         }
         if (b < B) *(uint4*)(XP + (size_t)b * Xp + 8 * c) = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
@@ -1338,6 +1345,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float z = 0.0f;
+                if (a.cond && f0 + i >= a.D && f0 + i < a.D + a.C) z = a.cond[(size_t)b * a.C + (f0 + i - a.D)];   // decoder input = concat(z, y)
                 if (f0 + i < a.D) {
                     const float mu = muv[i], sg = sgv[i];
                     z = mu + sg * e[i];                                  // iwae1.py:59
@@ -1921,9 +1929,9 @@ void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
         else hipLaunchKernelGGL((wgradp_kernel<8, false>), grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
     }
 }
-void launch_prep_rows(const float* x, int B, int X, int Xp, int Bp, uint16_t* XP, hipStream_t st) {
+void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st) {
     const int nchunk = Xp / 8;
-    hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, B, X, Xp, Bp, XP);
+    hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, cond, B, X, cond ? C : 0, Xp, Bp, XP);
 }
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st) {

@@ -16,7 +16,7 @@
 
 using namespace iwae;
 
-static_assert(sizeof(iwae_config) == 48 && offsetof(iwae_config, seed) == 32, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
+static_assert(sizeof(iwae_config) == 56 && offsetof(iwae_config, seed) == 32 && offsetof(iwae_config, cond_dim) == 48, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
 static_assert(sizeof(iwae_scalars) == 64 && sizeof(iwae_tensors) == 12 * sizeof(void*), "ABI struct layout");
 
 static thread_local std::string g_err;
@@ -70,6 +70,9 @@ struct MlpWs {     // decode_z_to_x applied to M rows
 struct iwae_model {
     iwae_config cfg;
     int X, Xp32;
+    int C = 0, Xinp = 0;       // conditional model: condition width; row width of the encoder input concat(x, y) (= Xp32 without)
+    DevBuf cond; int cond_n = 0;   // y [cond_n][C] fp32 for the next call (iwae_set_condition)
+    int cond_row0 = 0;         // first row of `cond` the current forward uses (eval_llh walks chunks)
     int H[2], D[2], Hp[2], Dp[2];
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -526,8 +529,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
     m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
-    const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
+    const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32, Xinp = m->Xinp;
     hipStream_t st = m->stream;
+    const float* cond = nullptr;
+    if (m->C > 0) {
+        if (from_ds) return fail(IWAE_ERR_ARG, "the conditional model takes (x, y) batches, not the resident dataset");
+        if (m->cond_row0 + B > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these images first");
+        cond = ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C;
+    }
     m->user_eps = eps != nullptr;
     // ---- the step's N(0,1) draws: normally already there (prefetched by the previous training step), else drawn now
     const bool keep_eps = !eps && (bwd || two);
@@ -541,10 +550,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     }
     if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
-    CHK(ensure(m->xP, (size_t)Bp * Xp * 2, st));
+    CHK(ensure(m->xP, (size_t)Bp * Xinp * 2, st));
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
-        launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xp, Bp, m->cfg.seed,
+        launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xinp, Bp, m->cfg.seed,
                                m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
         m->ds_start = -1;
     } else {
@@ -553,7 +562,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
             xd = ptr<float>(m->xin);
         }
-        launch_prep_rows(xd, B, X, Xp, Bp, ptr<uint16_t>(m->xP), st);
+        launch_prep_rows(xd, cond, B, X, m->C, Xinp, Bp, ptr<uint16_t>(m->xP), st);
     }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
@@ -578,6 +587,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
         s.ZP = ptr<uint16_t>(m->zP[0]);
+        s.cond = cond; s.C = m->C;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
@@ -629,7 +639,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             m->px_parts = L.MG;
             CHK(ensure(m->px_part, (size_t)L.MG * Mp * 4, st));
         }
-        a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k; a.B = B; a.Xdim = X;
+        a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xinp; a.k = k; a.B = B; a.Xdim = X;
         a.lpxz = m->px_parts > 1 ? ptr<float>(m->px_part) : lpxz; a.lpxz_stride = m->px_parts > 1 ? (size_t)Mp : 0;
         // training step: keep s = x - sigmoid(l) for the backward pass (out_bwd_s_kernel, output-layer weight gradient)
         m->s_mode = bwd && m->allow_s_mode && out_bwd_has_s_mode(L.KT);
@@ -716,7 +726,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         memset(&a, 0, sizeof(a));
         a.G2 = ptr<uint16_t>(w.g2P); a.ldG = L.Kp32; a.img1 = L.imgF; a.img2 = L.imgB;
         a.Xdim = X; a.Xp32 = Xp;
-        a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = Xp; a.k = k;
+        a.gx = ptr<float>(m->gx); a.XB = ptr<uint16_t>(m->xP); a.ldXB = m->Xinp; a.k = k;
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DPP = ptr<uint16_t>(w.d2P);
         if (m->s_mode) a.SP = ptr<uint16_t>(w.dlP);     // dlP holds s: one product, no recompute
@@ -905,6 +915,10 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         if (cfg->n_latent[i] < 1 || cfg->n_latent[i] > 128) return fail(IWAE_ERR_ARG, "n_latent must be in [1,128]");
     }
     if (cfg->x_dim < 1 || cfg->x_dim > 4096) return fail(IWAE_ERR_ARG, "x_dim must be in [1,4096]");
+    if (cfg->cond_dim < 0 || cfg->cond_dim > 64) return fail(IWAE_ERR_ARG, "cond_dim must be in [0,64]");
+    if (cfg->cond_dim > 0 && cfg->n_layers != 1) return fail(IWAE_ERR_ARG, "the conditional model is 1-layer (tasks/task05.py:101)");
+    if (cfg->cond_dim > 0 && cfg->n_latent[0] + cfg->cond_dim > round_up(cfg->n_latent[0], 32))
+        return fail(IWAE_ERR_ARG, "conditional model: n_latent + cond_dim must fit the 32-feature padding of z");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(IWAE_ERR_HIP, "no HIP device: the IWAE hot path needs an AMD GPU (there is no CPU fallback)");
@@ -913,8 +927,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->cfg = *cfg;
     if (const char* e = getenv("IWAE_DENSE_STAMPS")) sscanf(e, "%d:%d", &m->dstamp_epi, &m->dstamp_kt);
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
-    if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
+    if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
@@ -922,6 +936,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
 
     m->X = cfg->x_dim;
     m->Xp32 = round_up(cfg->x_dim, 32);
+    m->C = cfg->cond_dim;
+    m->Xinp = round_up(cfg->x_dim + cfg->cond_dim, 32);
     for (int i = 0; i < 2; ++i) {
         m->H[i] = cfg->n_hidden[i]; m->D[i] = cfg->n_latent[i];
         m->Hp[i] = round_up(std::max(1, m->H[i]), 32); m->Dp[i] = round_up(std::max(1, m->D[i]), 32);
@@ -942,8 +958,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork3, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_blk, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
-        add_block(m, m->enc1, "enc", m->X, m->H[0], m->D[0], false);
-        add_mlp3(m, m->dec1, "dec", m->D[0], m->H[0], m->X);
+        add_block(m, m->enc1, "enc", m->X + m->C, m->H[0], m->D[0], false);      // tasks/task05.py:113-118 when C > 0
+        add_mlp3(m, m->dec1, "dec", m->D[0] + m->C, m->H[0], m->X);
     } else {
         add_block(m, m->enc1, "enc1", m->X, m->H[0], m->D[0], false);
         add_block(m, m->enc2, "enc2", m->D[0], m->H[1], m->D[1], true);
@@ -991,7 +1007,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
     for (BlockWs* w : bw) {
@@ -1172,6 +1188,16 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     return IWAE_OK;
 }
 
+int iwae_set_condition(iwae_handle m, const float* y, int32_t n) {
+    if (!m || !y || n <= 0) return fail(IWAE_ERR_ARG, "set_condition: bad argument");
+    if (m->C <= 0) return fail(IWAE_ERR_STATE, "set_condition: the model was created with cond_dim = 0");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(copy_in(m, m->cond, y, (size_t)n * m->C * 4));
+    HIPCHK(hipStreamSynchronize(m->stream));       // y may be a temporary of the caller
+    m->cond_n = n;
+    return IWAE_OK;
+}
+
 int iwae_set_step(iwae_handle m, uint32_t noise_step, uint32_t batch_offset) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     m->noise_step = noise_step;
@@ -1190,7 +1216,10 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
     for (int i0 = 0; i0 < N; i0 += chunk) {
         const int nb = std::min(chunk, N - i0);
         m->batch_offset = saved_off + (uint32_t)i0;
-        CHK(forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr));
+        m->cond_row0 = i0;
+        const int rc_fwd = forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
+        m->cond_row0 = 0;
+        if (rc_fwd != IWAE_OK) { m->batch_offset = saved_off; return rc_fwd; }
         HIPCHK(hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
         for (int i = 0; i < nb; ++i) {
@@ -1221,7 +1250,7 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
     if (two) {
         // src/iwae2.py:184-196: pz1z2 = decode_z2_to_z1(z2); z1 = pz1z2.sample(); logits = decode_z1_to_x(z1)
         CHK(ensure(m->zP[1], (size_t)np * Dinp * 2, st));
-        launch_prep_rows(ptr<float>(m->xin), n, Din, Dinp, np, ptr<uint16_t>(m->zP[1]), st);
+        launch_prep_rows(ptr<float>(m->xin), nullptr, n, Din, 0, Dinp, np, ptr<uint16_t>(m->zP[1]), st);
         CHK(block_alloc(m, m->dec2, m->wdec2, n, np, false, false));
         CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), n));
         for (int i = 0; i < 2; ++i) CHK(ensure(m->rows[i], (size_t)np * 4, st));
@@ -1235,7 +1264,8 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
         launch_sample(s, st);
         m->noise_step += 1;
     } else {
-        launch_prep_rows(ptr<float>(m->xin), n, D0, Dp0, np, ptr<uint16_t>(m->zP[0]), st);
+        if (m->C > 0 && n > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these rows first");
+        launch_prep_rows(ptr<float>(m->xin), m->C > 0 ? ptr<float>(m->cond) : nullptr, n, D0, m->C, Dp0, np, ptr<uint16_t>(m->zP[0]), st);
     }
     CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, ptr<uint16_t>(w.g1P), nullptr, 0));
     CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, ptr<uint16_t>(w.g2P), nullptr, 0));
@@ -1346,7 +1376,7 @@ int iwae_debug_tensor(iwae_handle m, const char* name, float* out, size_t cap, i
     const int B = m->B, M = m->M, Mp = m->Mp;
     const int H0 = m->H[0], Hp0 = m->Hp[0], D0 = m->D[0], Dp0 = m->Dp[0];
     std::vector<Ent> ents = {
-        {"x", 0, &m->xP, B, m->X, m->Xp32},
+        {"x", 0, &m->xP, B, m->X, m->Xinp},
         {"enc.h1", 0, &m->wenc1.h1P, B, H0, Hp0},
         {"enc.h2", 0, &m->wenc1.h2P, B, H0, Hp0},
         {"enc.head", 2, &m->wenc1.head, B, 2 * Dp0, 2 * Dp0},

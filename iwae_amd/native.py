@@ -18,7 +18,7 @@ def _f32(a):
 
 
 class NativeModel:
-    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0):
+    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0):
         self.lib = _capi.load()
         cfg = Config()
         cfg.n_layers = int(n_layers)
@@ -29,6 +29,8 @@ class NativeModel:
             cfg.n_latent[i] = int(nl[i]) if i < len(nl) else 0
         cfg.x_dim, cfg.device, cfg.seed = int(x_dim), int(device), int(seed)
         cfg.world_size, cfg.rank = int(world_size), int(rank)
+        cfg.cond_dim = int(cond_dim)
+        self.cond_dim = int(cond_dim)
         self.n_layers, self.x_dim = cfg.n_layers, cfg.x_dim
         self.n_hidden, self.n_latent = nh[:cfg.n_layers], nl[:cfg.n_layers]
         h = C.c_void_p()
@@ -98,6 +100,11 @@ class NativeModel:
 
     def set_stream(self, stream_ptr):
         check(self.lib.iwae_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_condition(self, y):
+        """Conditional model (cond_dim > 0): y [n, cond_dim] float32 for the next forward / train step / eval_llh / decode."""
+        y = _f32(y).reshape(-1, self.cond_dim)
+        check(self.lib.iwae_set_condition(self.h, y.ctypes.data, y.shape[0]))
 
     def set_step(self, noise_step, batch_offset=0):
         check(self.lib.iwae_set_step(self.h, int(noise_step), int(batch_offset)))

@@ -45,16 +45,18 @@ def _id(a):
 # --------------------------------------------------------------------------
 # parameters (Keras trainable_weights creation order, SURVEY.md 2d)
 # --------------------------------------------------------------------------
-def layer_shapes(n_layers, n_hidden, n_latent, x_dim=784):
+def layer_shapes(n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0):
     """[(name, (in, out))] for every Dense, in Keras creation order.
+    cond_dim > 0 (1-layer only): the conditional model of tasks/task05.py, encoder input x_dim + cond_dim,
+    decoder input n_latent + cond_dim.
 
     1-layer: iwae1.py:31-34 (BasicBlock), :72-75 (decoder).
     2-layer: iwae2.py:55-56 (two encoder blocks), :77-87 (decoder block + MLP).
     """
     if n_layers == 1:
         H, D = int(n_hidden), int(n_latent)
-        return [("enc.l1", (x_dim, H)), ("enc.l2", (H, H)), ("enc.lmu", (H, D)), ("enc.lstd", (H, D)),
-                ("dec.d1", (D, H)), ("dec.d2", (H, H)), ("dec.out", (H, x_dim))]
+        return [("enc.l1", (x_dim + cond_dim, H)), ("enc.l2", (H, H)), ("enc.lmu", (H, D)), ("enc.lstd", (H, D)),
+                ("dec.d1", (D + cond_dim, H)), ("dec.d2", (H, H)), ("dec.out", (H, x_dim))]
     H1, H2 = int(n_hidden[0]), int(n_hidden[1])
     D1, D2 = int(n_latent[0]), int(n_latent[1])
     return [("enc1.l1", (x_dim, H1)), ("enc1.l2", (H1, H1)), ("enc1.lmu", (H1, D1)), ("enc1.lstd", (H1, D1)),
@@ -69,13 +71,13 @@ def output_bias_from_mean(train_mean):
     return -np.log(1.0 / m - 1.0)
 
 
-def init_params(n_layers, n_hidden, n_latent, seed, x_mean=None, x_dim=784):
+def init_params(n_layers, n_hidden, n_latent, seed, x_mean=None, x_dim=784, cond_dim=0):
     """Keras Dense defaults: glorot-uniform kernel, zero bias; final decoder bias
     from the data mean (iwae1.py:74-75, utils.py:11-23).  Returns list of
     (W [in,out], b [out]) float64."""
     rng = np.random.default_rng(seed)
     params = []
-    shapes = layer_shapes(n_layers, n_hidden, n_latent, x_dim)
+    shapes = layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim)
     for idx, (_, (fi, fo)) in enumerate(shapes):
         lim = np.sqrt(6.0 / (fi + fo))
         W = rng.uniform(-lim, lim, size=(fi, fo))
@@ -90,9 +92,9 @@ def flatten_params(params):
     return np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in params])
 
 
-def unflatten_params(flat, n_layers, n_hidden, n_latent, x_dim=784):
+def unflatten_params(flat, n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0):
     out, o = [], 0
-    for _, (fi, fo) in layer_shapes(n_layers, n_hidden, n_latent, x_dim):
+    for _, (fi, fo) in layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim):
         W = np.asarray(flat[o:o + fi * fo], dtype=np.float64).reshape(fi, fo); o += fi * fo
         b = np.asarray(flat[o:o + fo], dtype=np.float64).copy(); o += fo
         out.append((W, b))
@@ -223,18 +225,27 @@ def _weights_over_k(log_w):
 # --------------------------------------------------------------------------
 # 1-layer model: iwae1.py:98-151 (+ DReG: tasks/task02.py:34-85)
 # --------------------------------------------------------------------------
-def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None):
+def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None, y=None):
     """x [B,X] in {0,1}; eps [k,B,D] ~ N(0,1) (the draw of qzx.sample, iwae1.py:59).
-    Returns the reference's result dict (iwae1.py:141-151) as float64 arrays."""
+    Returns the reference's result dict (iwae1.py:141-151) as float64 arrays.
+    y [B,C] (optional): the conditional model of tasks/task05.py:108-122 -- the encoder sees concat(x, y), the
+    decoder concat(z, y) (y one-hot there; any float condition here), prior N(0,1), likelihood over x only."""
     rnd = rnd or _id
     x = np.asarray(x, dtype=np.float64)
     eps = np.asarray(eps, dtype=np.float64)
     k, B, D = eps.shape
     enc = _Block(params[0:4], rnd)
     dec = _MLP3(params[4:7], rnd)
-    mu, sigma = enc.fwd(rnd(x))                       # iwae1.py:57
+    if y is None:
+        mu, sigma = enc.fwd(rnd(x))                   # iwae1.py:57
+    else:
+        y = np.asarray(y, dtype=np.float64)
+        mu, sigma = enc.fwd(rnd(np.concatenate([x, y], axis=-1)))                     # task05.py:113-114
     z = mu[None] + sigma[None] * eps                  # iwae1.py:59 (reparameterised sample)
-    logits = dec.fwd(rnd(z))                          # iwae1.py:81
+    if y is None:
+        logits = dec.fwd(rnd(z))                      # iwae1.py:81
+    else:
+        logits = dec.fwd(rnd(np.concatenate([z, np.broadcast_to(y[None], (k, B, y.shape[-1]))], axis=-1)))   # task05.py:117-118
     lpz = np.sum(normal_log_prob(z, 0.0, 1.0), axis=-1)            # :107
     lqzx = np.sum(normal_log_prob(z, mu[None], sigma[None]), axis=-1)  # :109
     lpxz = np.sum(bernoulli_log_prob(x[None], logits), axis=-1)    # :111
@@ -261,14 +272,14 @@ def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None):
     return res
 
 
-def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None, tape=None):
+def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None, tape=None, y=None):
     """Closed-form gradient of loss = -res[objective] (iwae1.py:155-159) w.r.t. the
     14 tensors; objective "dreg" = tasks/task02.py:87-101 (encoder <- inference_loss,
     decoder <- -iwae_elbo).  Returns (res, [(dW, db)...])."""
     rnd = rnd or _id
     tape = {} if tape is None else tape
     dreg = objective == "dreg"
-    res = forward_1layer(params, x, eps, beta, rnd, dreg=dreg, _tape=tape)
+    res = forward_1layer(params, x, eps, beta, rnd, dreg=dreg, _tape=tape, y=y)
     enc, dec = tape["enc"], tape["dec"]
     mu, sigma, z, wn, xx = tape["mu"], tape["sigma"], tape["z"], tape["wn"], tape["x"]
     k, B = tape["k"], tape["B"]
@@ -284,7 +295,7 @@ def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None,
     else:
         raise KeyError(objective)         # iwae1.py:157 raises KeyError for unknown keys
     dlogits = G[:, :, None] * (xx[None] - p)          # d lpxz / d logits = x - sigmoid(l)
-    dz_dec = dec.bwd(dlogits)
+    dz_dec = dec.bwd(dlogits)[..., :z.shape[-1]]     # conditional model: the decoder input is concat(z, y)
     tape.update(G=G, dz_dec=dz_dec)
     if objective == "dreg":
         # encoder gets d inference_loss; decoder backward is linear in the row weight

@@ -41,10 +41,11 @@ def _mlp3(p3, z):
     return torch.tanh(torch.tanh(z @ W1 + b1) @ W2 + b2) @ W3 + b3
 
 
-def forward_1layer(params, x, eps, beta=1.0, dreg=False):
-    mu, sigma = _block(params[0:4], x)
+def forward_1layer(params, x, eps, beta=1.0, dreg=False, y=None):
+    """y [B,C]: conditional model of tasks/task05.py:108-122 (encoder on concat(x,y), decoder on concat(z,y))."""
+    mu, sigma = _block(params[0:4], x if y is None else torch.cat([x, y], dim=-1))
     z = mu.unsqueeze(0) + sigma.unsqueeze(0) * eps
-    logits = _mlp3(params[4:7], z)
+    logits = _mlp3(params[4:7], z if y is None else torch.cat([z, y.unsqueeze(0).expand(z.shape[0], -1, -1)], dim=-1))
     lpz = _normal_lp(z, torch.zeros((), dtype=z.dtype), torch.ones((), dtype=z.dtype)).sum(-1)
     lqzx = _normal_lp(z, mu.unsqueeze(0), sigma.unsqueeze(0)).sum(-1)
     lpxz = _bern_lp(x.unsqueeze(0), logits).sum(-1)
@@ -107,7 +108,7 @@ def to_torch_params(params_np, dtype=torch.float64, requires_grad=True):
     return out
 
 
-def loss_grads(params_np, x, eps, beta=1.0, objective="iwae_elbo", n_layers=1, dtype=torch.float64):
+def loss_grads(params_np, x, eps, beta=1.0, objective="iwae_elbo", n_layers=1, dtype=torch.float64, y=None):
     """autograd gradient of the reference's loss; eps is eps (1-layer) or (eps1, eps2)."""
     P = to_torch_params(params_np, dtype)
     xt = torch.tensor(x, dtype=dtype)
@@ -122,7 +123,7 @@ def loss_grads(params_np, x, eps, beta=1.0, objective="iwae_elbo", n_layers=1, d
             gd = torch.autograd.grad(-res["iwae_elbo"], dec)                           # task02.py:96
             g = list(ge) + list(gd)
         else:
-            res = forward_1layer(P, xt, e, beta)
+            res = forward_1layer(P, xt, e, beta, y=None if y is None else torch.tensor(y, dtype=dtype))
             g = torch.autograd.grad(-res[objective], flatP)
     else:
         e1 = torch.tensor(eps[0], dtype=dtype)

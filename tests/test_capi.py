@@ -37,7 +37,8 @@ def test_binding_table_covers_header(lib_built):
 
 def test_struct_layouts_match_header():
     from iwae_amd import _capi
-    assert C.sizeof(_capi.Config) == 48          # 7 int32 (+4 pad) + uint64 + 2 int32; static_assert'ed in model.hip
+    assert C.sizeof(_capi.Config) == 56          # 7 int32 (+4 pad) + uint64 + 4 int32; static_assert'ed in model.hip
+    assert _capi.Config.cond_dim.offset == 48
     assert _capi.Config.seed.offset == 32
     assert C.sizeof(_capi.Scalars) == 64
     assert C.sizeof(_capi.Tensors) == 12 * C.sizeof(C.c_void_p)

@@ -196,6 +196,48 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
     assert t0 == t1 == 25
 
 
+@pytest.mark.parametrize("B,k,obj,nh,nl,xd", [(6, 5, "iwae_elbo", 200, 100, 784), (9, 3, "vae_elbo_kl", 64, 20, 48), (170, 50, "iwae_elbo", 200, 100, 784)])
+def test_conditional_model_matches_oracle(gpu, B, k, obj, nh, nl, xd):
+    """tasks/task05.py:101-168 (CIWAE): encoder on concat(x, onehot(y)), decoder on concat(z, onehot(y)); the condition
+    travels through iwae_set_condition.  Small and large row counts (both kernel families)."""
+    from iwae_amd.native import NativeModel
+    C = 10
+    rng = np.random.default_rng(B * 7 + k)
+    x = O.synthetic_binarized(B, 31, x_dim=xd)
+    y = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+    eps = rng.standard_normal((k, B, nl)).astype(np.float32)
+    P = O.init_params(1, nh, nl, 17, x_mean=O.synthetic_pixel_means(xd), x_dim=xd, cond_dim=C)
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, obj, rnd=O.bf16_round, y=y)
+    m = NativeModel(1, nh, nl, x_dim=xd, seed=123, cond_dim=C)
+    assert m.n_params == sum(W.size + b.size for W, b in P)
+    m.set_params(O.flatten_params(P))
+    with pytest.raises(RuntimeError):
+        m.forward_backward(x, k, 1.0, obj, eps=eps)            # no condition set yet: fails loudly
+    m.set_condition(y)
+    r = m.forward_backward(x, k, 1.0, obj, eps=eps, want=("lpxz", "lqzx", "lpz"))
+    for key in ("lpxz", "lqzx", "lpz"):
+        assert np.max(np.abs(r[key] - res_e[key])) < EMU_ROW_ATOL, key
+    for key in ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14"):
+        assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
+    # sample(z, y) (tasks/task05.py:185-198): decoder on concat(z, y)
+    n = 7
+    z = rng.standard_normal((n, nl)).astype(np.float32)
+    yz = np.eye(C, dtype=np.float32)[np.full(n, 3)]
+    m.set_condition(yz)
+    dec = O._MLP3(P[4:7], O.bf16_round)
+    ref = O.sigmoid(dec.fwd(O.bf16_round(np.concatenate([z, yz], axis=-1).astype(np.float64))))
+    assert np.max(np.abs(m.decode(z) - ref)) < 2e-2
+    # the k = 64 likelihood estimate walks the condition rows chunk by chunk
+    m.set_condition(y)
+    m.set_step(5, 0)
+    a = m.eval_llh(x[:B], k=64, chunk=0)
+    m.set_step(5, 0)                                      # same noise keys: only the chunking differs
+    b2 = m.eval_llh(x[:B], k=64, chunk=max(1, B // 3))
+    assert abs(a - b2) < 1e-3
+    m.close()
+
+
 def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m = _model(2, [200, 100], [100, 50])
     x = O.synthetic_binarized(2, 1)

@@ -67,6 +67,36 @@ def test_iwae2_and_dreg_api(gpu):
     assert "inference_loss" in r and "iwae_elbo" in r and "vae_elbo" not in r    # tasks/task02.py:78-85
 
 
+def test_task05_ciwae_api(gpu):
+    """tasks/task05.py:101-198: CIWAE(n_hidden, n_latent); call / train_step / val_step take (x, y, ...), sample(z, label)."""
+    from iwae_amd import task05, utils
+    from iwae_amd.optimizers import Adam
+    np.random.seed(1)
+    model = task05.CIWAE(200, 100, output_bias=utils.bias_from_mean(utils.synthetic_pixel_means()))
+    w = model.trainable_weights
+    assert len(w) == 14 and w[0].shape == (794, 200) and w[8].shape == (110, 200) and w[12].shape == (200, 784)
+    x = O.synthetic_binarized(20, 2)
+    y = np.arange(20) % 10
+    opt = Adam(1e-3, epsilon=1e-4)
+    first = None
+    for _ in range(30):
+        res = model.train_step(x, y, 5, 1.0, opt, objective="iwae_elbo")
+        first = float(res["iwae_elbo"]) if first is None else first
+    for key in ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14", "al", "lpxzy", "lpz", "lqzxy"):      # tasks/task05.py:156-166
+        assert key in res, key
+    assert float(res["iwae_elbo"]) > first + 1.0                                   # it trains
+    v = model.val_step(x, y, 5, 1.0)
+    assert np.isfinite(float(v["iwae_elbo"]))
+    # the label matters: a wrong condition scores the same images differently
+    v2 = model(x, (y + 3) % 10, 5)
+    assert abs(float(v2["iwae_elbo"]) - float(v["iwae_elbo"])) > 1e-3
+    xs, probs = model.sample(np.random.randn(6, 100).astype(np.float32), 7)
+    assert xs.shape == (6, 784) and probs.shape == (6, 784) and 0.0 <= probs.min() and probs.max() <= 1.0
+    assert set(np.unique(xs)) <= {0.0, 1.0}
+    with pytest.raises(NotImplementedError):
+        model.set_dataset(x)
+
+
 def test_main_runs_one_epoch(gpu, monkeypatch, capsys):
     """main.py end to end on a tiny synthetic set (the reference's loop structure, flags and final print)."""
     import importlib

@@ -133,3 +133,25 @@ def test_device_binarize_restatement_is_bernoulli_of_grey_level():
     np.testing.assert_array_equal(x, philox_np.device_binarize(123, 3, g, np.arange(400)))      # deterministic
     assert (x != philox_np.device_binarize(123, 4, g, np.arange(400))).mean() > 0.2                 # new epoch, new draw
     np.testing.assert_array_equal(x[[7, 2]], philox_np.device_binarize(123, 3, g, [7, 2]))       # keyed by image id
+
+
+def test_conditional_model_closed_form_matches_autograd():
+    """tasks/task05.py:108-122: encoder on concat(x, y), decoder on concat(z, y).  The closed-form backward of the NumPy
+    oracle against torch autograd of the op-for-op forward."""
+    from oracle import iwae_torch as T
+    rng = np.random.default_rng(4)
+    B, k, X, H, D, C = 5, 4, 48, 16, 6, 10
+    P = O.init_params(1, H, D, 3, x_dim=X, cond_dim=C)
+    assert P[0][0].shape == (X + C, H) and P[4][0].shape == (D + C, H)
+    x = (rng.random((B, X)) < 0.3).astype(np.float64)
+    y = np.eye(C)[rng.integers(0, C, B)]
+    eps = rng.standard_normal((k, B, D))
+    for obj in ("iwae_elbo", "vae_elbo", "vae_elbo_kl", "iwae_eq14"):
+        res, g = O.loss_grads_1layer(P, x, eps, 0.8, obj, y=y)
+        rt, gt = T.loss_grads(P, x, eps, 0.8, obj, y=y)
+        assert abs(res[obj] - rt[obj]) < 1e-12
+        for (a, b), (c, d) in zip(g, gt):
+            assert np.max(np.abs(a - c)) < 1e-12 and np.max(np.abs(b - d)) < 1e-12
+    # without y the shapes are the unconditional ones and the condition is ignored everywhere
+    P0 = O.init_params(1, H, D, 3, x_dim=X)
+    assert P0[0][0].shape == (X, H) and P0[4][0].shape == (D, H)
