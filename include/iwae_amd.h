@@ -54,7 +54,8 @@ typedef struct {
     int32_t cond_dim;          /* 0, or C > 0: the conditional model of tasks/task05.py:101-168 (1-layer only): the encoder
                                   sees concat(x, y), the decoder concat(z, y), y [B, C] set with iwae_set_condition
                                   (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
-    int32_t reserved0;
+    int32_t cond_prior;        /* with cond_dim > 0: 1 = the learned conditional prior p(z|y) of tasks/task04.py:101-173 (a BasicBlock on y,
+                                  created after the decoder) replaces N(0,1) in lpz; sample(z, y) maps z through it (:190-196) */
 } iwae_config;
 
 /* scalar entries of the result dict (src/iwae1.py:141-144, tasks/task02.py:78-79) and the

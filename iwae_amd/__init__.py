@@ -7,6 +7,7 @@ Layout (only what the hot path needs):
   iwae1.py     reference API of src/iwae1.py   (IWAE, train_step, val_step, sample)
   iwae2.py     reference API of src/iwae2.py   (2 stochastic layers)
   task02.py    reference API of tasks/task02.py (IWAEDReG)
+  task04.py    reference API of tasks/task04.py (CIWAE with the learned conditional prior p(z|y))
   task05.py    reference API of tasks/task05.py (CIWAE: encoder on concat(x, y), decoder on concat(z, y))
   optimizers.py  the keras.optimizers.Adam surface main.py uses
   utils.py     logmeanexp / bernoullisample / MyMetric / get_bias (src/utils.py)

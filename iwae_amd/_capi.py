@@ -12,7 +12,7 @@ OBJECTIVES = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "
 class Config(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("n_hidden", C.c_int32 * 2), ("n_latent", C.c_int32 * 2),
                 ("x_dim", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
-                ("world_size", C.c_int32), ("rank", C.c_int32), ("cond_dim", C.c_int32), ("reserved0", C.c_int32)]
+                ("world_size", C.c_int32), ("rank", C.c_int32), ("cond_dim", C.c_int32), ("cond_prior", C.c_int32)]
 
 
 class Scalars(C.Structure):

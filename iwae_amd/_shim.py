@@ -46,8 +46,9 @@ class BaseIWAE:
     n_layers = 1
     scalar_keys = ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14")
 
-    def __init__(self, n_hidden, n_latent, x_dim=784, seed=123, device=0, output_bias=None, cond_dim=0, **kwargs):
-        self._net = NativeModel(self.n_layers, n_hidden, n_latent, x_dim=x_dim, device=device, seed=seed, cond_dim=cond_dim)
+    def __init__(self, n_hidden, n_latent, x_dim=784, seed=123, device=0, output_bias=None, cond_dim=0, cond_prior=False, **kwargs):
+        self._net = NativeModel(self.n_layers, n_hidden, n_latent, x_dim=x_dim, device=device, seed=seed, cond_dim=cond_dim,
+                                cond_prior=cond_prior)
         if output_bias is not None:
             self._net.set_output_bias(output_bias)
         self._table = self._net.tensor_table()

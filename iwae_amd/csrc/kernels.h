@@ -78,6 +78,7 @@ struct SampleArgs {
     int M, Mp, k, B;
     EpsSrc eps;
     uint16_t* ZP;
+    const float* prior_head;          // conditional prior: per-image head [B][ldH] (mu_p | sigma_p) scoring z, or null = N(0,1)
     const float* cond; int C;         // conditional model: y [B][C] goes into features D..D+C-1 of the z rows (decoder input concat(z, y))
     float* lp_prior; float* lq; float* lq_dreg;
 };
@@ -110,6 +111,8 @@ struct LatentBwdArgs {
     int B, Bp, k;
     float kmu, ksig;
     uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp]
+    const float* prior_head;          // conditional prior p(z|y) (tasks/task04.py:124-130): per-image head [B][ldH] like `head`, or null = N(0,1)
+    uint16_t* DHP2;                   // its dhead, P-layout [B][2Dp] (written when prior_head != null)
 };
 
 struct GaussBwdArgs {

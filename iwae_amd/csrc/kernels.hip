@@ -1336,12 +1336,18 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             const int f0 = 32 * t + 16 * h + 4 * q;
             float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float4 mu4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sg4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            float4 pm4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ps4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);     // prior: N(0,1) unless a head is given
             if (f0 < a.D) {
                 eps4(a.eps, b, s, rowc, f0 >> 2, a.D, e);
                 mu4 = *(const float4*)(hd + f0);
                 sg4 = *(const float4*)(hd + a.Dp + f0);
+                if (a.prior_head) {      // learned conditional prior p(z|y) of tasks/task04.py:124-130, one head per image
+                    pm4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + f0);
+                    ps4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + a.Dp + f0);
+                }
             }
             const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+            const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float z = 0.0f;
@@ -1349,7 +1355,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 if (f0 + i < a.D) {
                     const float mu = muv[i], sg = sgv[i];
                     z = mu + sg * e[i];                                  // iwae1.py:59
-                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;               // iwae1.py:107
+                    if (a.prior_head) {
+                        const float up = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
+                        lp += -0.5f * up * up - 0.5f * LOG2PI_F - __logf(psv[i]);   // task04.py:130
+                    } else {
+                        lp += -0.5f * z * z - 0.5f * LOG2PI_F;           // iwae1.py:107
+                    }
                     const float u = (z - mu) * __builtin_amdgcn_rcpf(sg);
                     lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
                     if (a.lq_dreg) {                                     // tasks/task02.py:63-65
@@ -1545,6 +1556,7 @@ __global__ __launch_bounds__(256) void scalars_kernel(const float* per_b, int B,
 //   dz_tot = ca*dz_dec + cz*z + cq*(z-mu)/(sigma+1e-6)^2
 //   dmu = sum_s dz_tot + kmu*mu ; dsigma = sum_s (dz_tot*eps + cs/sigma) + ksig*(sigma - 1/sigma)
 //   da = dsigma * exp(a) = dsigma * (sigma - 1e-6)
+__device__ __forceinline__ float sigp_of(const LatentBwdArgs& a, int b, int f) { return a.prior_head[(size_t)b * a.ldH + a.Dp + f]; }
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
     __shared__ float red[256][8];
     const int nf4 = a.Dp / 4;              // <= 32
@@ -1552,7 +1564,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
     const int f4 = threadIdx.x % nf4, sg = threadIdx.x / nf4;
     const int b = blockIdx.x;
     const int f0 = 4 * f4;
-    float dmu[4] = {0, 0, 0, 0}, dsg[4] = {0, 0, 0, 0};
+    float dmu[4] = {0, 0, 0, 0}, dsg[4] = {0, 0, 0, 0}, dpm[4] = {0, 0, 0, 0}, dps[4] = {0, 0, 0, 0};
     float mu[4] = {0, 0, 0, 0}, sgm[4] = {1, 1, 1, 1};
     const bool act = b < a.B && f0 < a.D && sg < SG;
     if (act) {
@@ -1563,11 +1575,16 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             sgm[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
         }
         float rs2[4], rsg[4];
+        float pmu[4] = {0, 0, 0, 0}, prs[4] = {1, 1, 1, 1};       // prior mean and 1/sigma_p (N(0,1) unless a head is given)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float s2 = sgm[i] + 1e-6f;
             rs2[i] = 1.0f / (s2 * s2);
             rsg[i] = 1.0f / sgm[i];
+            if (a.prior_head && f0 + i < a.D) {
+                pmu[i] = a.prior_head[(size_t)b * a.ldH + f0 + i];
+                prs[i] = 1.0f / a.prior_head[(size_t)b * a.ldH + a.Dp + f0 + i];
+            }
         }
         // the sample loop is latency-bound (3 dependent-free loads, little math): keep UN iterations' loads in flight
         constexpr int UN = 4;
@@ -1596,9 +1613,13 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                 for (int i = 0; i < 4; ++i) {
                     if (f0 + i < a.D) {
                         const float z = mu[i] + sgm[i] * e[u][i];
-                        const float t = cf[u].x * dzv[i] + cf[u].y * z + cf[u].z * (z - mu[i]) * rs2[i];
+                        const float up = (z - pmu[i]) * prs[i];                 // (z - mu_p)/sigma_p; = z for the N(0,1) prior
+                        const float t = cf[u].x * dzv[i] + cf[u].y * up * prs[i] + cf[u].z * (z - mu[i]) * rs2[i];
                         dmu[i] += t;
                         dsg[i] += t * e[u][i] + cf[u].w * rsg[i];
+                        // cf.y = -dLoss/dlpz: gradient of the prior head (task04.py:124-130), summed over the image's samples
+                        dpm[i] -= cf[u].y * up * prs[i];
+                        dps[i] -= cf[u].y * (up * up - 1.0f) * prs[i];
                     }
                 }
             }
@@ -1607,8 +1628,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = dmu[i]; red[threadIdx.x][4 + i] = dsg[i]; }
     __syncthreads();
-    if (sg != 0) return;
-    if (act) {
+    if (sg == 0 && act) {
         for (int g = 1; g < SG; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { dmu[i] += red[g * nf4 + f4][i]; dsg[i] += red[g * nf4 + f4][4 + i]; }
@@ -1621,10 +1641,29 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
         }
     }
-    if (b < a.B) {
+    if (sg == 0 && b < a.B) {
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
         *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
     }
+    if (!a.prior_head) return;       // block-uniform
+    // same reduction for the conditional prior's head: d/dmu_p, d/dsigma_p -> pre-activation of exp (sigma_p - 1e-6)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = dpm[i]; red[threadIdx.x][4 + i] = dps[i]; }
+    __syncthreads();
+    if (sg != 0 || b >= a.B) return;
+    if (act) {
+        for (int g = 1; g < SG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dpm[i] += red[g * nf4 + f4][i]; dps[i] += red[g * nf4 + f4][4 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (f0 + i < a.D) dps[i] *= (sigp_of(a, b, f0 + i) - 1e-6f);
+            else { dpm[i] = 0.0f; dps[i] = 0.0f; }
+        }
+    }
+    *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dpm[0], dpm[1]), pack2(dpm[2], dpm[3]));
+    *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dps[0], dps[1]), pack2(dps[2], dps[3]));
 }
 
 // per data row and 4 features, 2-layer model: everything that touches a per-row

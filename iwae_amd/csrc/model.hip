@@ -16,7 +16,7 @@
 
 using namespace iwae;
 
-static_assert(sizeof(iwae_config) == 56 && offsetof(iwae_config, seed) == 32 && offsetof(iwae_config, cond_dim) == 48, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
+static_assert(sizeof(iwae_config) == 56 && offsetof(iwae_config, seed) == 32 && offsetof(iwae_config, cond_dim) == 48 && offsetof(iwae_config, cond_prior) == 52, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
 static_assert(sizeof(iwae_scalars) == 64 && sizeof(iwae_tensors) == 12 * sizeof(void*), "ABI struct layout");
 
 static thread_local std::string g_err;
@@ -80,6 +80,9 @@ struct iwae_model {
     size_t nparam = 0;
     // Linear maps.  1-layer: enc{l1,l2,head}, dec{d1,d2,out}.  2-layer adds enc2, dec2 blocks.
     Linear enc1[3], enc2[3], dec2[3], dec1[3];
+    Linear prior[3];           // conditional prior network p(z|y) (cfg.cond_prior, tasks/task04.py:108): BasicBlock on y
+    bool has_prior = false;
+    DevBuf condP;              // y as bf16 P-layout [Bp][32*ceil(C/32)] (the prior block's input)
     float *param = nullptr, *grad = nullptr, *mom = nullptr, *vel = nullptr;
     int64_t adam_t = 0;
     uint32_t noise_step = 0, batch_offset = 0;
@@ -101,7 +104,7 @@ struct iwae_model {
     DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
     DevBuf logw, wn, gx, cf, per_b, dzdir;
-    BlockWs wenc1, wenc2, wdec2;
+    BlockWs wenc1, wenc2, wdec2, wprior;
     MlpWs wdec1;
     DevBuf scratch;            // exports
     // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
@@ -264,6 +267,7 @@ std::vector<Linear*> all_linears(iwae_model* m) {
         for (int i = 0; i < 3; ++i) v.push_back(&m->dec2[i]);
     }
     for (int i = 0; i < 3; ++i) v.push_back(&m->dec1[i]);
+    if (m->has_prior) for (int i = 0; i < 3; ++i) v.push_back(&m->prior[i]);
     return v;
 }
 
@@ -581,6 +585,13 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
+    if (m->has_prior) {     // p(z|y) = N(mu_p(y), sigma_p(y)) (tasks/task04.py:124): the prior block on the B condition rows
+        const int Cp = round_up(m->C, 32);
+        CHK(ensure(m->condP, (size_t)Bp * Cp * 2, st));
+        launch_prep_rows(cond, nullptr, B, m->C, 0, Cp, Bp, ptr<uint16_t>(m->condP), st);
+        CHK(block_alloc(m, m->prior, m->wprior, B, Bp, bwd, false));
+        CHK(block_fwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B));
+    }
     {
         SampleArgs s;
         memset(&s, 0, sizeof(s));
@@ -588,6 +599,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
         s.ZP = ptr<uint16_t>(m->zP[0]);
         s.cond = cond; s.C = m->C;
+        s.prior_head = m->has_prior ? ptr<float>(m->wprior.head) : nullptr;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
@@ -795,8 +807,10 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
         a.B = B; a.Bp = Bp; a.k = k;
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
         a.DHP = ptr<uint16_t>(m->wenc1.dheadP);
+        if (m->has_prior) { a.prior_head = ptr<float>(m->wprior.head); a.DHP2 = ptr<uint16_t>(m->wprior.dheadP); }
         launch_latent_bwd(a, st);
     }
+    if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
     if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
     if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
@@ -888,6 +902,7 @@ int check_objective(iwae_model* m, int objective) {
     if (objective < 0 || objective > 4) return fail(IWAE_ERR_ARG, "unknown objective");
     if (m->cfg.n_layers == 2 && (objective == OBJ_VAE_ELBO_KL || objective == OBJ_DREG))
         return fail(IWAE_ERR_ARG, "objective not defined for the 2-layer model (KeyError in src/iwae2.py:154-173)");
+    if (m->C > 0 && objective == OBJ_DREG) return fail(IWAE_ERR_ARG, "the DReG estimator is defined for the unconditional 1-layer model (tasks/task02.py)");
     return IWAE_OK;
 }
 
@@ -917,6 +932,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (cfg->x_dim < 1 || cfg->x_dim > 4096) return fail(IWAE_ERR_ARG, "x_dim must be in [1,4096]");
     if (cfg->cond_dim < 0 || cfg->cond_dim > 64) return fail(IWAE_ERR_ARG, "cond_dim must be in [0,64]");
     if (cfg->cond_dim > 0 && cfg->n_layers != 1) return fail(IWAE_ERR_ARG, "the conditional model is 1-layer (tasks/task05.py:101)");
+    if (cfg->cond_prior != 0 && cfg->cond_dim <= 0) return fail(IWAE_ERR_ARG, "cond_prior needs cond_dim > 0 (tasks/task04.py)");
     if (cfg->cond_dim > 0 && cfg->n_latent[0] + cfg->cond_dim > round_up(cfg->n_latent[0], 32))
         return fail(IWAE_ERR_ARG, "conditional model: n_latent + cond_dim must fit the 32-feature padding of z");
     int ndev = 0;
@@ -960,6 +976,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X + m->C, m->H[0], m->D[0], false);      // tasks/task05.py:113-118 when C > 0
         add_mlp3(m, m->dec1, "dec", m->D[0] + m->C, m->H[0], m->X);
+        m->has_prior = cfg->cond_prior != 0;
+        if (m->has_prior) add_block(m, m->prior, "prior", m->C, m->H[0], m->D[0], false);      // tasks/task04.py:108 (after the decoder)
     } else {
         add_block(m, m->enc1, "enc1", m->X, m->H[0], m->D[0], false);
         add_block(m, m->enc2, "enc2", m->D[0], m->H[1], m->D[1], true);
@@ -1007,9 +1025,9 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
-    BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2};
+    BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2, &m->wprior};
     for (BlockWs* w : bw) {
         DevBuf* bb[] = {&w->h1P, &w->h2P, &w->head, &w->dheadP, &w->d2P, &w->d1P, &w->dx};
         for (DevBuf* b : bb) free_buf(*b);
@@ -1102,7 +1120,7 @@ int iwae_get_params(iwae_handle m, float* flat, size_t n) {
 int iwae_set_output_bias(iwae_handle m, const float* bias, size_t n) {
     if (!m || !bias || n != (size_t)m->X) return fail(IWAE_ERR_ARG, "set_output_bias: need x_dim values");
     CHK(join_side(m));
-    HIPCHK(hipMemcpyAsync(m->param + m->klayers.back().offb, bias, n * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipMemcpyAsync(m->param + m->klayers[m->dec1[2].sub[0]].offb, bias, n * 4, hipMemcpyDefault, m->stream));
     CHK(refresh_images(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     return IWAE_OK;
@@ -1265,7 +1283,26 @@ int iwae_decode(iwae_handle m, const float* z, int32_t n, float* probs) {
         m->noise_step += 1;
     } else {
         if (m->C > 0 && n > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these rows first");
-        launch_prep_rows(ptr<float>(m->xin), m->C > 0 ? ptr<float>(m->cond) : nullptr, n, D0, m->C, Dp0, np, ptr<uint16_t>(m->zP[0]), st);
+        if (m->has_prior) {
+            // tasks/task04.py:190-196: z_new = pzy.loc + pzy.scale * z with pzy the conditional prior of the label rows
+            const int Cp = round_up(m->C, 32);
+            CHK(ensure(m->condP, (size_t)np * Cp * 2, st));
+            launch_prep_rows(ptr<float>(m->cond), nullptr, n, m->C, 0, Cp, np, ptr<uint16_t>(m->condP), st);
+            CHK(block_alloc(m, m->prior, m->wprior, n, np, false, false));
+            CHK(block_fwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), n));
+            for (int i = 0; i < 2; ++i) CHK(ensure(m->rows[i], (size_t)np * 4, st));
+            SampleArgs s;
+            memset(&s, 0, sizeof(s));
+            s.head = ptr<float>(m->wprior.head); s.ldH = 2 * Dp0; s.Dp = Dp0; s.D = D0; s.head_per_row = 1;
+            s.M = n; s.Mp = np; s.k = 1; s.B = n;
+            s.eps.user = ptr<float>(m->xin); s.eps.B = n;          // the caller's z plays the role of the N(0,1) draw
+            s.ZP = ptr<uint16_t>(m->zP[0]);
+            s.cond = ptr<float>(m->cond); s.C = m->C;
+            s.lp_prior = ptr<float>(m->rows[0]); s.lq = ptr<float>(m->rows[1]); s.lq_dreg = nullptr;
+            launch_sample(s, st);
+        } else {
+            launch_prep_rows(ptr<float>(m->xin), m->C > 0 ? ptr<float>(m->cond) : nullptr, n, D0, m->C, Dp0, np, ptr<uint16_t>(m->zP[0]), st);
+        }
     }
     CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), n, ptr<uint16_t>(w.g1P), nullptr, 0));
     CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), n, ptr<uint16_t>(w.g2P), nullptr, 0));

@@ -18,7 +18,7 @@ def _f32(a):
 
 
 class NativeModel:
-    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0):
+    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0, cond_prior=False):
         self.lib = _capi.load()
         cfg = Config()
         cfg.n_layers = int(n_layers)
@@ -30,6 +30,7 @@ class NativeModel:
         cfg.x_dim, cfg.device, cfg.seed = int(x_dim), int(device), int(seed)
         cfg.world_size, cfg.rank = int(world_size), int(rank)
         cfg.cond_dim = int(cond_dim)
+        cfg.cond_prior = 1 if cond_prior else 0
         self.cond_dim = int(cond_dim)
         self.n_layers, self.x_dim = cfg.n_layers, cfg.x_dim
         self.n_hidden, self.n_latent = nh[:cfg.n_layers], nl[:cfg.n_layers]

@@ -7,7 +7,7 @@ concat(x, onehot(y)) and whose decoder sees concat(z, onehot(y)), prior N(0, 1) 
     x_sample, probs = model.sample(z, label)              # tasks/task05.py:185-198
 
 Same kernels as iwae1.IWAE with the first encoder layer 794 -> H and the first decoder layer 110 -> H; the C ABI carries the
-condition separately (iwae_set_condition).  The conditional-PRIOR variant of tasks/task04.py is not built.
+condition separately (iwae_set_condition).  tasks/task04.py (learned conditional prior on top of this): iwae_amd/task04.py.
 """
 import numpy as np
 
@@ -30,6 +30,7 @@ class CIWAE(IWAE):
 
     def __init__(self, n_hidden, n_latent, **kwargs):
         super().__init__(n_hidden, n_latent, cond_dim=N_CLASSES, **kwargs)
+        self.decoder = type(self.decoder)(self, 8, 14)
 
     def _result(self, raw):
         res = super()._result(raw)

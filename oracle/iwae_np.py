@@ -45,18 +45,22 @@ def _id(a):
 # --------------------------------------------------------------------------
 # parameters (Keras trainable_weights creation order, SURVEY.md 2d)
 # --------------------------------------------------------------------------
-def layer_shapes(n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0):
+def layer_shapes(n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0, cond_prior=False):
     """[(name, (in, out))] for every Dense, in Keras creation order.
     cond_dim > 0 (1-layer only): the conditional model of tasks/task05.py, encoder input x_dim + cond_dim,
-    decoder input n_latent + cond_dim.
+    decoder input n_latent + cond_dim.  cond_prior: tasks/task04.py:108 adds a BasicBlock(cond_dim -> n_latent) AFTER the
+    decoder (Keras creation order), the learned prior p(z|y).
 
     1-layer: iwae1.py:31-34 (BasicBlock), :72-75 (decoder).
     2-layer: iwae2.py:55-56 (two encoder blocks), :77-87 (decoder block + MLP).
     """
     if n_layers == 1:
         H, D = int(n_hidden), int(n_latent)
-        return [("enc.l1", (x_dim + cond_dim, H)), ("enc.l2", (H, H)), ("enc.lmu", (H, D)), ("enc.lstd", (H, D)),
-                ("dec.d1", (D + cond_dim, H)), ("dec.d2", (H, H)), ("dec.out", (H, x_dim))]
+        out = [("enc.l1", (x_dim + cond_dim, H)), ("enc.l2", (H, H)), ("enc.lmu", (H, D)), ("enc.lstd", (H, D)),
+               ("dec.d1", (D + cond_dim, H)), ("dec.d2", (H, H)), ("dec.out", (H, x_dim))]
+        if cond_prior:
+            out += [("prior.l1", (cond_dim, H)), ("prior.l2", (H, H)), ("prior.lmu", (H, D)), ("prior.lstd", (H, D))]
+        return out
     H1, H2 = int(n_hidden[0]), int(n_hidden[1])
     D1, D2 = int(n_latent[0]), int(n_latent[1])
     return [("enc1.l1", (x_dim, H1)), ("enc1.l2", (H1, H1)), ("enc1.lmu", (H1, D1)), ("enc1.lstd", (H1, D1)),
@@ -71,18 +75,18 @@ def output_bias_from_mean(train_mean):
     return -np.log(1.0 / m - 1.0)
 
 
-def init_params(n_layers, n_hidden, n_latent, seed, x_mean=None, x_dim=784, cond_dim=0):
+def init_params(n_layers, n_hidden, n_latent, seed, x_mean=None, x_dim=784, cond_dim=0, cond_prior=False):
     """Keras Dense defaults: glorot-uniform kernel, zero bias; final decoder bias
     from the data mean (iwae1.py:74-75, utils.py:11-23).  Returns list of
     (W [in,out], b [out]) float64."""
     rng = np.random.default_rng(seed)
     params = []
-    shapes = layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim)
-    for idx, (_, (fi, fo)) in enumerate(shapes):
+    shapes = layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim, cond_prior)
+    for idx, (name, (fi, fo)) in enumerate(shapes):
         lim = np.sqrt(6.0 / (fi + fo))
         W = rng.uniform(-lim, lim, size=(fi, fo))
         b = np.zeros(fo)
-        if idx == len(shapes) - 1 and x_mean is not None:
+        if name.endswith(".out") and x_mean is not None:
             b = output_bias_from_mean(x_mean)
         params.append((W, b))
     return params
@@ -92,9 +96,9 @@ def flatten_params(params):
     return np.concatenate([np.concatenate([W.ravel(), b.ravel()]) for W, b in params])
 
 
-def unflatten_params(flat, n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0):
+def unflatten_params(flat, n_layers, n_hidden, n_latent, x_dim=784, cond_dim=0, cond_prior=False):
     out, o = [], 0
-    for _, (fi, fo) in layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim):
+    for _, (fi, fo) in layer_shapes(n_layers, n_hidden, n_latent, x_dim, cond_dim, cond_prior):
         W = np.asarray(flat[o:o + fi * fo], dtype=np.float64).reshape(fi, fo); o += fi * fo
         b = np.asarray(flat[o:o + fo], dtype=np.float64).copy(); o += fo
         out.append((W, b))
@@ -229,7 +233,9 @@ def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None, y
     """x [B,X] in {0,1}; eps [k,B,D] ~ N(0,1) (the draw of qzx.sample, iwae1.py:59).
     Returns the reference's result dict (iwae1.py:141-151) as float64 arrays.
     y [B,C] (optional): the conditional model of tasks/task05.py:108-122 -- the encoder sees concat(x, y), the
-    decoder concat(z, y) (y one-hot there; any float condition here), prior N(0,1), likelihood over x only."""
+    decoder concat(z, y) (y one-hot there; any float condition here), prior N(0,1), likelihood over x only.
+    With 11 parameter pairs (tasks/task04.py:101-173) the last four are the conditional prior network: p(z|y) =
+    N(mu_p(y), sigma_p(y)) replaces N(0,1) in lpz; the analytic KL of vae_elbo_kl stays against N(0,1) (:131)."""
     rnd = rnd or _id
     x = np.asarray(x, dtype=np.float64)
     eps = np.asarray(eps, dtype=np.float64)
@@ -246,7 +252,13 @@ def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None, y
         logits = dec.fwd(rnd(z))                      # iwae1.py:81
     else:
         logits = dec.fwd(rnd(np.concatenate([z, np.broadcast_to(y[None], (k, B, y.shape[-1]))], axis=-1)))   # task05.py:117-118
-    lpz = np.sum(normal_log_prob(z, 0.0, 1.0), axis=-1)            # :107
+    prior = None
+    if y is not None and len(params) == 11:
+        prior = _Block(params[7:11], rnd)
+        mu_p, sig_p = prior.fwd(rnd(y))                                # task04.py:124
+        lpz = np.sum(normal_log_prob(z, mu_p[None], sig_p[None]), axis=-1)   # :130
+    else:
+        lpz = np.sum(normal_log_prob(z, 0.0, 1.0), axis=-1)        # :107
     lqzx = np.sum(normal_log_prob(z, mu[None], sigma[None]), axis=-1)  # :109
     lpxz = np.sum(bernoulli_log_prob(x[None], logits), axis=-1)    # :111
     log_w = lpxz + beta * (lpz - lqzx)                # :113
@@ -268,7 +280,9 @@ def forward_1layer(params, x, eps, beta=1.0, rnd=None, dreg=False, _tape=None, y
         res["inference_loss"] = -np.mean(np.sum(al * al * stopped_log_w, axis=0), axis=-1)  # :73-76
     if _tape is not None:
         _tape.update(enc=enc, dec=dec, mu=mu, sigma=sigma, eps=eps, z=z, x=x, log_w=log_w,
-                     wn=wn, logits=logits, beta=beta, k=k, B=B)
+                     wn=wn, logits=logits, beta=beta, k=k, B=B, prior=prior)
+        if prior is not None:
+            _tape.update(mu_p=mu_p, sig_p=sig_p)
     return res
 
 
@@ -311,11 +325,26 @@ def loss_grads_1layer(params, x, eps, beta=1.0, objective="iwae_elbo", rnd=None,
         dsig = (dz * tape["eps"]).sum(axis=0) + beta * (sigma - 1.0 / sigma) / B
     else:
         Gb = G * beta
-        dz = dz_dec - Gb[:, :, None] * z              # lpz: d/dz = -z
+        if tape.get("prior") is None:
+            dz = dz_dec - Gb[:, :, None] * z          # lpz: d/dz = -z
+        else:                                          # lpz = log N(z; mu_p, sig_p): d/dz = -(z - mu_p)/sig_p^2
+            mu_p, sig_p = tape["mu_p"], tape["sig_p"]
+            u = (z - mu_p[None]) / sig_p[None]
+            dz = dz_dec - Gb[:, :, None] * u / sig_p[None]
+            dmu_p = (Gb[:, :, None] * u / sig_p[None]).sum(axis=0)
+            dsig_p = (Gb[:, :, None] * (u * u - 1.0) / sig_p[None]).sum(axis=0)
         dmu = dz.sum(axis=0)
         dsig = (dz * tape["eps"]).sum(axis=0) + (Gb[:, :, None] / sigma[None]).sum(axis=0)
     enc.bwd(dmu, dsig, need_dx=False)
-    return res, enc.grads() + dec.grads()
+    grads = enc.grads() + dec.grads()
+    prior = tape.get("prior")
+    if prior is not None:
+        if objective == "vae_elbo_kl":                 # lpz is not part of that objective (task04.py:136)
+            prior.bwd(np.zeros_like(tape["mu_p"]), np.zeros_like(tape["sig_p"]), need_dx=False)
+        else:
+            prior.bwd(dmu_p, dsig_p, need_dx=False)
+        grads = grads + prior.grads()
+    return res, grads
 
 
 # --------------------------------------------------------------------------

@@ -46,7 +46,11 @@ def forward_1layer(params, x, eps, beta=1.0, dreg=False, y=None):
     mu, sigma = _block(params[0:4], x if y is None else torch.cat([x, y], dim=-1))
     z = mu.unsqueeze(0) + sigma.unsqueeze(0) * eps
     logits = _mlp3(params[4:7], z if y is None else torch.cat([z, y.unsqueeze(0).expand(z.shape[0], -1, -1)], dim=-1))
-    lpz = _normal_lp(z, torch.zeros((), dtype=z.dtype), torch.ones((), dtype=z.dtype)).sum(-1)
+    if y is not None and len(params) == 11:           # tasks/task04.py:124-130: learned conditional prior p(z|y)
+        mu_p, sig_p = _block(params[7:11], y)
+        lpz = _normal_lp(z, mu_p.unsqueeze(0), sig_p.unsqueeze(0)).sum(-1)
+    else:
+        lpz = _normal_lp(z, torch.zeros((), dtype=z.dtype), torch.ones((), dtype=z.dtype)).sum(-1)
     lqzx = _normal_lp(z, mu.unsqueeze(0), sigma.unsqueeze(0)).sum(-1)
     lpxz = _bern_lp(x.unsqueeze(0), logits).sum(-1)
     log_w = lpxz + beta * (lpz - lqzx)
@@ -124,7 +128,8 @@ def loss_grads(params_np, x, eps, beta=1.0, objective="iwae_elbo", n_layers=1, d
             g = list(ge) + list(gd)
         else:
             res = forward_1layer(P, xt, e, beta, y=None if y is None else torch.tensor(y, dtype=dtype))
-            g = torch.autograd.grad(-res[objective], flatP)
+            g = torch.autograd.grad(-res[objective], flatP, allow_unused=True)
+            g = [gi if gi is not None else torch.zeros_like(p) for gi, p in zip(g, flatP)]
     else:
         e1 = torch.tensor(eps[0], dtype=dtype)
         e2 = torch.tensor(eps[1], dtype=dtype)

@@ -238,6 +238,50 @@ def test_conditional_model_matches_oracle(gpu, B, k, obj, nh, nl, xd):
     m.close()
 
 
+@pytest.mark.parametrize("B,k,obj,beta", [(7, 6, "iwae_elbo", 1.0), (5, 4, "vae_elbo", 0.7), (6, 3, "vae_elbo_kl", 1.0), (170, 50, "iwae_eq14", 1.0)])
+def test_conditional_prior_model_matches_oracle(gpu, B, k, obj, beta):
+    """tasks/task04.py:101-173: the conditional model with the learned prior p(z|y) = N(mu_p(y), sigma_p(y)) (a BasicBlock on
+    onehot(y), created after the decoder): lpz against that prior, its gradient through latent_bwd_kernel's second output."""
+    from iwae_amd.native import NativeModel
+    C, nh, nl, xd = 10, 200, 100, 784
+    rng = np.random.default_rng(B + 100 * k)
+    x = O.synthetic_binarized(B, 41)
+    y = np.eye(C, dtype=np.float32)[rng.integers(0, C, B)]
+    eps = rng.standard_normal((k, B, nl)).astype(np.float32)
+    P = O.init_params(1, nh, nl, 19, x_mean=O.synthetic_pixel_means(xd), x_dim=xd, cond_dim=C, cond_prior=True)
+    assert len(P) == 11
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, beta, obj, rnd=O.bf16_round, y=y)
+    m = NativeModel(1, nh, nl, x_dim=xd, seed=123, cond_dim=C, cond_prior=True)
+    assert m.n_params == sum(W.size + b.size for W, b in P)
+    m.set_params(O.flatten_params(P))
+    m.set_condition(y)
+    r = m.forward_backward(x, k, beta, obj, eps=eps, want=("lpxz", "lqzx", "lpz"))
+    for key in ("lpxz", "lqzx", "lpz"):
+        # lpz divides by sigma_p^2 of a head that comes out of bf16-fed GEMMs: a bf16-ulp flip upstream moves it more than
+        # the N(0,1) prior's lpz (same reason as lpz1z2 of the 2-layer model)
+        assert np.max(np.abs(r[key] - res_e[key])) < (0.2 if key == "lpz" else EMU_ROW_ATOL), key
+    for key in ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14"):
+        assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    errs = _grad_rel_errors(m.get_grads(), g_e)
+    if obj == "vae_elbo_kl":      # lpz is not in that objective: the prior network's gradient is exactly zero
+        assert np.all(m.get_grads()[-sum(W.size + b.size for W, b in P[7:]):] == 0.0)
+        errs = errs[:14]
+    assert max(errs) < EMU_GRAD_REL
+    with pytest.raises(ValueError):
+        m.forward_backward(x, k, beta, "dreg", eps=eps)
+    # sample(z, y) (tasks/task04.py:190-204): z -> mu_p(y) + sigma_p(y) * z, then the decoder on concat(z_new, y)
+    n = 5
+    z = rng.standard_normal((n, nl)).astype(np.float32)
+    yz = np.eye(C, dtype=np.float32)[np.full(n, 8)]
+    m.set_condition(yz)
+    prior = O._Block(P[7:11], O.bf16_round)
+    mu_p, sig_p = prior.fwd(O.bf16_round(yz.astype(np.float64)))
+    dec = O._MLP3(P[4:7], O.bf16_round)
+    ref = O.sigmoid(dec.fwd(O.bf16_round(np.concatenate([mu_p + sig_p * z, yz], axis=-1))))
+    assert np.max(np.abs(m.decode(z) - ref)) < 2e-2
+    m.close()
+
+
 def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m = _model(2, [200, 100], [100, 50])
     x = O.synthetic_binarized(2, 1)

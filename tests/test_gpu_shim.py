@@ -97,6 +97,32 @@ def test_task05_ciwae_api(gpu):
         model.set_dataset(x)
 
 
+def test_task04_ciwae_api(gpu):
+    """tasks/task04.py:101-204: CIWAE with the conditional prior network (22 trainable tensors), dict keys lpxzy/lpzy/lqzxy."""
+    from iwae_amd import task04, utils
+    from iwae_amd.optimizers import Adam
+    np.random.seed(2)
+    model = task04.CIWAE(200, 100, output_bias=utils.bias_from_mean(utils.synthetic_pixel_means()))
+    w = model.trainable_weights
+    assert len(w) == 22 and w[0].shape == (794, 200) and w[8].shape == (110, 200) and w[14].shape == (10, 200) and w[20].shape == (200, 100)
+    assert np.allclose(w[13], utils.bias_from_mean(utils.synthetic_pixel_means()), atol=1e-6)      # the OUTPUT layer's bias, not the last tensor
+    x = O.synthetic_binarized(20, 5)
+    y = np.arange(20) % 10
+    opt = Adam(1e-3, epsilon=1e-4)
+    before = [np.asarray(t).copy() for t in model.trainable_weights]
+    first = None
+    for _ in range(30):
+        res = model.train_step(x, y, 5, 1.0, opt, objective="iwae_elbo")
+        first = float(res["iwae_elbo"]) if first is None else first
+    for key in ("iwae_elbo", "lpxzy", "lpzy", "lqzxy"):
+        assert key in res, key
+    assert float(res["iwae_elbo"]) > first + 1.0
+    after = model.trainable_weights
+    assert all(np.max(np.abs(np.asarray(a) - b)) > 0 for a, b in zip(after, before))                 # every tensor moved, the prior network's too
+    xs, probs = model.sample(np.random.randn(4, 100).astype(np.float32), 2)
+    assert xs.shape == (4, 784) and 0.0 <= probs.min() and probs.max() <= 1.0
+
+
 def test_main_runs_one_epoch(gpu, monkeypatch, capsys):
     """main.py end to end on a tiny synthetic set (the reference's loop structure, flags and final print)."""
     import importlib

@@ -155,3 +155,23 @@ def test_conditional_model_closed_form_matches_autograd():
     # without y the shapes are the unconditional ones and the condition is ignored everywhere
     P0 = O.init_params(1, H, D, 3, x_dim=X)
     assert P0[0][0].shape == (X, H) and P0[4][0].shape == (D, H)
+
+
+def test_conditional_prior_closed_form_matches_autograd():
+    """tasks/task04.py:124-136: lpz against the learned conditional prior p(z|y); its network's gradient, and the zero
+    gradient under vae_elbo_kl (the analytic KL there stays against N(0,1))."""
+    from oracle import iwae_torch as T
+    rng = np.random.default_rng(6)
+    B, k, X, H, D, C = 4, 5, 48, 16, 6, 10
+    P = O.init_params(1, H, D, 3, x_dim=X, cond_dim=C, cond_prior=True)
+    assert len(P) == 11 and P[7][0].shape == (C, H) and P[10][0].shape == (H, D)
+    x = (rng.random((B, X)) < 0.3).astype(np.float64)
+    y = np.eye(C)[rng.integers(0, C, B)]
+    eps = rng.standard_normal((k, B, D))
+    for obj in ("iwae_elbo", "vae_elbo", "vae_elbo_kl", "iwae_eq14"):
+        res, g = O.loss_grads_1layer(P, x, eps, 0.7, obj, y=y)
+        rt, gt = T.loss_grads(P, x, eps, 0.7, obj, y=y)
+        assert abs(res[obj] - rt[obj]) < 1e-12
+        for (a, b), (c, d) in zip(g, gt):
+            assert np.max(np.abs(a - c)) < 1e-12 and np.max(np.abs(b - d)) < 1e-12
+        assert (np.abs(g[7][0]).max() == 0.0) == (obj == "vae_elbo_kl")
