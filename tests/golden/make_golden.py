@@ -18,8 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import iwae_np as O  # noqa: E402
 
 
-def inputs(n_layers, nh, nl, x_dim, B, k, seed):
-    """Deterministic inputs shared by the generator and the tests."""
+def inputs(n_layers, nh, nl, x_dim, B, k, seed, cond=0, cond_prior=False):
+    """Deterministic inputs shared by the generator and the tests.  cond > 0: the conditional models of tasks/task05.py /
+    task04.py (cond_prior); the one-hot condition y is returned as a 4th value."""
     rng = np.random.default_rng(seed)
     if x_dim == 784:
         x = O.synthetic_binarized(B, seed + 1)
@@ -27,12 +28,15 @@ def inputs(n_layers, nh, nl, x_dim, B, k, seed):
     else:
         x = (rng.random((B, x_dim)) < 0.3).astype(np.float32)
         mean = np.full(x_dim, 0.3)
-    P = O.init_params(n_layers, nh, nl, seed + 2, x_mean=mean, x_dim=x_dim)
+    P = O.init_params(n_layers, nh, nl, seed + 2, x_mean=mean, x_dim=x_dim, cond_dim=cond, cond_prior=cond_prior)
     P = [(W, b + 0.05 * rng.standard_normal(b.shape)) for W, b in P]
     if n_layers == 1:
         eps = rng.standard_normal((k, B, nl)).astype(np.float32)
     else:
         eps = (rng.standard_normal((k, B, nl[0])).astype(np.float32), rng.standard_normal((k, B, nl[1])).astype(np.float32))
+    if cond:
+        y = np.eye(cond, dtype=np.float32)[rng.integers(0, cond, B)]
+        return x, P, eps, y
     return x, P, eps
 
 
@@ -45,10 +49,14 @@ def grad_summary(grads):
     return np.array(rows)
 
 
-def run(n_layers, nh, nl, x_dim, B, k, seed, objective, beta, rnd):
-    x, P, eps = inputs(n_layers, nh, nl, x_dim, B, k, seed)
+def run(n_layers, nh, nl, x_dim, B, k, seed, objective, beta, rnd, cond=0, cond_prior=False):
+    y = None
+    if cond:
+        x, P, eps, y = inputs(n_layers, nh, nl, x_dim, B, k, seed, cond, cond_prior)
+    else:
+        x, P, eps = inputs(n_layers, nh, nl, x_dim, B, k, seed)
     if n_layers == 1:
-        res, g = O.loss_grads_1layer(P, x, eps, beta, objective, rnd=rnd)
+        res, g = O.loss_grads_1layer(P, x, eps, beta, objective, rnd=rnd, y=y)
     else:
         res, g = O.loss_grads_2layer(P, x, eps[0], eps[1], beta, objective, rnd=rnd)
     flat = O.flatten_params(P)
@@ -57,12 +65,14 @@ def run(n_layers, nh, nl, x_dim, B, k, seed, objective, beta, rnd):
     return x, P, eps, res, g, gflat, p1
 
 
-def save(name, n_layers, nh, nl, x_dim, B, k, seed, objectives, beta=1.0, full_arrays=False):
+def save(name, n_layers, nh, nl, x_dim, B, k, seed, objectives, beta=1.0, full_arrays=False, cond=0, cond_prior=False):
     out = {"n_layers": n_layers, "n_hidden": np.array(nh), "n_latent": np.array(nl), "x_dim": x_dim, "B": B, "k": k,
            "seed": seed, "beta": beta, "objectives": np.array(objectives)}
+    if cond:
+        out["cond_dim"], out["cond_prior"] = cond, int(cond_prior)
     for tag, rnd in (("exact", None), ("bf16", O.bf16_round)):
         for obj in objectives:
-            x, P, eps, res, g, gflat, p1 = run(n_layers, nh, nl, x_dim, B, k, seed, obj, beta, rnd)
+            x, P, eps, res, g, gflat, p1 = run(n_layers, nh, nl, x_dim, B, k, seed, obj, beta, rnd, cond, cond_prior)
             pre = "%s/%s/" % (tag, obj)
             for key, v in res.items():
                 if np.ndim(v) == 0 or key in ("lpxz", "lpz", "lqzx", "lpxz1", "lpz1z2", "lpz2", "lqz1x", "lqz2z1", "al") or full_arrays:
@@ -89,3 +99,5 @@ if __name__ == "__main__":
     save("full_1layer_B8_k50", 1, 200, 100, 784, 8, 50, 13, ["iwae_elbo", "vae_elbo_kl", "dreg"])
     save("full_1layer_B20_k1", 1, 200, 100, 784, 20, 1, 14, ["vae_elbo", "iwae_elbo"])
     save("full_2layer_B4_k5", 2, [200, 100], [100, 50], 784, 4, 5, 15, ["iwae_elbo", "vae_elbo"])
+    save("full_cond_B6_k5", 1, 200, 100, 784, 6, 5, 16, ["iwae_elbo", "vae_elbo_kl"], cond=10)                         # tasks/task05.py
+    save("full_condprior_B6_k5", 1, 200, 100, 784, 6, 5, 17, ["iwae_elbo", "vae_elbo"], beta=0.8, cond=10, cond_prior=True)  # tasks/task04.py

@@ -291,15 +291,24 @@ def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_1layer", "tiny_2layer", "full_1layer_B8_k50", "full_1layer_B20_k1", "full_2layer_B4_k5"])
+@pytest.mark.parametrize("name", ["tiny_1layer", "tiny_2layer", "full_1layer_B8_k50", "full_1layer_B20_k1", "full_2layer_B4_k5",
+                                  "full_cond_B6_k5", "full_condprior_B6_k5"])
 def test_against_golden_fixtures(gpu, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     nl = int(g["n_layers"])
     nh = g["n_hidden"].tolist() if nl == 2 else int(g["n_hidden"])
     nlat = g["n_latent"].tolist() if nl == 2 else int(g["n_latent"])
     B, k, beta = int(g["B"]), int(g["k"]), float(g["beta"])
-    x, P, eps = MG.inputs(nl, nh, nlat, int(g["x_dim"]), B, k, int(g["seed"]))
-    m = _model(nl, nh, nlat, int(g["x_dim"]))
+    cond = int(g["cond_dim"]) if "cond_dim" in g else 0
+    cprior = bool(int(g["cond_prior"])) if "cond_prior" in g else False
+    if cond:
+        from iwae_amd.native import NativeModel
+        x, P, eps, y = MG.inputs(nl, nh, nlat, int(g["x_dim"]), B, k, int(g["seed"]), cond, cprior)
+        m = NativeModel(nl, nh, nlat, x_dim=int(g["x_dim"]), seed=123, cond_dim=cond, cond_prior=cprior)
+        m.set_condition(y)
+    else:
+        x, P, eps = MG.inputs(nl, nh, nlat, int(g["x_dim"]), B, k, int(g["seed"]))
+        m = _model(nl, nh, nlat, int(g["x_dim"]))
     for obj in [str(o) for o in g["objectives"]]:
         m.set_params(O.flatten_params(P))
         r = m.forward_backward(x, k, beta, obj, eps=eps, want=("lpxz", "al"))
@@ -313,7 +322,7 @@ def test_against_golden_fixtures(gpu, name):
         gs = g[pre + "grad_summary"]
         flat = m.get_grads().astype(np.float64)
         off = 0
-        shapes = O.layer_shapes(nl, nh, nlat, int(g["x_dim"]))
+        shapes = O.layer_shapes(nl, nh, nlat, int(g["x_dim"]), cond, cprior)
         for li, (_, (fi, fo)) in enumerate(shapes):
             for ti, n in enumerate((fi * fo, fo)):
                 t = flat[off:off + n]; off += n

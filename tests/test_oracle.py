@@ -49,15 +49,22 @@ def test_parameter_counts_match_survey():       # 455,384 and 521,
     assert sum(a * b + b for _, (a, b) in O.layer_shapes(2, [200, 100], [100, 50])) == 521084
 
 
-@pytest.mark.parametrize("name", ["tiny_1layer", "tiny_2layer", "full_1layer_B8_k50", "full_1layer_B20_k1", "full_2layer_B4_k5"])
+GOLDEN = ["tiny_1layer", "tiny_2layer", "full_1layer_B8_k50", "full_1layer_B20_k1", "full_2layer_B4_k5",
+          "full_cond_B6_k5", "full_condprior_B6_k5"]
+
+
+@pytest.mark.parametrize("name", GOLDEN)
 def test_oracle_reproduces_golden(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     nl = int(g["n_layers"])
     nh = g["n_hidden"].tolist() if nl == 2 else int(g["n_hidden"])
     nlat = g["n_latent"].tolist() if nl == 2 else int(g["n_latent"])
+    cond = int(g["cond_dim"]) if "cond_dim" in g else 0
+    cprior = bool(int(g["cond_prior"])) if "cond_prior" in g else False
     for tag, rnd in (("exact", None), ("bf16", O.bf16_round)):
         for obj in [str(o) for o in g["objectives"]]:
-            x, P, eps, res, gr, gflat, p1 = MG.run(nl, nh, nlat, int(g["x_dim"]), int(g["B"]), int(g["k"]), int(g["seed"]), obj, float(g["beta"]), rnd)
+            x, P, eps, res, gr, gflat, p1 = MG.run(nl, nh, nlat, int(g["x_dim"]), int(g["B"]), int(g["k"]), int(g["seed"]), obj, float(g["beta"]), rnd,
+                                                   cond, cprior)
             pre = "%s/%s/" % (tag, obj)
             for key in res:
                 if pre + key in g:
