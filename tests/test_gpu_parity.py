@@ -282,6 +282,29 @@ def test_conditional_prior_model_matches_oracle(gpu, B, k, obj, beta):
     m.close()
 
 
+def test_changing_batch_shapes_do_not_leak_state(gpu):
+    """One handle driven through changing (B, k) -- growing and shrinking buffers, the speculative noise prefetch missing its
+    guess, the deferred decoder update pending across calls: every step must equal the same step on a fresh handle."""
+    P = O.init_params(1, 200, 100, 5, x_mean=O.synthetic_pixel_means())
+    m1 = _model(1, 200, 100)
+    m1.set_params(O.flatten_params(P))
+    shapes = [(64, 10), (16, 50), (200, 3), (64, 10), (64, 10), (180, 50), (5, 1)]
+    for t, (B, k) in enumerate(shapes):
+        x = O.synthetic_binarized(B, 100 + t)
+        before = m1.get_params().copy()
+        m2 = _model(1, 200, 100)
+        m2.set_params(before)
+        mo, ve, ts = m1.get_adam_state()
+        m2.set_adam_state(mo, ve, ts)
+        for m in (m1, m2):
+            m.set_step(40 + t, 0)
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=False)
+        np.testing.assert_array_equal(m1.get_grads(), m2.get_grads())
+        np.testing.assert_array_equal(m1.get_params(), m2.get_params())
+        m2.close()
+    m1.close()
+
+
 def test_2layer_rejects_vae_elbo_kl_and_dreg(gpu):
     m = _model(2, [200, 100], [100, 50])
     x = O.synthetic_binarized(2, 1)
