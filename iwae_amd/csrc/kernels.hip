@@ -1892,6 +1892,9 @@ static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, h
 }
 // 8 waves x 16 rows (four waves per SIMD): instantiated for the large-row-count launches of the reference shapes
 static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    // K > 256 (the 784-pixel input layer): the window loop is bound by issuing its LDS-DMA pieces and row loads (phase stamps:
+    // 37 % issue + 45 % wait, 3 % MFMA at B = 1024) -- eight waves share that issue work
+    if (a.KT > 8 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), lds, st, a); return true; }
     if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;
     if (a.KT == 7) {
         switch (epi) {

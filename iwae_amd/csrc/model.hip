@@ -349,7 +349,7 @@ EpsSrc eps_src(iwae_model* m, int layer) {
 
 // diagnostic (STAMPS=1 build + IWAE_DENSE_STAMPS="<epi>:<KT>"): record the phase stamps of the matching dense launch
 int attach_dense_stamps(iwae_model* m, int epi, DenseArgs& a) {
-    if (m->dstamp_epi != epi || m->dstamp_kt != a.KT || a.M < 4096) return IWAE_OK;
+    if (m->dstamp_epi != epi || m->dstamp_kt != a.KT || (a.M < 4096 && a.KT <= 8)) return IWAE_OK;
     m->dstamp_waves = ((a.M + 127) / 128) * ((a.MG + a.mg_per_block - 1) / a.mg_per_block) * 4;
     CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, m->stream));
     a.stamps = ptr<unsigned long long>(m->dstamps);
