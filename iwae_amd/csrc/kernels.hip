@@ -209,9 +209,8 @@ __device__ __forceinline__ float bern8(const f32x4& a0, const f32x4& a1, const u
 // (the LDS-frugal shape).  G = 1: 8 waves x 16 rows in <= 128 registers, i.e. FOUR waves per SIMD with two workgroups
 // per CU: the epilogues here are transcendental-bound on the wave's own issue stream (exp/log/rcp at quarter rate), and
 // the only way to fill a SIMD's transcendental unit is more resident waves.
-template <int EPI, int KTC, int G>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase
-__global__ __launch_bounds__(G == 2 ? 256 : 512, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD
-    constexpr int NWV = (G == 2) ? 4 : 8;
+template <int EPI, int KTC, int G, int NWV = (G == 2 ? 4 : 8)>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase; NWV waves
+__global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD
 #ifdef IWAE_DENSE_STAMPS
     unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
@@ -1896,9 +1895,14 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
     // 37 % issue + 45 % wait, 3 % MFMA at B = 1024) -- eight waves share that issue work
     if (a.KT > 8 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), lds, st, a); return true; }
     if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;
+    // the 200 -> 200 tanh layer (d2): 16 waves x 16 rows, one workgroup per CU -- half the LDS-DMA pieces and row loads per
+    // wave again, one weight stream per 256 rows (measured: -5 us per step; the other epilogues and the 100 -> 200 layer: no change)
+    if (a.KT == 7 && epi == EPI_TANH) {
+        hipLaunchKernelGGL((dense_kernel<EPI_TANH, 7, 1, 16>), dim3((a.M + 255) / 256, grid.y), dim3(1024), lds, st, a);
+        return true;
+    }
     if (a.KT == 7) {
         switch (epi) {
-            case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, 7, 1>), grid, dim3(512), lds, st, a); return true;
             case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, 7, 1>), grid, dim3(512), lds, st, a); return true;
             case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, 7, 1>), grid, dim3(512), lds, st, a); return true;
             case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, 7, 1>), grid, dim3(512), lds, st, a); return true;
