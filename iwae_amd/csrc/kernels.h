@@ -29,6 +29,7 @@ struct DenseArgs {
     const char* img;                  // MG-major A-image of the weight
     int split;                        // EPI_HEAD: out-features >= split are the sigma head (exp + 1e-6)
     int M, KT, MG, mg_per_block;
+    int stage_all;                    // run-time K path: stage every window's weights up front (needs mg_per_block * windows <= 4)
     unsigned g1_mask;                 // EPI bit mask: launches (M >= 8192) that take the 8-wave x 16-row shape
     int Np32;                         // out-features that are stored (multiple of 32)
     uint16_t* YP; int ldYP;           // bf16 P-layout out

@@ -313,7 +313,13 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
         st_mg = -1;
     };
 
-    if (nunits > 0) stage(0, 0);
+    // a.stage_all (run-time K path, <= 4 units per block, i.e. small row counts where a block owns ONE out-feature group):
+    // all windows' weights are requested up front into their own LDS buffers -- the window loop then waits once for the DMA
+    // instead of once per window (it was 45 % wait + 37 % issue at B = 1024)
+    const bool stage_all = !KTC && a.stage_all && nunits <= 4;
+    if (stage_all) {
+        for (int u = 0; u < nunits; ++u) stage(u, u);
+    } else if (nunits > 0) stage(0, 0);
     if (nkw == 1) load_b(0);
     uint4 pre[2][G], pre_n[2][G];
     if (kPre && mg0 < mg1) load_pre(mg0, pre);
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
 
         const char* lbias = smem;
         for (int kw = 0; kw < nkw; ++kw) {
-            const int unit = (mg - mg0) * nkw + kw, buf = unit & 1;
+            const int unit = (mg - mg0) * nkw + kw, buf = stage_all ? unit : (unit & 1);
             if constexpr (KTC == 0) if (nkw > 1) {
                 if (unit == 0) {
                     load_b(kw);
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
             __syncthreads();
             DS_STAMP(2)      // barrier
             const bool more = unit + 1 < nunits;
-            if (!KTC && more) stage(unit + 1, buf ^ 1);
+            if (!KTC && more && !stage_all) stage(unit + 1, buf ^ 1);
             if constexpr (KTC == 0) { if (nkw > 1 && more) load_b_into((kw + 1) % nkw, bfr_n); }
             if (kw == 0) {
                 emit_stores();
@@ -1893,7 +1899,10 @@ static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, h
 static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     // K > 256 (the 784-pixel input layer): the window loop is bound by issuing its LDS-DMA pieces and row loads (phase stamps:
     // 37 % issue + 45 % wait, 3 % MFMA at B = 1024) -- eight waves share that issue work
-    if (a.KT > 8 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), lds, st, a); return true; }
+    if (a.KT > 8 && epi == EPI_TANH) {
+        hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), a.stage_all ? 4 * DENSE_UNIT : lds, st, a);
+        return true;
+    }
     if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;
     // the 200 -> 200 tanh layer (d2): 16 waves x 16 rows, one workgroup per CU -- half the LDS-DMA pieces and row loads per
     // wave again, one weight stream per 256 rows (measured: -5 us per step; the other epilogues and the 100 -> 200 layer: no change)
@@ -1922,7 +1931,7 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
         case 4: launch_dense_k<4>(epi, a, grid, lds, st); break;
         case 7: launch_dense_k<7>(epi, a, grid, lds, st); break;
         case 8: launch_dense_k<8>(epi, a, grid, lds, st); break;
-        default: launch_dense_k<0>(epi, a, grid, lds, st); break;
+        default: launch_dense_k<0>(epi, a, grid, a.stage_all ? 4 * DENSE_UNIT : lds, st); break;
     }
 }
 bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }

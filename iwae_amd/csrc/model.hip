@@ -371,6 +371,7 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, u
     a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
     a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
     a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
+    a.stage_all = (a.mg_per_block == 1 && L.KT > 8 && (L.KT + 7) / 8 <= 4) ? 1 : 0;
     a.YP = YP; a.ldYP = L.Np32; a.YF = YF; a.ldYF = ldYF;
     CHK(attach_dense_stamps(m, epi, a));
     launch_dense(epi, a, m->stream);
