@@ -37,6 +37,11 @@ struct DenseArgs {
     const uint16_t* ACT; int ldACT;   // EPI_DX: stored activation of the out-features (P-layout)
     // EPI_BERN
     const uint16_t* XB; int ldXB; int k; int B; int Xdim;
+    // sampled-input mode (dense_kernel<..., ZIN>): z = mu + sigma*eps made in place of reading X (X's layout: ldX = 32*KT)
+    const float* zhead; int ldZH;     // encoder head per image [B][ldZH] (mu | sigma at zDp)
+    const float* zeps; int zD, zDp;   // the step's draws fp32 [rows][zDp]; latent width and its padding
+    uint16_t* ZPout;                  // z as bf16 P-layout [M][ldX] (kept for the weight gradient)
+    float* zlp; float* zlq;           // per-row log p(z), log q(z|x)
     float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]
     float* logits_out;
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null

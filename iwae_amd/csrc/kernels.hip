@@ -209,7 +209,11 @@ __device__ __forceinline__ float bern8(const f32x4& a0, const f32x4& a1, const u
 // (the LDS-frugal shape).  G = 1: 8 waves x 16 rows in <= 128 registers, i.e. FOUR waves per SIMD with two workgroups
 // per CU: the epilogues here are transcendental-bound on the wave's own issue stream (exp/log/rcp at quarter rate), and
 // the only way to fill a SIMD's transcendental unit is more resident waves.
-template <int EPI, int KTC, int G, int NWV = (G == 2 ? 4 : 8)>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase; NWV waves
+// ZIN: the data operand is not read but MADE: the layer's input is the reparameterised sample z = mu + sigma*eps of its rows
+// (first decoder layer of a training step).  The wave draws its fragments from the encoder head of the row's image and the
+// step's noise, stores them (they ARE the P-layout rows of z, which the weight gradient needs) and sums the row's prior and
+// posterior log-densities on the way -- the separate sampling pass over the rows (42 MB, 14 us) disappears.
+template <int EPI, int KTC, int G, int NWV = (G == 2 ? 4 : 8), bool ZIN = false>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase; NWV waves
 __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD
 #ifdef IWAE_DENSE_STAMPS
     unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
@@ -320,7 +324,52 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
     if (stage_all) {
         for (int u = 0; u < nunits; ++u) stage(u, u);
     } else if (nunits > 0) stage(0, 0);
-    if (nkw == 1) load_b(0);
+    if constexpr (ZIN) {
+        static_assert(KTC > 0, "the sampled-input mode is a single-window launch");
+        float lp[G], lq[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            lp[g] = 0.0f; lq[g] = 0.0f;
+            const int b = rowc[g] / a.k;
+            const float* hd = a.zhead + (size_t)b * a.ldZH;
+            const float* er = a.zeps + (size_t)rowc[g] * a.zDp;
+#pragma unroll
+            for (int ks = 0; ks < KTC; ++ks) {
+                float z8[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int f0 = 32 * ks + 16 * h + 4 * q;          // the lane's features f0..f0+3 of this k-step (P order)
+                    float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = e4, sg4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (f0 < a.zD) {
+                        e4 = *(const float4*)(er + f0);
+                        mu4 = *(const float4*)(hd + f0);
+                        sg4 = *(const float4*)(hd + a.zDp + f0);
+                    }
+                    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float z = 0.0f;
+                        if (f0 + i < a.zD) {
+                            z = fmaf(sgv[i], ev[i], muv[i]);                              // iwae1.py:59
+                            lp[g] += -0.5f * z * z - 0.5f * LOG2PI_F;                     // iwae1.py:107
+                            lq[g] += -0.5f * ev[i] * ev[i] - 0.5f * LOG2PI_F - __logf(sgv[i]);   // iwae1.py:109: (z - mu)/sigma IS eps
+                        }
+                        z8[4 * h + i] = z;
+                    }
+                }
+                const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+                bfr[ks][g] = valid[g] ? frag : make_uint4(0, 0, 0, 0);
+                if (valid[g]) *(uint4*)(a.ZPout + (size_t)row[g] * a.ldX + ks * 32 + q * 8) = frag;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float v0 = lp[g], v1 = lq[g];
+            v0 += __shfl_xor(v0, 16); v0 += __shfl_xor(v0, 32);
+            v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+            if (q == 0 && valid[g]) { a.zlp[row[g]] = v0; a.zlq[row[g]] = v1; }
+        }
+    } else if (nkw == 1) load_b(0);
     uint4 pre[2][G], pre_n[2][G];
     if (kPre && mg0 < mg1) load_pre(mg0, pre);
     DS_STAMP(0)      // prologue
@@ -1901,6 +1950,11 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
     // 37 % issue + 45 % wait, 3 % MFMA at B = 1024) -- eight waves share that issue work
     if (a.KT > 8 && epi == EPI_TANH) {
         hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), a.stage_all ? 4 * DENSE_UNIT : lds, st, a);
+        return true;
+    }
+    if (a.zhead) {      // sampled-input mode (host asks for it only where an instantiation exists: 1-layer training step, latent <= 128)
+        if (a.KT == 4) hipLaunchKernelGGL((dense_kernel<EPI_TANH, 4, 1, 8, true>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((dense_kernel<EPI_TANH, 2, 1, 8, true>), grid, dim3(512), lds, st, a);
         return true;
     }
     if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;

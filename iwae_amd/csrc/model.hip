@@ -135,6 +135,7 @@ struct iwae_model {
     // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
+    bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
@@ -365,13 +366,18 @@ int join_side(iwae_model* m) {
 }
 
 // ---------------------------------------------------------------- forward pieces
-int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, uint16_t* YP, float* YF, int ldYF) {
+int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, uint16_t* YP, float* YF, int ldYF, const SampleArgs* zin = nullptr) {
     DenseArgs a;
     memset(&a, 0, sizeof(a));
     a.X = XP; a.ldX = L.Kp32; a.img = L.imgF;
     a.split = (L.nsub == 2) ? L.joff[1] : (1 << 30);
     a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
     a.stage_all = (a.mg_per_block == 1 && L.KT > 8 && (L.KT + 7) / 8 <= 4) ? 1 : 0;
+    if (zin) {      // sampled-input mode: the layer makes its own input rows z = mu + sigma*eps (and keeps them in zin->ZP)
+        a.zhead = zin->head; a.ldZH = zin->ldH; a.zeps = zin->eps.cache; a.zD = zin->D; a.zDp = zin->Dp;
+        a.ZPout = zin->ZP; a.zlp = zin->lp_prior; a.zlq = zin->lq; a.k = zin->k;
+        a.mg_per_block = L.MG;          // one block owns all out-feature groups of its rows (the z rows are made once)
+    }
     a.YP = YP; a.ldYP = L.Np32; a.YF = YF; a.ldYF = ldYF;
     CHK(attach_dense_stamps(m, epi, a));
     launch_dense(epi, a, m->stream);
@@ -586,6 +592,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
+    bool fuse_z = false;
+    SampleArgs zin;
+    memset(&zin, 0, sizeof(zin));
     if (m->has_prior) {     // p(z|y) = N(mu_p(y), sigma_p(y)) (tasks/task04.py:124): the prior block on the B condition rows
         const int Cp = round_up(m->C, 32);
         CHK(ensure(m->condP, (size_t)Bp * Cp * 2, st));
@@ -605,7 +614,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
         s.lq_dreg = want_dreg ? lqd : nullptr;
-        launch_sample(s, st);
+        // 1-layer training step on the device's own noise: the first decoder layer makes z itself (dense_kernel ZIN mode)
+        fuse_z = m->allow_zin && !two && m->C == 0 && bwd && !want_dreg && s.eps.cache != nullptr && M >= 8192 &&
+                 (m->dec1[0].KT == 4 || m->dec1[0].KT == 2) && m->dec1[0].Kp32 == m->Dp[0];
+        if (fuse_z) zin = s;
+        else launch_sample(s, st);
     }
     if (two) {
         // ---- q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
@@ -634,7 +647,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     const int Hp = m->dec1[0].Np32;
     CHK(ensure(w.g1P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.g2P, (size_t)Mp * Hp * 2, st));
-    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0));
+    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
     CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
     {
         Linear& L = m->dec1[2];
@@ -947,6 +960,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
+    m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));

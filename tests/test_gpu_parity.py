@@ -136,9 +136,33 @@ def test_large_row_count_kernels_match_oracle(gpu):
     m.close()
 
 
+def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
+    """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
+    decoder layer making z = mu + sigma*eps itself) against the oracle fed the same draws, restated on the host from the
+    published Philox4x32-10 + Box-Muller (oracle/philox_np.py).  The host draws are float64, the device's float32: the
+    tolerances are the bf16-emulation ones."""
+    B, k, step = 170, 50, 9
+    x = O.synthetic_binarized(B, 23)
+    P = O.init_params(1, 200, 100, 29, x_mean=O.synthetic_pixel_means())
+    eps = philox_np.device_eps(123, step, B, k, 100)                     # [k, B, D], seed 123 = _model's
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
+    m = _model(1, 200, 100)
+    m.set_params(O.flatten_params(P))
+    m.set_step(step, 0)
+    r = m.forward_backward(x, k, 1.0, "iwae_elbo", want=("lpxz", "lpz", "lqzx", "z"))
+    np.testing.assert_allclose(r["z"], res_e["z"], rtol=0, atol=1e-2)
+    for key in ("lpxz", "lpz", "lqzx"):
+        assert np.max(np.abs(r[key] - res_e[key])) < EMU_ROW_ATOL, key
+    for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+        assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
+    m.close()
+
+
 def test_kernel_variants_agree(gpu, monkeypatch):
     """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
-    instead of reading the stored s, and the 4-wave x 32-row dense shape instead of 8 x 16."""
+    instead of reading the stored s, the 4-wave x 32-row dense shape instead of 8 x 16, and the separate sampling kernel
+    instead of the first decoder layer making z itself."""
     B, k = 170, 50
     x = O.synthetic_binarized(B, 3)
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
@@ -157,7 +181,7 @@ def test_kernel_variants_agree(gpu, monkeypatch):
         return r["iwae_elbo"], g
 
     e0, g0 = run({})
-    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}):
+    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
