@@ -44,6 +44,7 @@ struct DenseArgs {
     float* zlp; float* zlq;           // per-row log p(z), log q(z|x)
     float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]
     float* logits_out;
+    int pipe;                         // EPI_BERN: take bern_pipe_kernel where it exists (IWAE_NO_BERN_PIPE=1 clears it)
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 

@@ -561,6 +561,208 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
 }
 
 // ---------------------------------------------------------------------------------
+// bern_pipe_kernel: the Bernoulli forward (decoder output layer + log p(x|z), iwae1.py:74-75,83,111) at large row counts,
+// software-pipelined INSIDE each wave.  dense_kernel<EPI_BERN> runs "MFMAs of a 64-pixel group, then its epilogue": the
+// waves of a workgroup pass those phases in lockstep (barriers) and two workgroups sharing a CU fall into step with each
+// other (they contend for the same LDS port in one phase and the same VALU in the other), so the MFMA/LDS phase (33 us
+// alone) and the epilogue's VALU issue (~80 cycles per logit, 21+ us alone) add up instead of overlapping (52 us).
+// Here a wave works in HALF groups (32 pixels = one accumulator tile pair = one bern8 call) and issues the 2*KTC MFMAs of
+// half h+1 between the VALU / transcendental instructions of the epilogue of half h (four fenced chunks per half), so
+// every wave's own instruction stream keeps both pipes busy and no phase alignment between waves matters.
+//   * 8 waves x 16 rows, <= 128 registers (four waves per SIMD): g2 fragments 4*KTC, two accumulator tile pairs 16,
+//     two deferred s fragments 8, LDS read pipeline 16
+//   * x - 1/2 of the (<= BERN_XIMG_MAX) images the workgroup's 128 rows belong to is staged in LDS once, as fp32: the loop has
+//     no global loads, only the weight DMA (one group ahead, issued right behind the barrier) and the deferred s stores
+//   * pad halves beyond Np32 are skipped (800 of 832 padded pixels at X = 784)
+// ---------------------------------------------------------------------------------
+#define BERN_XIMG_MAX 5
+template <int KTC, bool KEEP>
+__global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int UNIT = KTC * 4096 + 1024, NPC = 4 * KTC + 1, NIDX = (NPC + 7) / 8, NF = 2 * KTC, P = 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * 8 + wave) * 16 + rho;
+    const bool valid = row < a.M;
+    const int rowc = min(row, a.M - 1);
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    const int H = a.Np32 >> 5;                  // 32-pixel halves that hold real pixels
+    const size_t gbytes = img_mg_group_bytes(KTC);
+
+    auto dma_group = [&](int g, int buf) {      // wave w moves pieces w, w+8, ...
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) {
+            const int p = wave + 8 * idx;
+            if (p < NPC)
+                glds16(a.img + (size_t)g * gbytes + (size_t)p * 1024 + lane * 16,
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
+        }
+    };
+    dma_group(0, 0);
+    // x of the images of this block's rows -> LDS (the rows of XB are contiguous)
+    // x - 1/2 as fp32 (P order, so a lane's 8 values of a half are 32 contiguous bytes): the epilogue reads its operand ready-made
+    char* lx = smem + 2 * UNIT;
+    const int blk_r0 = blockIdx.x * 128;
+    const int b0 = blk_r0 / a.k, b1 = min(blk_r0 + 127, a.M - 1) / a.k;
+    const int xchunks = (b1 - b0 + 1) * a.ldXB / 8;           // 16-byte pieces of bf16 x (the rows of XB are contiguous)
+    for (int o = threadIdx.x; o < xchunks; o += 512) {
+        const uint4 v = *(const uint4*)(a.XB + (size_t)b0 * a.ldXB + (size_t)o * 8);
+        float4 lo, hi;
+        lo.x = bflo(v.x) - 0.5f; lo.y = bfhi(v.x) - 0.5f; lo.z = bflo(v.y) - 0.5f; lo.w = bfhi(v.y) - 0.5f;
+        hi.x = bflo(v.z) - 0.5f; hi.y = bfhi(v.z) - 0.5f; hi.z = bflo(v.w) - 0.5f; hi.w = bfhi(v.w) - 0.5f;
+        *(float4*)(lx + (size_t)o * 32) = lo;
+        *(float4*)(lx + (size_t)o * 32 + 16) = hi;
+    }
+    const char* lxrow = lx + (size_t)(rowc / a.k - b0) * a.ldXB * 4 + q * 32;     // + 128 bytes per half
+    uint4 bfr[KTC];
+#pragma unroll
+    for (int ks = 0; ks < KTC; ++ks) {
+        const uint4 v = *(const uint4*)(a.X + (size_t)rowc * a.ldX + ks * 32 + q * 8);
+        bfr[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+    }
+
+    f32x4 accA[2], accB[2];      // the two tile pairs swap roles every stage (multiply into one, epilogue from the other)
+    uint4 st[2];
+    float rowacc = 0.0f;
+    auto store_s = [&](int h, const uint4& v) {
+        if (KEEP && valid) *(uint4*)(a.YP + (size_t)row * a.ldYP + 32 * h + 8 * q) = v;
+    };
+    // One pipeline stage: the 2*KTC MFMAs of half hN = h+1 (tile pair tbN of the group in buffer bufN, accumulators accN,
+    // started from the bias block) are issued in four chunks between the epilogue arithmetic of half h (accC, two logits
+    // per chunk); sched_barrier fences keep the chunks apart, inside a chunk the compiler schedules freely.  MF = false:
+    // epilogue only (last half).  The per-logit arithmetic is bern8's (see there).
+    auto stage = [&](auto masked, auto domfma, f32x4 (&accC)[2], f32x4 (&accN)[2], int h, int bufN, int tbN, float4 (&xq)[2], uint4& sp) {
+        constexpr bool MASKED = decltype(masked)::value, MF = decltype(domfma)::value;
+        const char* lb = smem + bufN * UNIT + a_off + tbN * 1024;
+        uint4 av[P];
+        if constexpr (MF) {
+            const char* lbias = smem + bufN * UNIT + KTC * 4096 + tbN * 64 + q * 16;
+            const float4 c0 = *(const float4*)lbias, c1 = *(const float4*)(lbias + 64);
+            accN[0] = (f32x4){c0.x, c0.y, c0.z, c0.w};
+            accN[1] = (f32x4){c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int i = 0; i < P; ++i) av[i] = *(const uint4*)(lb + ((i >> 1) * 4 + (i & 1)) * 1024);
+        }
+        float s_xl = 0.0f, s_al = 0.0f, prod = 1.0f, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int f0 = 32 * h + 4 * q;
+        // x - 1/2 of this half was read a stage ago (xq); the next half's is requested here and pinned at the end of the stage,
+        // so no epilogue instruction waits on an LDS read issued right in front of it
+        float xm8[8] = {xq[0].x, xq[0].y, xq[0].z, xq[0].w, xq[1].x, xq[1].y, xq[1].z, xq[1].w};
+        asm volatile("" : "+v"(xm8[0]), "+v"(xm8[1]), "+v"(xm8[2]), "+v"(xm8[3]), "+v"(xm8[4]), "+v"(xm8[5]), "+v"(xm8[6]), "+v"(xm8[7]));
+        float4 xn0 = *(const float4*)(lxrow + (h + 1) * 128), xn1 = *(const float4*)(lxrow + (h + 1) * 128 + 16);   // <= one half past the end: the pad
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // chunk fence.  The arithmetic is pure, so a scheduling barrier alone does not hold it in its chunk: the
+            // chunk's inputs (two logits, the running accumulators) and the previous chunk's results pass through an
+            // empty volatile asm, which pins both ends of every chunk's dependence chains.
+            float l0 = (c < 2) ? accC[0][(2 * c) & 3] : accC[1][(2 * c) & 3];
+            float l1 = (c < 2) ? accC[0][(2 * c + 1) & 3] : accC[1][(2 * c + 1) & 3];
+            if (MF && c > 0) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(prod), "+v"(s_al), "+v"(s_xl), "+v"(accN[0]), "+v"(accN[1]));
+            else asm volatile("" : "+v"(l0), "+v"(l1), "+v"(prod), "+v"(s_al), "+v"(s_xl));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MF) {     // chunk 0 is arithmetic only: it covers the latency of the LDS reads issued just above
+                if (c > 0) {
+#pragma unroll
+                    for (int i = ((c - 1) * NF) / 3; i < (c * NF) / 3; ++i) {
+                        accN[i & 1] = mfma16(av[i % P], bfr[i >> 1], accN[i & 1]);
+                        if (i + P < NF) av[i % P] = *(const uint4*)(lb + (((i + P) >> 1) * 4 + ((i + P) & 1)) * 1024);
+                    }
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * c + jj;
+                const float l = jj ? l1 : l0;
+                const float xm = xm8[j];
+                const float e = exp2_raw(-fabsf(l * LOG2E_F));               // exp(-|l|)
+                const bool in = !MASKED || (f0 + 16 * (j >> 2) + (j & 3) < a.Xdim);
+                s_al += fabsf(l);
+                s_xl = fmaf(xm, l, s_xl);
+                if (KEEP) {
+                    const float ope = 1.0f + e;
+                    prod *= in ? ope : 1.0f;
+                    const float hh = __builtin_copysignf(rcp_fast(ope) - 0.5f, l);    // sigmoid(l) - 1/2
+                    sv[j] = in ? xm - hh : 0.0f;
+                } else {
+                    prod = in ? fmaf(prod, e, prod) : prod;                   // prod * (1 + e) in one instruction
+                }
+            }
+            if (KEEP) asm volatile("" : "+v"(sv[2 * c]), "+v"(sv[2 * c + 1]));
+        }
+        if constexpr (MF) asm volatile("" : "+v"(prod), "+v"(s_al), "+v"(s_xl), "+v"(accN[0]), "+v"(accN[1]));
+        asm volatile("" : "+v"(xn0.x), "+v"(xn0.y), "+v"(xn0.z), "+v"(xn0.w), "+v"(xn1.x), "+v"(xn1.y), "+v"(xn1.z), "+v"(xn1.w));
+        xq[0] = xn0; xq[1] = xn1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (KEEP) sp = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
+        rowacc += s_xl - 0.5f * s_al - LN2_F * log2_raw(prod);
+    };
+
+    wait_all_vmem();
+    __syncthreads();
+    if (2 < H) dma_group(1, 1);
+    {       // half 0: MFMAs only
+        const char* lb = smem + a_off;
+        const char* lbias = smem + KTC * 4096 + q * 16;
+        const float4 c0 = *(const float4*)lbias, c1 = *(const float4*)(lbias + 64);
+        accA[0] = (f32x4){c0.x, c0.y, c0.z, c0.w};
+        accA[1] = (f32x4){c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int i = 0; i < NF; ++i) accA[i & 1] = mfma16(*(const uint4*)(lb + ((i >> 1) * 4 + (i & 1)) * 1024), bfr[i >> 1], accA[i & 1]);
+    }
+
+    // at the top of an odd half: half h+1 opens group gN -- its weights must have landed, and group gN-1's buffer is free
+    // for group gN+1 once every wave is here; the s fragments of the two previous halves go out now (deferred by a group:
+    // a store never sits in front of the next wait)
+    auto boundary = [&](int h, bool domf) {
+        const int gN = (h + 1) >> 1;
+        if (domf) {
+            wait_all_vmem();
+            __syncthreads();
+            if (2 * (gN + 1) < H) dma_group(gN + 1, (gN & 1) ^ 1);
+        }
+        if (h >= 3) store_s(h - 2, st[1]);
+        store_s(h - 1, st[0]);
+    };
+    float4 xbq[2] = {*(const float4*)lxrow, *(const float4*)(lxrow + 16)};
+    const int Hmain = min(a.Xdim >> 5, H - 1) & ~1;      // halves [0, Hmain): all 32 pixels real, a next half to multiply; in pairs
+    int h = 0;
+    for (; h < Hmain; h += 2) {
+        const int buf = (h >> 1) & 1;
+        stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, st[0]);          // MFMAs: tiles 2, 3 of this group
+        {       // boundary(h + 1, true) with st[1] still holding half h - 1
+            wait_all_vmem();
+            __syncthreads();
+            const int gN = (h >> 1) + 1;
+            if (2 * (gN + 1) < H) dma_group(gN + 1, buf);
+            if (h >= 2) store_s(h - 1, st[1]);
+            store_s(h, st[0]);
+        }
+        stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbq, st[1]);   // tiles 0, 1 of the next group
+    }
+    for (; h < H; ++h) {        // the last halves (masked epilogue; the very last one has nothing left to multiply)
+        const int nh = h + 1, bufN = (nh >> 1) & 1, tbN = (nh & 1) * 2;
+        const bool domf = nh < H;
+        if (h & 1) boundary(h, domf);
+        uint4 sp = make_uint4(0, 0, 0, 0);
+        if (domf) {
+            if (h & 1) stage(std::true_type{}, std::true_type{}, accB, accA, h, bufN, tbN, xbq, sp);
+            else stage(std::true_type{}, std::true_type{}, accA, accB, h, bufN, tbN, xbq, sp);
+        } else {
+            if (h & 1) stage(std::true_type{}, std::false_type{}, accB, accA, h, bufN, tbN, xbq, sp);
+            else stage(std::true_type{}, std::false_type{}, accA, accB, h, bufN, tbN, xbq, sp);
+        }
+        if (h & 1) st[1] = sp; else st[0] = sp;
+    }
+    if (H & 1) { if (H >= 2) store_s(H - 2, st[1]); store_s(H - 1, st[0]); }
+    else store_s(H - 1, st[1]);
+
+    float v = rowacc;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (q == 0 && valid) a.lpxz[row] = v;
+}
+
+// ---------------------------------------------------------------------------------
 // out_bwd_kernel: backward of the Bernoulli output layer for one block of rows, logits
 // recomputed on the fly (never stored): per 64-pixel group
 //   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also stored, P-layout, for dV3)
@@ -1975,9 +2177,22 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
     if (a.KT == 4 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 4, 1>), grid, dim3(512), lds, st, a); return true; }
     return false;
 }
+// the pipelined Bernoulli forward exists for the reference's hidden width (7 k-steps), one block owning all pixel groups,
+// and k large enough that a block's 128 rows span <= BERN_XIMG_MAX images
+bool bern_pipe_ok(const DenseArgs& a) {
+    return a.KT == 7 && a.M >= 8192 && a.mg_per_block >= a.MG && !a.logits_out && !a.stamps && a.lpxz_stride == 0 &&
+           (126 + a.k) / a.k + 1 <= BERN_XIMG_MAX && (a.Np32 >> 5) >= 2 && (a.Np32 >> 5) <= 2 * a.MG &&
+           2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128 <= 80 * 1024;
+}
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     dim3 grid((a.M + 127) / 128, (a.MG + a.mg_per_block - 1) / a.mg_per_block);
     const size_t lds = 2 * DENSE_UNIT;
+    if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
+        const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
+        if (a.YP) hipLaunchKernelGGL((bern_pipe_kernel<7, true>), dim3(grid.x), dim3(512), ldsb, st, a);
+        else hipLaunchKernelGGL((bern_pipe_kernel<7, false>), dim3(grid.x), dim3(512), ldsb, st, a);
+        return;
+    }
     if (launch_dense_g1(epi, a, grid, lds, st)) return;
     // compile-time k-step counts for the reference model's shapes (200->224, 100->128, 50->64, head 256)
     switch (a.KT) {

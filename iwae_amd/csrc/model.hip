@@ -136,6 +136,7 @@ struct iwae_model {
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
+    bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
@@ -674,6 +675,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.YP = ptr<uint16_t>(m->wdec1.dlP); a.ldYP = Xp;
         }
         a.logits_out = nullptr;
+        a.pipe = m->allow_bern_pipe ? 1 : 0;
         if (want && want->logits) {
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
@@ -961,6 +963,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
+    m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));

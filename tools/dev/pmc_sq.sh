@@ -15,7 +15,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 done
 python3 - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections
-out = sys.argv[1]; pats = sys.argv[2:] or ["dense_kernel<4", "out_bwd", "dense_kernel<0, 7", "wgradp_kernel<16, true"]
+out = sys.argv[1]; pats = sys.argv[2:] or ["bern_pipe_kernel", "out_bwd", "dense_kernel<0, 7", "wgradp_kernel<16, true"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(out + "/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(fn)):

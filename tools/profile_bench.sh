@@ -31,7 +31,7 @@ for k, c in agg.items():
 json.dump(summ, open(out + "/pmc_per_launch.json", "w"), indent=1, sort_keys=True)
 # gfx950: FETCH_SIZE (KiB) under-reports wide coalesced reads by exactly 2x (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact
 traffic = {}
-for short, pat in (("bernoulli_fwd", "dense_kernel<4"), ("out_bwd", "out_bwd"), ("wgrad_out", "wgradp_kernel<16, true")):
+for short, pat in (("bernoulli_fwd", "bern_pipe_kernel<7, true"), ("out_bwd", "out_bwd"), ("wgrad_out", "wgradp_kernel<16, true")):
     ks = [k for k in summ if pat in k]
     if not ks: continue
     v = summ[ks[0]]
