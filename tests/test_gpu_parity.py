@@ -136,6 +136,27 @@ def test_large_row_count_kernels_match_oracle(gpu):
     m.close()
 
 
+@pytest.mark.parametrize("B,k,xd", [(170, 50, 100), (260, 33, 1000), (2, 5000, 784), (175, 48, 48)])
+def test_pipelined_bernoulli_forward_shapes(gpu, B, k, xd):
+    """bern_pipe_kernel (>= 8 192 rows, hidden 200, k >= 32) beyond the reference's 784 pixels and k = 50: pixel counts whose
+    last 32-pixel half is partial (100 = 3 x 32 + 4) or that fill an even / minimal number of halves (1000 -> 32, 48 -> 2),
+    blocks of 128 rows that straddle images at other k, a ragged last block, and k = 5000 (the test-LLH evaluator's regime:
+    all rows of a block belong to one image).  Both instantiations: forward only (no s kept) and training step (s kept,
+    checked through the gradient it feeds), per-row log p(x|z) against the oracle with the same bf16 rounding points."""
+    nh, nl = 200, 20
+    x, P, eps = MG.inputs(1, nh, nl, xd, B, k, 77 + xd)
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
+    m = _model(1, nh, nl, xd)
+    m.set_params(O.flatten_params(P))
+    r0 = m.forward(x, k, 1.0, eps=eps, want=("lpxz",))
+    assert np.max(np.abs(r0["lpxz"] - res_e["lpxz"])) < EMU_ROW_ATOL
+    r = m.forward_backward(x, k, 1.0, "iwae_elbo", eps=eps, want=("lpxz",))
+    np.testing.assert_allclose(r["lpxz"], r0["lpxz"], rtol=2e-6, atol=1e-4)   # the s-keeping instantiation: same sums, prod*(1+e) as mul vs fma
+    assert abs(r["iwae_elbo"] - res_e["iwae_elbo"]) < EMU_SCALAR_ATOL
+    assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
+    m.close()
+
+
 def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
     """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
     decoder layer making z = mu + sigma*eps itself) against the oracle fed the same draws, restated on the host from the
