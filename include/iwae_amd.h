@@ -129,6 +129,14 @@ int iwae_train_step(iwae_handle h, const float* x, int32_t B, int32_t k, float b
 int iwae_forward_backward(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, int32_t objective,
                           const float* eps, iwae_scalars* scalars, const iwae_tensors* want);
 int iwae_grad_devptr(iwae_handle h, void** dev_ptr, size_t* n);
+/* iwae_forward_backward for a data-parallel step that overlaps its exchange with the backward pass: the gradient of the
+ * decoder's layers -- floats [*side_offset, n) of the flat buffer, final long before the encoder's -- is completed on the
+ * library's side stream (*side_stream, a hipStream_t) and NOT joined into the main stream: the caller orders its
+ * all-reduce of that segment behind *side_stream and of [0, *side_offset) behind the main stream, makes the main stream
+ * wait for both and calls iwae_adam_step.  Models without such a segment return *side_offset = n (nothing left on the
+ * side stream).  No reference counterpart (the reference is single-device, main.py:32). */
+int iwae_forward_backward_split(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, int32_t objective,
+                                const float* eps, void** side_stream, size_t* side_offset);
 int iwae_adam_step(iwae_handle h, float lr, float grad_scale);      /* keras Adam(lr, epsilon=1e-4), main.py:93 */
 /* conditional model (cond_dim > 0): y [n, cond_dim] (host or device) for the NEXT forward / train step / eval_llh / decode
  * of n images -- tasks/task05.py:108-118 (y_onehot), :185-190 (sample(z, y)).  Stays set until replaced. */

@@ -50,6 +50,7 @@ SYMBOLS = {
     "iwae_forward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
     "iwae_train_step": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
     "iwae_forward_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.POINTER(Scalars), C.POINTER(Tensors)]),
+    "iwae_forward_backward_split": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "iwae_grad_devptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "iwae_adam_step": (C.c_int, [_P, C.c_float, C.c_float]),
     "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),

@@ -135,6 +135,7 @@ struct iwae_model {
     // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
+    size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
@@ -737,7 +738,7 @@ float adam_alpha(iwae_model* m, float lr) {      // keras Adam: lr_t = lr * sqrt
 }
 
 // fused_lr >= 0: the optimizer update runs inside the slab reduction (single-GPU train step); < 0: gradient only
-int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
+int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool split = false) {
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "backward without forward");
     const bool two = m->cfg.n_layers == 2;
     const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
@@ -829,11 +830,22 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f) {
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
     if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
-    if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
+    // split (data-parallel step, iwae_forward_backward_split): the decoder's layers are summed into the flat gradient on the
+    // side stream, right behind their weight gradients, and NOT joined here -- the caller's all-reduce of that segment is
+    // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
+    const bool early = split && !fuse && m->early_first > 0 && !two;
+    m->split_offset = m->nparam;
+    if (early) {
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+                            m->vel, 0.0f, 1e-4f, 0, nullptr, 0, 0.f, nullptr, m->side);
+        HIPCHK(hipEventRecord(m->ev_dec, m->side));
+        m->dec_pending = true;
+        m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
+    } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->side));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
-    launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, defer ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+    launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                         alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, ordered behind the main
@@ -1187,6 +1199,19 @@ int iwae_forward_backward(iwae_handle m, const float* x, int32_t B, int32_t k, f
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
     CHK(backward_impl(m, objective));
     CHK(fetch_outputs(m, scalars, want));
+    m->noise_step += 1;
+    return IWAE_OK;
+}
+
+int iwae_forward_backward_split(iwae_handle m, const float* x, int32_t B, int32_t k, float beta, int32_t objective, const float* eps,
+                                void** side_stream, size_t* side_offset) {
+    if (!m || !side_stream || !side_offset) return fail(IWAE_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(check_objective(m, objective));
+    CHK(forward_impl(m, x, B, k, beta, eps, objective, true, nullptr));
+    CHK(backward_impl(m, objective, -1.0f, true));
+    *side_stream = (void*)m->side;
+    *side_offset = m->split_offset;
     m->noise_step += 1;
     return IWAE_OK;
 }

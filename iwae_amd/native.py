@@ -195,6 +195,13 @@ class NativeModel:
         check(self.lib.iwae_forward_backward(self.h, C.c_void_p(x_devptr), int(B), int(k), float(beta), int(objective_id),
                                              None, None, None))
 
+    def forward_backward_split_devptr(self, x_devptr, B, k, beta, objective_id):
+        """iwae_forward_backward_split: returns (side stream handle, first float of the gradient segment completed on it)."""
+        side, off = C.c_void_p(), C.c_size_t()
+        check(self.lib.iwae_forward_backward_split(self.h, C.c_void_p(x_devptr), int(B), int(k), float(beta), int(objective_id),
+                                                   None, C.byref(side), C.byref(off)))
+        return side.value or 0, off.value
+
     def eval_llh(self, x, k=5000, chunk=0, per_image=False):
         x = _f32(x)
         N = x.shape[0]

@@ -209,6 +209,34 @@ def test_kernel_variants_agree(gpu, monkeypatch):
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
 
 
+@pytest.mark.parametrize("B,k", [(170, 50), (20, 5)])
+def test_split_backward_equals_joined_backward(gpu, B, k):
+    """iwae_forward_backward_split (the data-parallel step's entry: decoder gradient completed on the side stream, unjoined,
+    so its all-reduce overlaps the encoder's backward pass) leaves exactly the gradient of iwae_forward_backward, reports the
+    decoder's first tensor as the start of the side segment, and the following Adam step lands on the same parameters."""
+    x = O.synthetic_binarized(B, 31)
+    P = O.init_params(1, 200, 100, 37, x_mean=O.synthetic_pixel_means())
+    outs = []
+    for split in (False, True):
+        m = _model(1, 200, 100)
+        m.set_params(O.flatten_params(P))
+        m.set_step(3, 0)
+        if split:
+            side, off = m.forward_backward_split_devptr(x.ctypes.data, B, k, 1.0, 1)
+            names = [t[0] for t in m.tensor_table()]
+            first_dec = [t for t in m.tensor_table() if t[0].startswith("dec")][0]
+            assert off == first_dec[2], (off, names)
+            assert side != 0
+        else:
+            m.forward_backward(x, k, 1.0, "iwae_elbo")
+        g = m.get_grads().copy()
+        m.adam_step(1e-3, 0.5)
+        outs.append((g, m.get_params().copy()))
+        m.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
     """iwae_train_step leaves the decoder's slab reduction + Adam on the side stream and joins it lazily (before the next
     sampling kernel / any parameter access): scheduling only -- 25 steps with device noise must land on exactly the

@@ -120,7 +120,14 @@ def _dp_worker(rank, world, port, q):
     # each rank: mean-over-its-shard gradient (what iwae_forward_backward leaves on the device)
     _, g = O.loss_grads_1layer(P, x[lo:hi], eps[:, lo:hi], 1.0, "iwae_elbo")
     flat = torch.tensor(O.flatten_grads(g))
+    split = flat.clone()
     parallel.allreduce_sum_(flat)
+    # the overlapped exchange (decoder segment first, then the encoder's): the same sums, message by message
+    parallel.exchange_split_(split, split.numel() // 3, None)
+    assert torch.equal(split, flat)
+    whole = flat.clone()
+    parallel.exchange_split_(whole, whole.numel(), None)      # no side segment: one message
+    assert torch.equal(whole, flat * world)
     flat = flat / world                       # grad_scale = 1/world in iwae_adam_step
     p1, _, _ = O.adam_update(O.flatten_params(P), flat.numpy(), 0.0, 0.0, 1, 1e-3)
     if rank == 0:
