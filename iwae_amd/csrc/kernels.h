@@ -48,6 +48,18 @@ struct DenseArgs {
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
+struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <= 4096 rows
+    const uint16_t* X; int ldX;       // input rows, P-layout [R][32*KT0]
+    const char *img0, *img1, *img2;   // MG-major forward images of l1 (KT0 k-steps), l2 and the head (KT1 k-steps each)
+    int KT0, KT1;
+    int NT1, NT2;                     // stored 16-feature tiles of the hidden layers (= 2*KT1) and of the head (<= 16 each)
+    int R;
+    uint16_t *H1, *H2; int ldH;       // hidden activations, P-layout [R][32*KT1]
+    float* YF; int ldYF; int split;   // head, fp32 [R][ldYF]; out-features >= split are the sigma head
+};
+bool block_fwd_ok(const BlockFwdArgs& a);
+void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st);
+
 struct OutBwdArgs {
     const uint16_t* G2; int ldG;      // last hidden activation, P-layout [M][32*KT]
     const char* img1;                 // MG-major image of W^T (out = pixels, k = hidden)
@@ -143,6 +155,9 @@ struct LayerDesc {
     int rblock_begin;                 // same for the slab-reduce grid (64 elements per block)
 };
 
+// arms a completion event for the NEXT launch_dense / launch_out_bwd / launch_reduce_grads of this thread: it rides on that
+// kernel's dispatch packet (cheaper on both streams than hipEventRecord behind the kernel); consumed by that launch
+void set_launch_stop_event(hipEvent_t e);
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel

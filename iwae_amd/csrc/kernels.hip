@@ -8,6 +8,7 @@
 //                                    tape.gradient(loss, w)   src/iwae1.py:155-159
 //   adam_kernel                      Adam(eps=1e-4)           main.py:93, src/iwae1.py:160
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 #include <algorithm>
@@ -558,6 +559,113 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
         for (int i = 0; i < 8; ++i) a.stamps[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NWV + wave) * 8 + i] = ds_sum[i];
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------
+// block_fwd_kernel: a whole BasicBlock (iwae1.py:36-44: two tanh layers + the mu | sigma head) on a SMALL number of rows --
+// the encoder on the B images of a batch -- in ONE launch.  As three dense_kernel launches this is a chain of
+// latency-bound kernels (B = 1024: 15 + 8 + 5 us on 32 workgroups each); here one 16-wave workgroup owns 16 rows through
+// all three layers:
+//   * wave w owns out-feature tile w (16 features) of every layer (hidden <= 256, head <= 2 x 128: at most 16 tiles);
+//   * weights never touch LDS: each wave reads ITS tile's A fragments straight from the L2-resident image (1 KiB per
+//     wave instruction, coalesced), AD fragments in flight; the second layer's fragments are requested before the first
+//     layer starts and the head's while it finishes.  <= 96 registers: a workgroup (16 waves) leaves a quarter of the CU's
+//     register file to whatever else is resident (the deferred decoder update runs beside the encoder);
+//   * activations (the shared B operand) live in LDS as 1 KiB k-step blocks in the A-image's conflict-free arrangement;
+//     a layer's output goes back there (and to HBM for the backward pass) as bf16, 8 bytes per lane.
+// ---------------------------------------------------------------------------------
+#define BLOCKFWD_MAX_KT 8      // k-steps of the two later layers (hidden <= 256)
+template <int AD>
+__global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int row = r0 + rho;
+    const bool valid = row < a.R;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    char* act0 = smem;                                   // x tile: KT0 blocks
+    char* act1 = smem + (size_t)a.KT0 * 1024;            // h1: KT1 blocks
+    char* act2 = act1 + (size_t)a.KT1 * 1024;            // h2: KT1 blocks
+
+    // stage the x tile (rows beyond R: zeros)
+    for (int c = threadIdx.x; c < a.KT0 * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
+        const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < a.R) v = *(const uint4*)(a.X + (size_t)(r0 + rr) * a.ldX + ks * 32 + qq * 8);
+        *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
+    }
+    // the later layers' weights: requested now, used after the barriers
+    const int mg = wave >> 2, tg = wave & 3;
+    const bool has1 = wave < a.NT1, has2 = wave < a.NT2;
+    const char* w0 = a.img0 + (size_t)mg * img_mg_group_bytes(a.KT0) + tg * 1024 + a_off;
+    const char* w1 = a.img1 + (size_t)mg * img_mg_group_bytes(a.KT1) + tg * 1024 + a_off;
+    const char* w2 = a.img2 + (size_t)mg * img_mg_group_bytes(a.KT1) + tg * 1024 + a_off;
+    uint4 A1[BLOCKFWD_MAX_KT], A2[BLOCKFWD_MAX_KT];
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A1[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT1 && has1) A1[ks] = *(const uint4*)(w1 + (size_t)ks * 4096);
+    }
+    const float4 b0 = has1 ? *(const float4*)(a.img0 + (size_t)mg * img_mg_group_bytes(a.KT0) + (size_t)a.KT0 * 4096 + (16 * tg + 4 * q) * 4) : make_float4(0, 0, 0, 0);
+    const float4 b1 = has1 ? *(const float4*)(a.img1 + (size_t)mg * img_mg_group_bytes(a.KT1) + (size_t)a.KT1 * 4096 + (16 * tg + 4 * q) * 4) : make_float4(0, 0, 0, 0);
+    const float4 b2 = has2 ? *(const float4*)(a.img2 + (size_t)mg * img_mg_group_bytes(a.KT1) + (size_t)a.KT1 * 4096 + (16 * tg + 4 * q) * 4) : make_float4(0, 0, 0, 0);
+
+    // out-feature tile `wave` of a tanh layer -> bf16, 8 bytes per lane: half a k-step fragment of the next layer's operand
+    auto emit_tanh = [&](const f32x4& acc, const float4& b, char* act, uint16_t* YP, int ldY) {
+        const uint2 v = make_uint2(pack2(tanh_fast(acc[0] + b.x), tanh_fast(acc[1] + b.y)), pack2(tanh_fast(acc[2] + b.z), tanh_fast(acc[3] + b.w)));
+        const int ks = wave >> 1, h = wave & 1;
+        *(uint2*)(act + ks * 1024 + a_off + 8 * h) = v;
+        if (valid) *(uint2*)(YP + (size_t)row * ldY + ks * 32 + q * 8 + 4 * h) = v;
+    };
+
+    // ---- layer 1: K = KT0 k-steps, A fragments streamed AD deep
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        uint4 av[AD];
+#pragma unroll
+        for (int i = 0; i < AD; ++i) av[i] = (i < a.KT0 && has1) ? *(const uint4*)(w0 + (size_t)i * 4096) : make_uint4(0, 0, 0, 0);
+        __syncthreads();                         // x tile staged
+        for (int k0 = 0; k0 < a.KT0; k0 += AD) {
+#pragma unroll
+            for (int i = 0; i < AD; ++i) {
+                const int ks = k0 + i;
+                if (ks < a.KT0) {
+                    const uint4 bv = *(const uint4*)(act0 + ks * 1024 + a_off);
+                    acc = mfma16(av[i], bv, acc);
+                    if (ks + AD < a.KT0 && has1) av[i] = *(const uint4*)(w0 + (size_t)(ks + AD) * 4096);
+                }
+            }
+        }
+    }
+    // the head's weights: requested here (the first layer's stream registers are free), used two barriers later
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A2[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT1 && has2) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
+    }
+    if (has1) emit_tanh(acc, b0, act1, a.H1, a.ldH);
+    __syncthreads();
+    // ---- layer 2
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT1) acc = mfma16(A1[ks], *(const uint4*)(act1 + ks * 1024 + a_off), acc);
+    if (has1) emit_tanh(acc, b1, act2, a.H2, a.ldH);
+    __syncthreads();
+    // ---- head: mu | sigma = exp(.) + 1e-6 (iwae1.py:34,42), fp32 natural order
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT1) acc = mfma16(A2[ks], *(const uint4*)(act2 + ks * 1024 + a_off), acc);
+    if (has2 && valid) {
+        const int f0 = 16 * wave + 4 * q;
+        float o[4] = {acc[0] + b2.x, acc[1] + b2.y, acc[2] + b2.z, acc[3] + b2.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (f0 + i >= a.split) o[i] = exp2_raw(o[i] * LOG2E_F) + 1e-6f;
+        *(float4*)(a.YF + (size_t)row * a.ldYF + f0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -2133,17 +2241,31 @@ __global__ void eps_dump_kernel(EpsSrc e, int B, int k, int D, float* out) {   /
 // ---------------------------------------------------------------------------------
 // launch wrappers (plain C++ callers in model.cpp)
 // ---------------------------------------------------------------------------------
+// Completion event riding on a kernel's own dispatch packet (hipExtLaunchKernelGGL stop event) instead of a separate
+// hipEventRecord behind it.  Measured on MI355X (tools/probe/event_latency.hip): the record puts a 5.5-7 us bubble in
+// front of the recording stream's next kernel and the waiting stream starts 12 us after the kernel ended; with the event
+// on the dispatch packet these are 2.2 and 7.6 us, and a join back 6.2 instead of 10.  set_launch_stop_event(e) arms it
+// for the NEXT launch that goes through LAUNCH_EV on this thread.
+static thread_local hipEvent_t g_stop_event = nullptr;
+void set_launch_stop_event(hipEvent_t e) { g_stop_event = e; }
+#define LAUNCH_EV(kern, grid, block, lds, st, ...)                                                        \
+    do {                                                                                                  \
+        hipEvent_t ev_ = g_stop_event;                                                                    \
+        g_stop_event = nullptr;                                                                           \
+        if (ev_) hipExtLaunchKernelGGL(kern, grid, block, lds, st, nullptr, ev_, 0, __VA_ARGS__);         \
+        else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                 \
+    } while (0)
 static inline dim3 grid1(size_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 template <int KTC>
 static void launch_dense_k(int epi, const DenseArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     switch (epi) {
-        case EPI_TANH: hipLaunchKernelGGL((dense_kernel<EPI_TANH, KTC, 2>), grid, dim3(256), lds, st, a); break;
-        case EPI_HEAD: hipLaunchKernelGGL((dense_kernel<EPI_HEAD, KTC, 2>), grid, dim3(256), lds, st, a); break;
-        case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, KTC, 2>), grid, dim3(256), lds, st, a); break;
-        case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, KTC, 2>), grid, dim3(256), lds, st, a); break;
-        case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, KTC, 2>), grid, dim3(256), lds, st, a); break;
-        case EPI_SIGMOID: hipLaunchKernelGGL((dense_kernel<EPI_SIGMOID, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_TANH: LAUNCH_EV((dense_kernel<EPI_TANH, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_HEAD: LAUNCH_EV((dense_kernel<EPI_HEAD, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_DX: LAUNCH_EV((dense_kernel<EPI_DX, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_F32: LAUNCH_EV((dense_kernel<EPI_F32, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_BERN: LAUNCH_EV((dense_kernel<EPI_BERN, KTC, 2>), grid, dim3(256), lds, st, a); break;
+        case EPI_SIGMOID: LAUNCH_EV((dense_kernel<EPI_SIGMOID, KTC, 2>), grid, dim3(256), lds, st, a); break;
     }
 }
 // 8 waves x 16 rows (four waves per SIMD): instantiated for the large-row-count launches of the reference shapes
@@ -2151,31 +2273,38 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
     // K > 256 (the 784-pixel input layer): the window loop is bound by issuing its LDS-DMA pieces and row loads (phase stamps:
     // 37 % issue + 45 % wait, 3 % MFMA at B = 1024) -- eight waves share that issue work
     if (a.KT > 8 && epi == EPI_TANH) {
-        hipLaunchKernelGGL((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), a.stage_all ? 4 * DENSE_UNIT : lds, st, a);
+        LAUNCH_EV((dense_kernel<EPI_TANH, 0, 1>), grid, dim3(512), a.stage_all ? 4 * DENSE_UNIT : lds, st, a);
         return true;
     }
     if (a.zhead) {      // sampled-input mode (host asks for it only where an instantiation exists: 1-layer training step, latent <= 128)
-        if (a.KT == 4) hipLaunchKernelGGL((dense_kernel<EPI_TANH, 4, 1, 8, true>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((dense_kernel<EPI_TANH, 2, 1, 8, true>), grid, dim3(512), lds, st, a);
+        if (a.KT == 4) LAUNCH_EV((dense_kernel<EPI_TANH, 4, 1, 8, true>), grid, dim3(512), lds, st, a);
+        else LAUNCH_EV((dense_kernel<EPI_TANH, 2, 1, 8, true>), grid, dim3(512), lds, st, a);
         return true;
     }
     if (a.M < 8192 || !((a.g1_mask >> epi) & 1u)) return false;
     // the 200 -> 200 tanh layer (d2): 16 waves x 16 rows, one workgroup per CU -- half the LDS-DMA pieces and row loads per
     // wave again, one weight stream per 256 rows (measured: -5 us per step; the other epilogues and the 100 -> 200 layer: no change)
     if (a.KT == 7 && epi == EPI_TANH) {
-        hipLaunchKernelGGL((dense_kernel<EPI_TANH, 7, 1, 16>), dim3((a.M + 255) / 256, grid.y), dim3(1024), lds, st, a);
+        LAUNCH_EV((dense_kernel<EPI_TANH, 7, 1, 16>), dim3((a.M + 255) / 256, grid.y), dim3(1024), lds, st, a);
         return true;
     }
     if (a.KT == 7) {
         switch (epi) {
-            case EPI_DX: hipLaunchKernelGGL((dense_kernel<EPI_DX, 7, 1>), grid, dim3(512), lds, st, a); return true;
-            case EPI_F32: hipLaunchKernelGGL((dense_kernel<EPI_F32, 7, 1>), grid, dim3(512), lds, st, a); return true;
-            case EPI_BERN: hipLaunchKernelGGL((dense_kernel<EPI_BERN, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_DX: LAUNCH_EV((dense_kernel<EPI_DX, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_F32: LAUNCH_EV((dense_kernel<EPI_F32, 7, 1>), grid, dim3(512), lds, st, a); return true;
+            case EPI_BERN: LAUNCH_EV((dense_kernel<EPI_BERN, 7, 1>), grid, dim3(512), lds, st, a); return true;
             default: return false;
         }
     }
-    if (a.KT == 4 && epi == EPI_TANH) { hipLaunchKernelGGL((dense_kernel<EPI_TANH, 4, 1>), grid, dim3(512), lds, st, a); return true; }
+    if (a.KT == 4 && epi == EPI_TANH) { LAUNCH_EV((dense_kernel<EPI_TANH, 4, 1>), grid, dim3(512), lds, st, a); return true; }
     return false;
+}
+bool block_fwd_ok(const BlockFwdArgs& a) {
+    return a.R <= 4096 && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT2 <= 16 && a.NT1 == 2 * a.KT1 &&
+           (size_t)(a.KT0 + 2 * a.KT1) * 1024 <= 150 * 1024;
+}
+void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((block_fwd_kernel<6>), dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KT0 + 2 * a.KT1) * 1024, st, a);
 }
 // the pipelined Bernoulli forward exists for the reference's hidden width (7 k-steps), one block owning all pixel groups,
 // and k large enough that a block's 128 rows span <= BERN_XIMG_MAX images
@@ -2189,8 +2318,8 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     const size_t lds = 2 * DENSE_UNIT;
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
-        if (a.YP) hipLaunchKernelGGL((bern_pipe_kernel<7, true>), dim3(grid.x), dim3(512), ldsb, st, a);
-        else hipLaunchKernelGGL((bern_pipe_kernel<7, false>), dim3(grid.x), dim3(512), ldsb, st, a);
+        if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true>), dim3(grid.x), dim3(512), ldsb, st, a);
+        else LAUNCH_EV((bern_pipe_kernel<7, false>), dim3(grid.x), dim3(512), ldsb, st, a);
         return;
     }
     if (launch_dense_g1(epi, a, grid, lds, st)) return;
@@ -2209,13 +2338,18 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
         const size_t lds = 2 * ((size_t)a.KT * 4096 + 1024);
         const int nparts = a.part ? (a.NG + a.gpb - 1) / a.gpb : 1;
         dim3 grid((a.M + 127) / 128, nparts);
+        hipEvent_t stop = g_stop_event;      // belongs to the LAST kernel of this wrapper
+        if (a.part) g_stop_event = nullptr;
         switch (a.KT) {
-            case 7: hipLaunchKernelGGL(out_bwd_s_kernel<7>, grid, dim3(256), lds, st, a); break;
-            case 4: hipLaunchKernelGGL(out_bwd_s_kernel<4>, grid, dim3(256), lds, st, a); break;
-            case 2: hipLaunchKernelGGL(out_bwd_s_kernel<2>, grid, dim3(256), lds, st, a); break;
+            case 7: LAUNCH_EV(out_bwd_s_kernel<7>, grid, dim3(256), lds, st, a); break;
+            case 4: LAUNCH_EV(out_bwd_s_kernel<4>, grid, dim3(256), lds, st, a); break;
+            case 2: LAUNCH_EV(out_bwd_s_kernel<2>, grid, dim3(256), lds, st, a); break;
             default: return;      // the host only asks for this mode when out_bwd_has_s_mode(KT)
         }
-        if (a.part) hipLaunchKernelGGL(out_bwd_finish_kernel, grid1((size_t)a.M * (a.ldG / 8), 256), dim3(256), 0, st, a, nparts);
+        if (a.part) {
+            g_stop_event = stop;
+            LAUNCH_EV(out_bwd_finish_kernel, grid1((size_t)a.M * (a.ldG / 8), 256), dim3(256), 0, st, a, nparts);
+        }
         return;
     }
     // pair kernel: one W^T image per pixel group, double buffered, + 4 KiB of dl exchange per pair.  Two 4-wave
@@ -2225,16 +2359,16 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     const size_t ldsp = 2 * ((size_t)a.KT * 4096 + 1024) + (size_t)PAIRS * 4096;
     dim3 gridp((a.M + PAIRS * 32 - 1) / (PAIRS * 32));
     if (a.stamps) {   // diagnostic build
-        hipLaunchKernelGGL((out_bwd_pair_kernel<7, PAIRS, true>), gridp, dim3(PAIRS * 128), 2 * ((size_t)7 * 4096 + 1024) + (size_t)PAIRS * 4096, st, a);
+        LAUNCH_EV((out_bwd_pair_kernel<7, PAIRS, true>), gridp, dim3(PAIRS * 128), 2 * ((size_t)7 * 4096 + 1024) + (size_t)PAIRS * 4096, st, a);
         return;
     }
     switch (a.KT) {
-        case 7: hipLaunchKernelGGL((out_bwd_pair_kernel<7, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
-        case 4: hipLaunchKernelGGL((out_bwd_pair_kernel<4, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
-        case 2: hipLaunchKernelGGL((out_bwd_pair_kernel<2, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        case 7: LAUNCH_EV((out_bwd_pair_kernel<7, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        case 4: LAUNCH_EV((out_bwd_pair_kernel<4, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
+        case 2: LAUNCH_EV((out_bwd_pair_kernel<2, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
         default: {   // run-time hidden width: generic 4-wave kernel with both weight images
             const size_t lds = 2 * ((size_t)a.KT * 8192 + 1024);
-            hipLaunchKernelGGL((out_bwd_kernel<0, false>), dim3((a.M + 127) / 128), dim3(256), lds, st, a);
+            LAUNCH_EV((out_bwd_kernel<0, false>), dim3((a.M + 127) / 128), dim3(256), lds, st, a);
         }
     }
 }
@@ -2280,7 +2414,7 @@ void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, 
                          float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
     const AdamCoef c = {alpha, 1.0f, 0.9f, 0.999f, eps, fuse_adam};
     const MeansArgs mn = {per_b, B, beta, scalars};
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
+    LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
 }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);

@@ -137,6 +137,7 @@ struct iwae_model {
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
+    bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
@@ -403,6 +404,19 @@ int block_alloc(iwae_model* m, Linear* blk, BlockWs& w, int R, int Rp, bool bwd,
 }
 
 int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R) {
+    if (m->allow_block_fused) {       // few rows (the encoder on the batch's images): the whole block in one launch
+        BlockFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.X = XP; a.ldX = blk[0].Kp32; a.img0 = blk[0].imgF; a.img1 = blk[1].imgF; a.img2 = blk[2].imgF;
+        a.KT0 = blk[0].KT; a.KT1 = blk[1].KT; a.NT1 = blk[0].Np32 / 16; a.NT2 = blk[2].Np32 / 16; a.R = R;
+        a.H1 = ptr<uint16_t>(w.h1P); a.H2 = ptr<uint16_t>(w.h2P); a.ldH = blk[0].Np32;
+        a.YF = ptr<float>(w.head); a.ldYF = blk[2].Np32; a.split = (blk[2].nsub == 2) ? blk[2].joff[1] : (1 << 30);
+        if (blk[1].Np32 == blk[0].Np32 && blk[2].KT == blk[1].KT && blk[1].Kp32 == blk[0].Np32 && block_fwd_ok(a)) {
+            launch_block_fwd(a, m->stream);
+            HIPCHK(hipGetLastError());
+            return IWAE_OK;
+        }
+    }
     CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, ptr<uint16_t>(w.h1P), nullptr, 0));
     CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, ptr<uint16_t>(w.h2P), nullptr, 0));
     CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, nullptr, ptr<float>(w.head), blk[2].Np32));
@@ -769,22 +783,25 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
-            { ScopedTimer tm(m, 0); launch_out_bwd(a, st); }
+            { ScopedTimer tm(m, 0); set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    HIPCHK(hipEventRecord(m->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
     { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
     CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr));
-    HIPCHK(hipEventRecord(m->ev_fork2, st));
+    set_launch_stop_event(m->ev_fork2);
+    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
+    // ONE event behind both dX kernels (every record costs the main stream a ~6 us bubble): the first decoder layer's weight
+    // gradient needs dpre1 (dX of d2) and sits behind two other weight gradients on the side stream anyway; the deferred
+    // decoder update further down that stream must come after dX of d1, the last reader of the decoder's weight images.
+    // It rides on that kernel's dispatch packet (set_launch_stop_event above).
     CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
     if (!m->user_eps) CHK(draw_eps(m, m->epsc_par ^ 1, m->noise_step + 1, M, m->side));    // next step's noise (speculative)
-    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -836,9 +853,9 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     const bool early = split && !fuse && m->early_first > 0 && !two;
     m->split_offset = m->nparam;
     if (early) {
+        set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, 0.0f, 1e-4f, 0, nullptr, 0, 0.f, nullptr, m->side);
-        HIPCHK(hipEventRecord(m->ev_dec, m->side));
         m->dec_pending = true;
         m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
@@ -848,15 +865,13 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                         alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     if (defer) {
-        // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, ordered behind the main
-        // stream's last kernel of this step -- hence behind dX of d1, the last reader of the decoder's weight images, and
-        // not competing with the encoder's update above -- and joined by the next user of the decoder (join_side):
-        // it runs beside the next step's encoder forward.
-        HIPCHK(hipEventRecord(m->ev_fork3, st));
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork3, 0));
+        // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
+        // (which wait for ev_fork2, i.e. for dX of d1, the last reader of the decoder's weight images -- without that order
+        // the trajectory test caught a stale-image race), joined by the next user of the decoder (join_side): it runs beside
+        // the encoder's backward pass / update and the next step's encoder forward.
+        set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, alpha, 1e-4f, 1, nullptr, 0, 0.f, nullptr, m->side);
-        HIPCHK(hipEventRecord(m->ev_dec, m->side));
         m->dec_pending = true;
     }
     HIPCHK(hipGetLastError());
@@ -976,6 +991,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
+    m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
