@@ -50,6 +50,7 @@ struct DenseArgs {
 
 struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <= 4096 rows
     const uint16_t* X; int ldX;       // input rows, P-layout [R][32*KT0]
+    const float* Xf; int Xdim; uint16_t* XPout;   // or (Xf != null) fp32 rows [R][Xdim], converted on the way in and kept in XPout (P-layout, ldX)
     const char *img0, *img1, *img2;   // MG-major forward images of l1 (KT0 k-steps), l2 and the head (KT1 k-steps each)
     int KT0, KT1;
     int NT1, NT2;                     // stored 16-feature tiles of the hidden layers (= 2*KT1) and of the head (<= 16 each)

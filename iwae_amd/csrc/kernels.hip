@@ -588,11 +588,33 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
     char* act1 = smem + (size_t)a.KT0 * 1024;            // h1: KT1 blocks
     char* act2 = act1 + (size_t)a.KT1 * 1024;            // h2: KT1 blocks
 
-    // stage the x tile (rows beyond R: zeros)
+    // stage the x tile (rows beyond R: zeros).  Xf != null: the rows arrive as fp32 [R][Xdim] (the batch as the caller
+    // handed it over) and are converted here -- prep_rows_kernel's job, without its launch; the bf16 P-layout rows also go
+    // to HBM (XPout) for the kernels that read x later (Bernoulli forward, weight gradient of the first layer).
     for (int c = threadIdx.x; c < a.KT0 * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
         const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + rr < a.R) v = *(const uint4*)(a.X + (size_t)(r0 + rr) * a.ldX + ks * 32 + qq * 8);
+        if (r0 + rr < a.R) {
+            if (a.Xf) {
+                float t[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int f0 = 32 * ks + 16 * h + 4 * qq;
+                    const float* src = a.Xf + (size_t)(r0 + rr) * a.Xdim + f0;
+                    if ((a.Xdim & 3) == 0 && f0 + 3 < a.Xdim) {
+                        const float4 x4 = *(const float4*)src;
+                        t[4 * h] = x4.x; t[4 * h + 1] = x4.y; t[4 * h + 2] = x4.z; t[4 * h + 3] = x4.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) t[4 * h + i] = (f0 + i < a.Xdim) ? src[i] : 0.0f;
+                    }
+                }
+                v = make_uint4(pack2(t[0], t[1]), pack2(t[2], t[3]), pack2(t[4], t[5]), pack2(t[6], t[7]));
+                *(uint4*)(a.XPout + (size_t)(r0 + rr) * a.ldX + ks * 32 + qq * 8) = v;
+            } else {
+                v = *(const uint4*)(a.X + (size_t)(r0 + rr) * a.ldX + ks * 32 + qq * 8);
+            }
+        }
         *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
     }
     // the later layers' weights: requested now, used after the barriers

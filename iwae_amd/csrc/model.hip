@@ -403,7 +403,10 @@ int block_alloc(iwae_model* m, Linear* blk, BlockWs& w, int R, int Rp, bool bwd,
     return IWAE_OK;
 }
 
-int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R) {
+// xf != null: the input rows are still fp32 [R][xdim]; the fused kernel converts them into XP itself (returns *took = true),
+// otherwise the caller runs prep_rows first
+int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R, const float* xf = nullptr, int xdim = 0, bool* took = nullptr) {
+    if (took) *took = false;
     if (m->allow_block_fused) {       // few rows (the encoder on the batch's images): the whole block in one launch
         BlockFwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -412,11 +415,13 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R)
         a.H1 = ptr<uint16_t>(w.h1P); a.H2 = ptr<uint16_t>(w.h2P); a.ldH = blk[0].Np32;
         a.YF = ptr<float>(w.head); a.ldYF = blk[2].Np32; a.split = (blk[2].nsub == 2) ? blk[2].joff[1] : (1 << 30);
         if (blk[1].Np32 == blk[0].Np32 && blk[2].KT == blk[1].KT && blk[1].Kp32 == blk[0].Np32 && block_fwd_ok(a)) {
+            if (xf && took) { a.Xf = xf; a.Xdim = xdim; a.XPout = const_cast<uint16_t*>(XP); *took = true; }
             launch_block_fwd(a, m->stream);
             HIPCHK(hipGetLastError());
             return IWAE_OK;
         }
     }
+    if (xf) return IWAE_OK;      // not taken (*took = false): the caller converts the rows and calls again
     CHK(dense_fwd(m, blk[0], EPI_TANH, XP, R, ptr<uint16_t>(w.h1P), nullptr, 0));
     CHK(dense_fwd(m, blk[1], EPI_TANH, ptr<uint16_t>(w.h1P), R, ptr<uint16_t>(w.h2P), nullptr, 0));
     CHK(dense_fwd(m, blk[2], EPI_HEAD, ptr<uint16_t>(w.h2P), R, nullptr, ptr<float>(w.head), blk[2].Np32));
@@ -578,6 +583,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     }
     if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
     CHK(ensure(m->xP, (size_t)Bp * Xinp * 2, st));
+    const float* xf_pending = nullptr;
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xinp, Bp, m->cfg.seed,
@@ -589,12 +595,22 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(copy_in(m, m->xin, x, (size_t)B * X * 4));
             xd = ptr<float>(m->xin);
         }
-        launch_prep_rows(xd, cond, B, X, m->C, Xinp, Bp, ptr<uint16_t>(m->xP), st);
+        if (m->C == 0 && m->allow_block_fused) xf_pending = xd;      // the fused encoder kernel converts the rows itself
+        else launch_prep_rows(xd, cond, B, X, m->C, Xinp, Bp, ptr<uint16_t>(m->xP), st);
     }
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
     CHK(block_alloc(m, m->enc1, m->wenc1, B, Bp, bwd, false));
-    CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B));
+    if (xf_pending) {
+        bool took = false;
+        CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, xf_pending, X, &took));
+        if (!took) {        // shapes the fused kernel does not cover: convert, then the three-launch path
+            launch_prep_rows(xf_pending, nullptr, B, X, 0, Xinp, Bp, ptr<uint16_t>(m->xP), st);
+            CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B));
+        }
+    } else {
+        CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B));
+    }
 
     for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
     float* lpxz = ptr<float>(m->rows[0]);
