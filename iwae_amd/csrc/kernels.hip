@@ -1480,6 +1480,13 @@ __global__ __launch_bounds__(256) void out_bwd_finish_kernel(OutBwdArgs a, int n
 // permutation is undone for free by which 8-byte piece a lane addresses.  Rows >= M read a zero line.
 // grid = (j-blocks of NW*16 features, i-blocks of 256 features, row splits); fp32 slabs as before.
 // ---------------------------------------------------------------------------------
+// Register blocking: the NW waves form a WI x (NW/WI) grid; a wave owns 16/WI i-tiles x WI j-tiles (16 accumulator tiles
+// either way) and reads 16/WI + WI fragments per 32-row step instead of 16 + 1 -- the transposing LDS reads (2-way bank
+// conflict by construction) were what a 64-row chunk waited for (4 352 LDS cycles per chunk against 2 048 MFMA cycles per
+// SIMD at 16 x 1).  The row-weighted variant scales every G fragment it reads, so it takes the 8 x 2 shape.
+#ifndef WGRAD_WI_SC
+#define WGRAD_WI_SC 2
+#endif
 template <int NW, bool SC>     // SC: G rows carry a per-row weight (a.rowscale), staged through LDS with the tiles
 __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -1491,10 +1498,10 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     typedef __attribute__((ext_vector_type(4))) short v4s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
+    constexpr int WI = SC ? WGRAD_WI_SC : 4, AI = 16 / WI, BJ = WI;
+    const int ig = wave % WI, jg = wave / WI;          // the wave's i-tiles ig*AI .. +AI-1, local j-tiles jg*BJ .. +BJ-1
     const int it0 = by * 16;
     const int nit = min(16, a.IT - it0);
-    const int jt = bx * NW + wave;
-    const bool jvalid = jt < a.JT;
     const int split = bz;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.M, rbeg + a.rows_per_split);
@@ -1526,17 +1533,20 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
         glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * BUF) + (uint32_t)pc * 1024u)));
     };
 
-    f32x4 acc[16];
+    f32x4 acc[AI][BJ];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    float bsum = 0.0f;
+    for (int t = 0; t < AI; ++t)
+#pragma unroll
+        for (int u = 0; u < BJ; ++u) acc[t][u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum[BJ];
+#pragma unroll
+    for (int u = 0; u < BJ; ++u) bsum[u] = 0.0f;
     if (nchunk > 0) {
 #pragma unroll
         for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, 0, idx);
     }
     // lane-constant parts of the transposing-read addresses: row 4q+q' of a 16-row half-step, piece p
     const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
-    const int jl = wave, gslot = ((4 * (jl >> 1)) ^ (qp << 2)) + p;      // G strip: local tile jl -> chunk 4*(jl>>1)+p, half jl&1
 
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
@@ -1549,51 +1559,74 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             ++dma_idx;
         };
         const char* xb = smem + buf * BUF + xrow_off + p * 16;
-        const char* gb = smem + buf * BUF + XT_BYTES + grow_off + gslot * 16 + 8 * (jl & 1);
+        const char* gbase = smem + buf * BUF + XT_BYTES + grow_off;
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
-            // B fragment: 8 data rows (two 4-row blocks) of this wave's 16 G features
-            const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs) * GROW));
-            const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs + 16) * GROW));
-            const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
-            uint4 g = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+            // B fragments: 8 data rows (two 4-row blocks) of each of this wave's BJ j-tiles (local tile jl -> chunk 4*(jl>>1)+p, half jl&1)
+            uint4 g[BJ];
+#pragma unroll
+            for (int u = 0; u < BJ; ++u) {
+                const int jl = jg * BJ + u;
+                const char* gb = gbase + ((((4 * (jl >> 1)) ^ (qp << 2)) + p) * 16) + 8 * (jl & 1);
+                const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs) * GROW));
+                const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs + 16) * GROW));
+                const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
+                g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+            }
             if (SC) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row step (output layer: G = s, weight = dLoss/dlpxz)
                 const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 32 * rs + 4 * q;
                 const float4 s0 = *(const float4*)scl, s1 = *(const float4*)(scl + 16);
-                g = make_uint4(pack2(bflo(g.x) * s0.x, bfhi(g.x) * s0.y), pack2(bflo(g.y) * s0.z, bfhi(g.y) * s0.w),
-                               pack2(bflo(g.z) * s1.x, bfhi(g.z) * s1.y), pack2(bflo(g.w) * s1.z, bfhi(g.w) * s1.w));
+#pragma unroll
+                for (int u = 0; u < BJ; ++u)
+                    g[u] = make_uint4(pack2(bflo(g[u].x) * s0.x, bfhi(g[u].x) * s0.y), pack2(bflo(g[u].y) * s0.z, bfhi(g[u].y) * s0.w),
+                                      pack2(bflo(g[u].z) * s1.x, bfhi(g[u].z) * s1.y), pack2(bflo(g[u].w) * s1.z, bfhi(g[u].w) * s1.w));
             }
-            bsum += bflo(g.x) + bfhi(g.x) + bflo(g.y) + bfhi(g.y) + bflo(g.z) + bfhi(g.z) + bflo(g.w) + bfhi(g.w);
-            lds_pipeline<16, 3>(
-                [&](int i) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
+            if (ig == 0) {       // bias gradient = column sums of G: one wave per j-tile (wave-uniform branch)
+#pragma unroll
+                for (int u = 0; u < BJ; ++u)
+                    bsum[u] += bflo(g[u].x) + bfhi(g[u].x) + bflo(g[u].y) + bfhi(g[u].y) + bflo(g[u].z) + bfhi(g[u].z) + bflo(g[u].w) + bfhi(g[u].w);
+            }
+            lds_pipeline<AI, (AI < 3 ? AI : 3)>(
+                [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
+                    const int i = ig * AI + t;
                     const char* p0 = xb + (32 * rs) * 512 + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
                     const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
                     const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 16 * 512));
                     const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
                     return make_uint4(lo.x, lo.y, hi.x, hi.y);
                 },
-                [&](int i, const uint4& av) { if (i < nit) acc[i] = mfma16(av, g, acc[i]); },
-                [&](int i) { if (i == 0 || i == 8) dma_next(); });
+                [&](int t, const uint4& av) {
+                    if (ig * AI + t < nit) {
+#pragma unroll
+                        for (int u = 0; u < BJ; ++u) acc[t][u] = mfma16(av, g[u], acc[t][u]);
+                    }
+                },
+                [&](int t) { if (t == 0 || (AI > 1 && t == AI / 2)) dma_next(); });
         }
         while (dma_idx < NIDX) dma_next();
     }
 
     // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
-    if (jvalid) {
-        float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+    float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            if (it < nit) {
+    for (int u = 0; u < BJ; ++u) {
+        const int jt = bx * NW + jg * BJ + u;
+        if (jt < a.JT) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-                    slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + l16] = acc[it][ii];
+            for (int t = 0; t < AI; ++t) {
+                const int it = ig * AI + t;
+                if (it < nit) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        slab[(size_t)((it0 + it) * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + l16] = acc[t][u][ii];
+                }
             }
-        }
-        if (by == 0) {
-            float v = bsum;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + l16] = v;
+            if (by == 0 && ig == 0) {
+                float v = bsum[u];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (q == 0) a.slabB[(size_t)split * a.JT * 16 + jt * 16 + l16] = v;
+            }
         }
     }
 }

@@ -111,7 +111,10 @@ struct iwae_model {
     DevBuf ds_data, ds_order;
     int ds_N = 0;
     int wg_target16_1 = 128;   // same, for layers that are a single 16-wave block wide (IWAE_WG16_1)
-    int wg_target16 = 256;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid)
+    int wg_target8 = 256;      // same for the 8-wave launches (small row counts: the encoder's layers) (IWAE_WG8)
+    int wg_target16 = 160;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
+                               // workgroups (128 KB of LDS); 256 of them lock every CU against the dX kernels running beside them on the main
+                               // stream, 160 leave 96 CUs free (measured 256 -> 0.294, 224 -> 0.287, 192 -> 0.280, 160 -> 0.279 ms/step)
     // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling and
     // backward kernels.  A training step draws the NEXT step's noise on the side stream behind its weight gradients
     // (speculating step+1, same batch shape), so the Philox work runs in the shadow of the encoder backward and is
@@ -435,10 +438,11 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     const int chunks = (rows + 63) / 64;
     nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
     const int blocks = ((L.JT + nw - 1) / nw) * ((L.IT + 15) / 16);
-    // one workgroup per CU is the measured optimum for the wide output layer (k=50,B=1024: 64 -> 0.501, 128 -> 0.425,
-    // 256 -> 0.406, 384 -> 0.443, 512 -> 0.455 ms/step): fewer leaves CUs idle, more pays a full fp32 slab (write +
-    // read back) per extra split; the single-block-wide hidden layers run next to other kernels and prefer 128
-    const int target = (nw == 16) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : 256;
+    // Workgroup targets (measured at k=50, B=1024).  Early builds, the weight gradients alone on the machine: 64 -> 0.501,
+    // 128 -> 0.425, 256 -> 0.406, 384 -> 0.443 ms/step (fewer leaves CUs idle, more pays a full fp32 slab per extra split).
+    // Since they run beside the dX chain and with the register-blocked kernel: 160 (see wg_target16); the
+    // single-block-wide hidden layers prefer 128.
+    const int target = (nw == 16) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : m->wg_target8;
     nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
@@ -1009,6 +1013,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
+    if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 

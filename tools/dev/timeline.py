@@ -4,6 +4,7 @@ import csv, glob, sys
 fn = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:58], r["Queue_Id"]) for r in csv.DictReader(open(fn)))
 starts = [i for i, e in enumerate(ev) if "prep_rows" in e[2] or "gather_binarize" in e[2]]
+if len(starts) < 4: starts = [i for i, e in enumerate(ev) if "block_fwd_kernel" in e[2]]      # the fused encoder kernel converts the batch itself
 n = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 i0, i1 = starts[n], starts[n + 1]
 t0 = ev[i0][0]
