@@ -167,7 +167,7 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);
-void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st);
+void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks = 0);   // max_blocks > 0: grid-stride over at most that many blocks
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
 void launch_lse(const LseArgs& a, hipStream_t st);

@@ -1725,13 +1725,17 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
 // The N(0,1) draws of one latent layer for a whole step, fp32 [rows][ld] (4 per thread).  They depend on nothing but
 // the counters, so the host launches this on the side stream at the top of the step: the ~40 quarter-rate integer
 // multiplies per Philox call run in the shadow of the (small, latency-bound) encoder forward.
+// Grid-stride: drawn ahead (a whole step early, beside the forward pass) the launch is a few hundred small blocks that
+// take their time in a corner of every CU; as 5 000 blocks it filled the machine for 11 us and the forward's large
+// workgroups queued behind it.
 __global__ __launch_bounds__(256) void eps_gen_kernel(EpsSrc e, int M, int nd4, int ld, float* out) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)M * nd4) return;
-    const int row = (int)(idx / nd4), d4 = (int)(idx - (size_t)row * nd4);
-    float n[4];
-    normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
-    *(float4*)(out + (size_t)row * ld + 4 * d4) = make_float4(n[0], n[1], n[2], n[3]);
+    const size_t total = (size_t)M * nd4;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int row = (int)(idx / nd4), d4 = (int)(idx - (size_t)row * nd4);
+        float n[4];
+        normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
+        *(float4*)(out + (size_t)row * ld + 4 * d4) = make_float4(n[0], n[1], n[2], n[3]);
+    }
 }
 
 // z = mu + sigma*eps, prior/posterior log-densities, z written bf16 P-layout.
@@ -2452,9 +2456,11 @@ void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start
     hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
                        Bp, seed, epoch, XP, xf);
 }
-void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st) {
+void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks) {
     const int nd4 = (D + 3) / 4;
-    hipLaunchKernelGGL(eps_gen_kernel, grid1((size_t)M * nd4, 256), dim3(256), 0, st, e, M, nd4, ld, out);
+    dim3 grid = grid1((size_t)M * nd4, 256);
+    if (max_blocks > 0 && (int)grid.x > max_blocks) grid.x = max_blocks;
+    hipLaunchKernelGGL(eps_gen_kernel, grid, dim3(256), 0, st, e, M, nd4, ld, out);
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }

@@ -111,6 +111,7 @@ struct iwae_model {
     DevBuf ds_data, ds_order;
     int ds_N = 0;
     int wg_target16_1 = 128;   // same, for layers that are a single 16-wave block wide (IWAE_WG16_1)
+    int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
     int wg_target8 = 256;      // same for the 8-wave launches (small row counts: the encoder's layers) (IWAE_WG8)
     int wg_target16 = 160;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
                                // workgroups (128 KB of LDS); 256 of them lock every CU against the dX kernels running beside them on the main
@@ -120,8 +121,9 @@ struct iwae_model {
     // (speculating step+1, same batch shape), so the Philox work runs in the shadow of the encoder backward and is
     // ordered by the join the main stream performs anyway; a forward whose counters do not match the speculation
     // draws on its own stream first.  Two buffers: the prefetch never overwrites what this step still reads.
-    DevBuf epsc[2][2];          // [parity][layer]
-    struct EpsTag { bool valid = false; uint32_t step = 0; uint64_t row_offset = 0; int M = 0; } eps_tag[2];
+    DevBuf epsc[3][2];          // [ring slot][layer]: the step's draws, the previous step's (its backward may still read them
+                                // when the next step's are requested) and the next step's (drawn during this step's forward)
+    struct EpsTag { bool valid = false; uint32_t step = 0; uint64_t row_offset = 0; int M = 0; } eps_tag[3];
     int epsc_par = 0;
     const float* epsc_ptr[2] = {nullptr, nullptr};
     char* d_zero = nullptr;    // 1 KiB of zeros (wgradp_kernel's source for rows >= M)
@@ -541,7 +543,7 @@ int copy_out(iwae_model* m, void* dst, const void* src, size_t bytes) {
 
 // ---------------------------------------------------------------- the forward pass
 // fills eps buffer `par` with the draws of (step, current batch offset) for M data rows on stream gs
-int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs) {
+int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int max_blocks = 0) {
     const int Mp = round_up(M, 128);
     iwae_model::EpsTag& tg = m->eps_tag[par];
     tg.valid = false;
@@ -549,7 +551,7 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs) {
         CHK(ensure(m->epsc[par][l], (size_t)Mp * m->Dp[l] * 4, m->stream));
         EpsSrc e = eps_src(m, l);
         e.user = nullptr; e.cache = nullptr; e.step = step;
-        launch_eps_gen(e, M, m->D[l], m->Dp[l], ptr<float>(m->epsc[par][l]), gs);
+        launch_eps_gen(e, M, m->D[l], m->Dp[l], ptr<float>(m->epsc[par][l]), gs, max_blocks);
     }
     HIPCHK(hipGetLastError());
     tg.valid = true; tg.step = step; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
@@ -578,10 +580,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     const bool keep_eps = !eps && (bwd || two);
     m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
     if (keep_eps) {
-        const int np = m->epsc_par ^ 1;
+        const int np = (m->epsc_par + 1) % 3;
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
         iwae_model::EpsTag& tg = m->eps_tag[np];
-        if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) CHK(draw_eps(m, np, m->noise_step, M, st));
+        if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
+            CHK(join_side(m));          // a speculative draw into this slot may still be on the side stream
+            if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+            CHK(draw_eps(m, np, m->noise_step, M, st));
+        }
         m->epsc_par = np;
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     }
@@ -628,6 +634,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
+    // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the
+    // side stream, which is idle until the backward pass forks -- behind the weight gradients it sat on the step's critical
+    // tail (the side stream's chain decides when the next decoder forward may start).  Third ring slot: the previous step's
+    // draws may still be read by its backward pass, this step's are in use.
+    if (bwd && keep_eps && m->side) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
     bool fuse_z = false;
     SampleArgs zin;
     memset(&zin, 0, sizeof(zin));
@@ -821,7 +832,6 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
     HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
-    if (!m->user_eps) CHK(draw_eps(m, m->epsc_par ^ 1, m->noise_step + 1, M, m->side));    // next step's noise (speculative)
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -1014,6 +1024,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
+    if (const char* e = getenv("IWAE_EPS_BLOCKS")) m->eps_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 
@@ -1092,7 +1103,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2, &m->wprior};
     for (BlockWs* w : bw) {
