@@ -30,12 +30,15 @@ PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain 
 M_ROWS = B_PER_GPU * K_SAMPLES
 # The two heaviest kernels of the step, both below the roofline ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), i.e. HBM-bound
 # by the model.  Algorithmic bytes per data row (unpadded):
-#   bernoulli_fwd  (bern_pipe_kernel): g2 row in (2H) + x of the image, shared by its k rows (2X/k) + s = x - sigmoid(l)
-#                  out (2X) + log p(x|z) out (4);   FLOP 2HX
+#   bernoulli_fwd  (bern_pipe_kernel<7,true,true>: the WHOLE decoder forward in one launch): the step's draws in (4D) + the image's
+#                  encoder head and x, shared by its k rows ((8D + 2X)/k) + z, g1, g2 out for the backward pass (2D + 2H + 2H) +
+#                  s = x - sigmoid(l) out (2X) + log p(x|z), log p(z), log q(z|x) out (12);   FLOP 2(DH + HH + HX)
 #   out_bwd        (out_bwd_s_kernel): s in (2X) + g2 in (2H) + row weight (4) + dpre2 out (2H);   FLOP 2HX
 KERNELS = {
-    "bernoulli_fwd": {"name": "bern_pipe_kernel<7,true> (decoder output layer + Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
-                      "bytes": M_ROWS * (2 * N_HIDDEN + 2.0 * X_DIM / K_SAMPLES + 2 * X_DIM + 4), "flop": 2 * M_ROWS * N_HIDDEN * X_DIM,
+    "bernoulli_fwd": {"name": "bern_pipe_kernel<7,true,true> (whole decoder forward: z = mu + sigma*eps, two tanh layers, output layer + "
+                              "Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
+                      "bytes": M_ROWS * (4 * N_LATENT + (8.0 * N_LATENT + 2.0 * X_DIM) / K_SAMPLES + 2 * N_LATENT + 4 * N_HIDDEN + 2 * X_DIM + 12),
+                      "flop": 2 * M_ROWS * (N_LATENT * N_HIDDEN + N_HIDDEN * N_HIDDEN + N_HIDDEN * X_DIM),
                       "match": "bern_pipe_kernel"},
     "out_bwd": {"name": "out_bwd_s_kernel<7> (decoder output-layer backward from the stored s)",
                 "bytes": M_ROWS * (2 * X_DIM + 2 * N_HIDDEN + 4 + 2 * N_HIDDEN), "flop": 2 * M_ROWS * N_HIDDEN * X_DIM,

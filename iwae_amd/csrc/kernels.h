@@ -45,6 +45,11 @@ struct DenseArgs {
     float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]
     float* logits_out;
     int pipe;                         // EPI_BERN: take bern_pipe_kernel where it exists (IWAE_NO_BERN_PIPE=1 clears it)
+    // bern_pipe_kernel<.., PRE>: the two tanh layers in front of the output layer run inside the same launch (pre_img1 != null)
+    const char* pre_img1; int pre_KT1;   // first decoder layer: forward image, k-steps of its input (latent, <= 4)
+    const char* pre_img2;                // second decoder layer (KT k-steps in and out)
+    const uint16_t* pre_Z;               // z rows, P-layout [M][32*pre_KT1] (when zhead == null; else z is made in the kernel, see ZIN fields)
+    uint16_t *pre_G1, *pre_G2;           // the layers' activations, P-layout [M][32*KT], kept for the backward pass
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
@@ -161,6 +166,7 @@ struct LayerDesc {
 void set_launch_stop_event(hipEvent_t e);
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
+bool bern_pipe_ok(const DenseArgs& a);  // shapes bern_pipe_kernel covers (launch_dense falls back to dense_kernel<EPI_BERN> otherwise)
 bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
 //   * pad halves beyond Np32 are skipped (800 of 832 padded pixels at X = 784)
 // ---------------------------------------------------------------------------------
 #define BERN_XIMG_MAX 5
-template <int KTC, bool KEEP>
+template <int KTC, bool KEEP, bool PRE>
 __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int UNIT = KTC * 4096 + 1024, NPC = 4 * KTC + 1, NIDX = (NPC + 7) / 8, NF = 2 * KTC, P = 4;
@@ -728,7 +728,27 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
         }
     };
-    dma_group(0, 0);
+    // PRE: the whole decoder in this launch.  The two tanh layers in front of the output layer (iwae1.py:81-82) run first, on
+    // the same 16 rows per wave, operands in registers from layer to layer: z (made here from the encoder head and the step's
+    // draws -- a.zhead -- or read from pre_Z) -> g1 -> g2, each also stored for the backward pass, g2's fragments ARE the
+    // output layer's data operand.  Their weights stream through the same two LDS buffers, one 64-feature group per unit:
+    // units 0..MGH-1 layer 1, MGH..2MGH-1 layer 2, then the output layer's group 0 (an even unit: buffer 0, as below).
+    constexpr int MGH = (2 * KTC + 3) / 4;
+    auto dma_unit = [&](int u, int buf) {
+        const char* src = a.img;
+        int npc = NPC;
+        if (u < MGH) { src = a.pre_img1 + (size_t)u * img_mg_group_bytes(a.pre_KT1); npc = 4 * a.pre_KT1 + 1; }
+        else if (u < 2 * MGH) src = a.pre_img2 + (size_t)(u - MGH) * gbytes;
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) {
+            const int p = wave + 8 * idx;
+            if (p < npc)
+                glds16(src + (size_t)p * 1024 + lane * 16,
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
+        }
+    };
+    if constexpr (PRE) dma_unit(0, 0);
+    else dma_group(0, 0);
     // x of the images of this block's rows -> LDS (the rows of XB are contiguous)
     // x - 1/2 as fp32 (P order, so a lane's 8 values of a half are 32 contiguous bytes): the epilogue reads its operand ready-made
     char* lx = smem + 2 * UNIT;
@@ -745,10 +765,101 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
     }
     const char* lxrow = lx + (size_t)(rowc / a.k - b0) * a.ldXB * 4 + q * 32;     // + 128 bytes per half
     uint4 bfr[KTC];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int ks = 0; ks < KTC; ++ks) {
-        const uint4 v = *(const uint4*)(a.X + (size_t)rowc * a.ldX + ks * 32 + q * 8);
-        bfr[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < KTC; ++ks) {
+            const uint4 v = *(const uint4*)(a.X + (size_t)rowc * a.ldX + ks * 32 + q * 8);
+            bfr[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        const int KT1 = a.pre_KT1, ldZ = 32 * KT1;       // <= 4 k-steps of latent features
+        uint4 zf[4];
+        if (a.zhead) {      // z = mu + sigma*eps of this row, its prior and posterior log-densities (iwae1.py:59,107,109)
+            float lp = 0.0f, lq = 0.0f;
+            const float* hd = a.zhead + (size_t)(rowc / a.k) * a.ldZH;
+            const float* er = a.zeps + (size_t)rowc * a.zDp;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                zf[ks] = make_uint4(0, 0, 0, 0);
+                if (ks < KT1) {
+                    float z8[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int f0 = 32 * ks + 16 * h + 4 * q;
+                        float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = e4, sg4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (f0 < a.zD) {
+                            e4 = *(const float4*)(er + f0);
+                            mu4 = *(const float4*)(hd + f0);
+                            sg4 = *(const float4*)(hd + a.zDp + f0);
+                        }
+                        const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float z = 0.0f;
+                            if (f0 + i < a.zD) {
+                                z = fmaf(sgv[i], ev[i], muv[i]);
+                                lp += -0.5f * z * z - 0.5f * LOG2PI_F;
+                                lq += -0.5f * ev[i] * ev[i] - 0.5f * LOG2PI_F - __logf(sgv[i]);
+                            }
+                            z8[4 * h + i] = z;
+                        }
+                    }
+                    const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+                    zf[ks] = valid ? frag : make_uint4(0, 0, 0, 0);
+                    if (valid) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
+                }
+            }
+            lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+            lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
+            if (q == 0 && valid) { a.zlp[row] = lp; a.zlq[row] = lq; }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                zf[ks] = make_uint4(0, 0, 0, 0);
+                if (ks < KT1) {
+                    const uint4 v = *(const uint4*)(a.pre_Z + (size_t)rowc * ldZ + ks * 32 + q * 8);
+                    zf[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+                }
+            }
+        }
+        // one tanh layer: groups of 64 out-features (4 accumulator tiles), data operand bin[0..KTin), result as the next
+        // layer's operand fragments bout[] (tile pair 2p, 2p+1 of group mg = k-step 2mg + p) and as P-layout rows in Gout
+        uint4 g1f[KTC];
+        auto hidden = [&](auto nb_tag, const uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout) {
+            constexpr int NB = decltype(nb_tag)::value;
+#pragma unroll
+            for (int mg = 0; mg < MGH; ++mg) {
+                const int u = ubase + mg, buf = u & 1;
+                wait_all_vmem();
+                __syncthreads();
+                dma_unit(u + 1, buf ^ 1);          // behind the last unit of layer 2 comes the output layer's group 0
+                const char* lb = smem + buf * UNIT + a_off;
+                const char* lbias = smem + buf * UNIT + KTin * 4096 + q * 16;
+                f32x4 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 c = *(const float4*)(lbias + 64 * t);
+                    acc[t] = (f32x4){c.x, c.y, c.z, c.w};
+                }
+                lds_pipeline<NB * 4, 4>(
+                    [&](int i) { return (i >> 2) < KTin ? *(const uint4*)(lb + i * 1024) : make_uint4(0, 0, 0, 0); },
+                    [&](int i, const uint4& av) { if ((i >> 2) < KTin) acc[i & 3] = mfma16(av, bin[i >> 2], acc[i & 3]); });
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const int kso = 2 * mg + p2;
+                    if (kso < KTC) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
+                        const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                        bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
+                        if (valid) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;
+                    }
+                }
+            }
+        };
+        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1);
+        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2);
     }
 
     f32x4 accA[2], accB[2];      // the two tile pairs swap roles every stage (multiply into one, epilogue from the other)
@@ -2368,6 +2479,7 @@ void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
 // the pipelined Bernoulli forward exists for the reference's hidden width (7 k-steps), one block owning all pixel groups,
 // and k large enough that a block's 128 rows span <= BERN_XIMG_MAX images
 bool bern_pipe_ok(const DenseArgs& a) {
+    if (a.pre_img1 && (a.pre_KT1 < 1 || a.pre_KT1 > 4)) return false;
     return a.KT == 7 && a.M >= 8192 && a.mg_per_block >= a.MG && !a.logits_out && !a.stamps && a.lpxz_stride == 0 &&
            (126 + a.k) / a.k + 1 <= BERN_XIMG_MAX && (a.Np32 >> 5) >= 2 && (a.Np32 >> 5) <= 2 * a.MG &&
            2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128 <= 80 * 1024;
@@ -2377,8 +2489,11 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     const size_t lds = 2 * DENSE_UNIT;
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
-        if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true>), dim3(grid.x), dim3(512), ldsb, st, a);
-        else LAUNCH_EV((bern_pipe_kernel<7, false>), dim3(grid.x), dim3(512), ldsb, st, a);
+        if (a.pre_img1) {       // the whole decoder in one launch
+            if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true>), dim3(grid.x), dim3(512), ldsb, st, a);
+            else LAUNCH_EV((bern_pipe_kernel<7, false, true>), dim3(grid.x), dim3(512), ldsb, st, a);
+        } else if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, false>), dim3(grid.x), dim3(512), ldsb, st, a);
+        else LAUNCH_EV((bern_pipe_kernel<7, false, false>), dim3(grid.x), dim3(512), ldsb, st, a);
         return;
     }
     if (launch_dense_g1(epi, a, grid, lds, st)) return;

@@ -143,6 +143,7 @@ struct iwae_model {
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
+    bool allow_dec_fused = true;     // IWAE_NO_DEC_FUSED=1: the two tanh layers of the decoder stay dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
@@ -694,8 +695,6 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     const int Hp = m->dec1[0].Np32;
     CHK(ensure(w.g1P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.g2P, (size_t)Mp * Hp * 2, st));
-    CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
-    CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
     {
         Linear& L = m->dec1[2];
         DenseArgs a;
@@ -725,6 +724,27 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         if (want && want->logits) {
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
+        }
+        // The whole decoder in one launch (bern_pipe_kernel<.., PRE>) where that kernel exists: the two tanh layers' activations
+        // stay in registers from layer to layer (z made in the kernel when the step runs on the device's noise).
+        bool fuse_dec = false;
+        if (m->allow_dec_fused && a.pipe && m->C == 0 && m->dec1[0].KT <= 4 && m->dec1[0].Kp32 == m->Dp[0] &&
+            m->dec1[0].Np32 == L.Kp32 && m->dec1[1].Kp32 == L.Kp32 && m->dec1[1].Np32 == L.Kp32) {
+            a.pre_img1 = m->dec1[0].imgF; a.pre_KT1 = m->dec1[0].KT; a.pre_img2 = m->dec1[1].imgF;
+            a.pre_Z = ptr<uint16_t>(m->zP[0]); a.pre_G1 = ptr<uint16_t>(w.g1P); a.pre_G2 = ptr<uint16_t>(w.g2P);
+            if (fuse_z) {
+                a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zD = zin.D; a.zDp = zin.Dp;
+                a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq;
+            }
+            fuse_dec = bern_pipe_ok(a);
+            if (!fuse_dec) {
+                a.pre_img1 = a.pre_img2 = nullptr; a.pre_Z = nullptr; a.pre_G1 = a.pre_G2 = nullptr; a.pre_KT1 = 0;
+                a.zhead = nullptr; a.zeps = nullptr; a.ZPout = nullptr; a.zlp = a.zlq = nullptr;
+            }
+        }
+        if (!fuse_dec) {
+            CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
+            CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
             { ScopedTimer tm(m, 1); launch_dense(EPI_BERN, a, st); }
@@ -1022,6 +1042,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
+    m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_EPS_BLOCKS")) m->eps_blocks = std::max(0, atoi(e));
