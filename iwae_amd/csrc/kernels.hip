@@ -2121,7 +2121,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             }
         }
         // the sample loop is latency-bound (3 dependent-free loads, little math): keep UN iterations' loads in flight
-        constexpr int UN = 4;
+        constexpr int UN = 8;
         for (int s0 = sg; s0 < a.k; s0 += UN * SG) {
             float4 dz[UN], cf[UN];
             float e[UN][4];

@@ -183,8 +183,8 @@ def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
 def test_kernel_variants_agree(gpu, monkeypatch):
     """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
     instead of reading the stored s, the 4-wave x 32-row dense shape instead of 8 x 16, the separate sampling kernel
-    instead of the first decoder layer making z itself, and the Bernoulli forward on dense_kernel<EPI_BERN> instead of the
-    software-pipelined bern_pipe_kernel."""
+    instead of the first decoder layer making z itself, the Bernoulli forward on dense_kernel<EPI_BERN> instead of the
+    software-pipelined bern_pipe_kernel, and the decoder's tanh layers / the encoder block as separate launches instead of fused ones."""
     B, k = 170, 50
     x = O.synthetic_binarized(B, 3)
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
@@ -203,7 +203,8 @@ def test_kernel_variants_agree(gpu, monkeypatch):
         return r["iwae_elbo"], g
 
     e0, g0 = run({})
-    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"}):
+    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
+                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
