@@ -900,20 +900,23 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // split (data-parallel step, iwae_forward_backward_split): the decoder's layers are summed into the flat gradient on the
     // side stream, right behind their weight gradients, and NOT joined here -- the caller's all-reduce of that segment is
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
-    const bool early = split && !fuse && m->early_first > 0 && !two;
+    // Without split (iwae_forward_backward: gradient only, e.g. the one-message data-parallel step) the same early decoder
+    // reduction runs on the side stream and the main stream joins it behind its own, shorter, encoder reduction.
+    const bool early = !fuse && m->early_first > 0 && !two;
     m->split_offset = m->nparam;
     if (early) {
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, 0.0f, 1e-4f, 0, nullptr, 0, 0.f, nullptr, m->side);
         m->dec_pending = true;
-        m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
+        if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->side));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                         alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+    if (early && !split) CHK(join_side(m));
     if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
         // (which wait for ev_fork2, i.e. for dX of d1, the last reader of the decoder's weight images -- without that order
