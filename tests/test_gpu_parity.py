@@ -157,6 +157,22 @@ def test_pipelined_bernoulli_forward_shapes(gpu, B, k, xd):
     m.close()
 
 
+@pytest.mark.parametrize("B,k,obj", [(170, 50, "iwae_elbo"), (172, 48, "vae_elbo")])
+def test_two_layer_large_row_count_matches_oracle(gpu, B, k, obj):
+    """The 2-layer model (iwae2.py) at >= 8 192 rows: the per-sample blocks on M rows take the large-row dense shapes and
+    the z1 -> x decoder the one-launch decoder kernel (z1 read from the sampling kernel's rows instead of being made in
+    the kernel); gradients of all 26 tensors against the oracle with the same bf16 rounding points."""
+    nh, nl, xd = [200, 100], [100, 50], 784
+    x, P, eps = MG.inputs(2, nh, nl, xd, B, k, 4321)
+    res_e, g_e = O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, obj, rnd=O.bf16_round)
+    m = _model(2, nh, nl, xd)
+    m.set_params(O.flatten_params(P))
+    r = m.forward_backward(x, k, 1.0, obj, eps=eps)
+    assert abs(r[obj] - res_e[obj]) < EMU_SCALAR_ATOL, (r[obj], res_e[obj])
+    assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
+    m.close()
+
+
 def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
     """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
     decoder layer making z = mu + sigma*eps itself) against the oracle fed the same draws, restated on the host from the
