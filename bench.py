@@ -145,6 +145,16 @@ def main():
     ktimes = {k: net.kernel_time(k) for k in KERNELS}
     net.enable_timing(0)
     elbo = net.forward(x_np[lo:lo + B_PER_GPU], K_SAMPLES)["iwae_elbo"]
+    llh_eval = None
+    if world == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
+        n_eval = 1000
+        net.eval_llh(x_np[:32], 5000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        llh = net.eval_llh(x_np[:n_eval], 5000)
+        dt_eval = time.perf_counter() - t1
+        llh_eval = {"k": 5000, "images": n_eval, "images_per_s": round(n_eval / dt_eval, 1), "llh": round(float(llh), 3),
+                    "note": "forward-only evaluator on synthetic images with the just-trained weights; 10 000 images take %.2f s" % (dt_eval * 10000 / n_eval)}
 
     if rank == 0:
         ms = dt * 1e3 / args.steps
@@ -169,7 +179,7 @@ def main():
                                    + (" + RCCL all-reduce of 455384 fp32 grads" if world > 1 else ""),
                        "global_batch": B_PER_GPU * world, "n_samples": K_SAMPLES, "parallelism": "dp%d" % world,
                        "step_gemm_tflops": round(FLOP_PER_STEP * world / (dt / args.steps) / 1e12, 1),
-                       "iwae_elbo_after": round(float(elbo), 3)},
+                       "iwae_elbo_after": round(float(elbo), 3), "llh_eval_k5000": llh_eval},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom]["name"],
                          "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
