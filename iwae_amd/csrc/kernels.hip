@@ -2579,7 +2579,7 @@ void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
-void launch_lse(const LseArgs& a, hipStream_t st) { hipLaunchKernelGGL(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
+void launch_lse(const LseArgs& a, hipStream_t st) { LAUNCH_EV(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(a.Bp), dim3(256), 0, st, a);
 }

@@ -113,9 +113,10 @@ struct iwae_model {
     int wg_target16_1 = 128;   // same, for layers that are a single 16-wave block wide (IWAE_WG16_1)
     int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
     int wg_target8 = 256;      // same for the 8-wave launches (small row counts: the encoder's layers) (IWAE_WG8)
-    int wg_target16 = 160;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
-                               // workgroups (128 KB of LDS); 256 of them lock every CU against the dX kernels running beside them on the main
-                               // stream, 160 leave 96 CUs free (measured 256 -> 0.294, 224 -> 0.287, 192 -> 0.280, 160 -> 0.279 ms/step)
+    int wg_target16 = 128;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
+                               // workgroups (128 KB of LDS); 256 of them lock every CU against the kernels running beside them on the main
+                               // stream (256 -> 0.294, 192 -> 0.280, 160 -> 0.279 ms/step while the gradient forked behind out_bwd; forked
+                               // behind lse_kernel, beside out_bwd: 96 -> 0.268, 112 -> 0.262, 128 -> 0.258, 144 -> 0.261, 160 -> 0.265)
     // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling and
     // backward kernels.  A training step draws the NEXT step's noise on the side stream behind its weight gradients
     // (speculating step+1, same batch shape), so the Philox work runs in the shadow of the encoder backward and is
@@ -134,6 +135,8 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
+    hipEvent_t ev_lse = nullptr;
+    bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_fork3 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
     // Single-GPU train step: the decoder's slab reduction + Adam (90 % of the slab bytes) stays on the side stream and is
     // NOT joined at the end of the step -- nothing needs the decoder's new weights before the next step's d1 layer, so it
@@ -786,6 +789,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
         a.n_px_part = m->px_parts; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
         if (m->px_parts > 1) a.term[0] = ptr<float>(m->px_part);
+        // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights lse_kernel leaves -- not
+        // out_bwd -- so the side stream forks here (ev_lse on this kernel's dispatch packet), one kernel earlier, and the
+        // gradient runs beside out_bwd (both read s)
+        m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two;
+        if (m->early_wout) set_launch_stop_event(m->ev_lse);
         launch_lse(a, st);
         // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
         if (!bwd) launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
@@ -840,8 +848,14 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
-    { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
+    if (m->early_wout) {     // forked behind lse_kernel (forward_impl): the rest of the side stream's chain waits for out_bwd
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
+        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, ptr<float>(m->gx))); }
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    } else {
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
+        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
+    }
     CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr));
     set_launch_stop_event(m->ev_fork2);
     CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
@@ -1069,6 +1083,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         const int prio = getenv("IWAE_SIDE_PRIO_NORMAL") ? 0 : least;
         HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
     }
+    HIPCHK(hipEventCreateWithFlags(&m->ev_lse, hipEventDisableTiming));
+    m->allow_early_wout = getenv("IWAE_NO_EARLY_WOUT") == nullptr;
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
@@ -1156,6 +1172,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
+    if (m->ev_lse) (void)hipEventDestroy(m->ev_lse);
     if (m->ev_fork3) (void)hipEventDestroy(m->ev_fork3);
     if (m->ev_blk) (void)hipEventDestroy(m->ev_blk);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
