@@ -842,16 +842,16 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
-            { ScopedTimer tm(m, 0); set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
+            // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
+            { ScopedTimer tm(m, 0); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    if (m->early_wout) {     // forked behind lse_kernel (forward_impl): the rest of the side stream's chain waits for out_bwd
+    if (m->early_wout) {     // forked behind lse_kernel (forward_impl)
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
         { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, ptr<float>(m->gx))); }
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
     } else {
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
         { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
@@ -863,8 +863,12 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // gradient needs dpre1 (dX of d2) and sits behind two other weight gradients on the side stream anyway; the deferred
     // decoder update further down that stream must come after dX of d1, the last reader of the decoder's weight images.
     // It rides on that kernel's dispatch packet (set_launch_stop_event above).
+    // Forked early, the side stream is busy with the output layer's gradient until after dX of d1: ONE wait (ev_fork2) then
+    // covers out_bwd (dpre2), dX of d2 (dpre1) and dX of d1, and out_bwd carries no event at all -- one bubble less on the
+    // main stream, one wait less on the side stream.
+    if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
-    HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+    if (!m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
