@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-llh-eval", action="store_true", help="skip the untimed k = 5000 evaluator run (profiling: keeps its kernels out of the statistics)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,7 +147,7 @@ def main():
     net.enable_timing(0)
     elbo = net.forward(x_np[lo:lo + B_PER_GPU], K_SAMPLES)["iwae_elbo"]
     llh_eval = None
-    if world == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
+    if world == 1 and not args.no_llh_eval:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
         n_eval = 1000
         net.eval_llh(x_np[:32], 5000)
         torch.cuda.synchronize()

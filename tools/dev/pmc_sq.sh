@@ -4,7 +4,7 @@
 TAG=${1:-x}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/sq_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-llh-eval"
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS" \

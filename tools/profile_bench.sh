@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline"
+CMD="python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-llh-eval"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace run failed"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || echo "pmc write failed"
