@@ -1834,8 +1834,8 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
 }
 
 // The N(0,1) draws of one latent layer for a whole step, fp32 [rows][ld] (4 per thread).  They depend on nothing but
-// the counters, so the host launches this on the side stream at the top of the step: the ~40 quarter-rate integer
-// multiplies per Philox call run in the shadow of the (small, latency-bound) encoder forward.
+// the counters, so the host launches this a whole step ahead, on the side stream beside the forward pass: the ~40
+// quarter-rate integer multiplies per Philox call are off every dependency chain.
 // Grid-stride: drawn ahead (a whole step early, beside the forward pass) the launch is a few hundred small blocks that
 // take their time in a corner of every CU; as 5 000 blocks it filled the machine for 11 us and the forward's large
 // workgroups queued behind it.

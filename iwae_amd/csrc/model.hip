@@ -117,11 +117,11 @@ struct iwae_model {
                                // workgroups (128 KB of LDS); 256 of them lock every CU against the kernels running beside them on the main
                                // stream (256 -> 0.294, 192 -> 0.280, 160 -> 0.279 ms/step while the gradient forked behind out_bwd; forked
                                // behind lse_kernel, beside out_bwd: 96 -> 0.268, 112 -> 0.262, 128 -> 0.258, 144 -> 0.261, 160 -> 0.265)
-    // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling and
-    // backward kernels.  A training step draws the NEXT step's noise on the side stream behind its weight gradients
-    // (speculating step+1, same batch shape), so the Philox work runs in the shadow of the encoder backward and is
-    // ordered by the join the main stream performs anyway; a forward whose counters do not match the speculation
-    // draws on its own stream first.  Two buffers: the prefetch never overwrites what this step still reads.
+    // N(0,1) draws of a step, fp32 [Mp][Dp] per latent layer, made by eps_gen_kernel and read by the sampling / decoder and
+    // backward kernels.  A training step draws the NEXT step's noise during its forward pass on the side stream, idle then
+    // (speculating step+1, same batch shape); it is ordered by the join the main stream performs anyway, and a forward
+    // whose counters do not match the speculation draws on its own stream first.  Three ring slots: this step's draws, the
+    // previous step's (its backward pass may still read them) and the next step's.
     DevBuf epsc[3][2];          // [ring slot][layer]: the step's draws, the previous step's (its backward may still read them
                                 // when the next step's are requested) and the next step's (drawn during this step's forward)
     struct EpsTag { bool valid = false; uint32_t step = 0; uint64_t row_offset = 0; int M = 0; } eps_tag[3];
