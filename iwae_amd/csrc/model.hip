@@ -137,7 +137,7 @@ struct iwae_model {
     hipStream_t side = nullptr;
     hipEvent_t ev_lse = nullptr;
     bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_fork3 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
     // Single-GPU train step: the decoder's slab reduction + Adam (90 % of the slab bytes) stays on the side stream and is
     // NOT joined at the end of the step -- nothing needs the decoder's new weights before the next step's d1 layer, so it
     // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
@@ -1093,7 +1093,6 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_dec, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_fork3, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_blk, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X + m->C, m->H[0], m->D[0], false);      // tasks/task05.py:113-118 when C > 0
@@ -1177,7 +1176,6 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
     if (m->ev_lse) (void)hipEventDestroy(m->ev_lse);
-    if (m->ev_fork3) (void)hipEventDestroy(m->ev_fork3);
     if (m->ev_blk) (void)hipEventDestroy(m->ev_blk);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
