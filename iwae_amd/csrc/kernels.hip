@@ -706,14 +706,23 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
 //   * pad halves beyond Np32 are skipped (800 of 832 padded pixels at X = 784)
 // ---------------------------------------------------------------------------------
 #define BERN_XIMG_MAX 5
-template <int KTC, bool KEEP, bool PRE>
-__global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
+// QW: one 16-wave workgroup per CU owning 200 rows = 12.5 sixteen-row tiles (51 200 rows = 256 such workgroups: 3.125 tiles per
+// SIMD, no SIMD carries 4).  Waves 0..11 own a full tile each; the half-filled tile 12 belongs to the FOUR waves 12..15
+// (one per SIMD): each runs the tanh layers for it (redundantly; wave 12 stores) and takes one of the four 16-pixel tiles of
+// EVERY 64-pixel group of the output layer, so a SIMD carries 3.25 tile-equivalents of that phase instead of 4.  Their partial
+// log p(x|z) sums meet in LDS.
+template <int KTC, bool KEEP, bool PRE, bool QW = false>
+__global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int UNIT = KTC * 4096 + 1024, NPC = 4 * KTC + 1, NIDX = (NPC + 7) / 8, NF = 2 * KTC, P = 4;
+    constexpr int NWV = QW ? 16 : 8, ROWS = QW ? 200 : 128;
+    constexpr int UNIT = KTC * 4096 + 1024, NPC = 4 * KTC + 1, NIDX = (NPC + NWV - 1) / NWV, NF = 2 * KTC, P = 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int row = (blockIdx.x * 8 + wave) * 16 + rho;
-    const bool valid = row < a.M;
+    const int tile = QW ? min(wave, 12) : wave;
+    const int qw = QW ? wave - 12 : -1;                 // >= 0: one of the four waves sharing tile 12
+    const int row = blockIdx.x * ROWS + tile * 16 + rho;
+    const bool valid = row < a.M && tile * 16 + rho < ROWS;
+    const bool storer = qw <= 0;                          // quarter waves 1..3 recompute tile 12's activations but do not store them
     const int rowc = min(row, a.M - 1);
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     const int H = a.Np32 >> 5;                  // 32-pixel halves that hold real pixels
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
     auto dma_group = [&](int g, int buf) {      // wave w moves pieces w, w+8, ...
 #pragma unroll
         for (int idx = 0; idx < NIDX; ++idx) {
-            const int p = wave + 8 * idx;
+            const int p = wave + NWV * idx;
             if (p < NPC)
                 glds16(a.img + (size_t)g * gbytes + (size_t)p * 1024 + lane * 16,
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
         else if (u < 2 * MGH) src = a.pre_img2 + (size_t)(u - MGH) * gbytes;
 #pragma unroll
         for (int idx = 0; idx < NIDX; ++idx) {
-            const int p = wave + 8 * idx;
+            const int p = wave + NWV * idx;
             if (p < npc)
                 glds16(src + (size_t)p * 1024 + lane * 16,
                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
@@ -752,10 +761,10 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
     // x of the images of this block's rows -> LDS (the rows of XB are contiguous)
     // x - 1/2 as fp32 (P order, so a lane's 8 values of a half are 32 contiguous bytes): the epilogue reads its operand ready-made
     char* lx = smem + 2 * UNIT;
-    const int blk_r0 = blockIdx.x * 128;
-    const int b0 = blk_r0 / a.k, b1 = min(blk_r0 + 127, a.M - 1) / a.k;
+    const int blk_r0 = blockIdx.x * ROWS;
+    const int b0 = blk_r0 / a.k, b1 = min(blk_r0 + ROWS - 1, a.M - 1) / a.k;
     const int xchunks = (b1 - b0 + 1) * a.ldXB / 8;           // 16-byte pieces of bf16 x (the rows of XB are contiguous)
-    for (int o = threadIdx.x; o < xchunks; o += 512) {
+    for (int o = threadIdx.x; o < xchunks; o += 64 * NWV) {
         const uint4 v = *(const uint4*)(a.XB + (size_t)b0 * a.ldXB + (size_t)o * 8);
         float4 lo, hi;
         lo.x = bflo(v.x) - 0.5f; lo.y = bfhi(v.x) - 0.5f; lo.z = bflo(v.y) - 0.5f; lo.w = bfhi(v.y) - 0.5f;
@@ -806,12 +815,12 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
                     }
                     const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
                     zf[ks] = valid ? frag : make_uint4(0, 0, 0, 0);
-                    if (valid) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
+                    if (valid && storer) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
                 }
             }
             lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
             lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
-            if (q == 0 && valid) { a.zlp[row] = lp; a.zlq[row] = lq; }
+            if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -853,7 +862,7 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
                         for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
                         const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
                         bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
-                        if (valid) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;
+                        if (valid && storer) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;
                     }
                 }
             }
@@ -938,18 +947,62 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
         rowacc += s_xl - 0.5f * s_al - LN2_F * log2_raw(prod);
     };
 
+    // MFMAs of one half alone (start of the pipeline)
+    auto mfma_only = [&](int buf, int tb, f32x4 (&acc)[2]) {
+        const char* lb = smem + buf * UNIT + a_off + tb * 1024;
+        const char* lbias = smem + buf * UNIT + KTC * 4096 + tb * 64 + q * 16;
+        const float4 c0 = *(const float4*)lbias, c1 = *(const float4*)(lbias + 64);
+        acc[0] = (f32x4){c0.x, c0.y, c0.z, c0.w};
+        acc[1] = (f32x4){c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+        for (int i = 0; i < NF; ++i) acc[i & 1] = mfma16(*(const uint4*)(lb + ((i >> 1) * 4 + (i & 1)) * 1024), bfr[i >> 1], acc[i & 1]);
+    };
+    // ---- quarter waves (QW): tile qw (16 pixels) of EVERY 64-pixel group, so each SIMD carries the same extra quarter in
+    // every group (the groups are barrier-separated: a quarter wave owning whole groups would make its SIMD the slow one
+    // of each of them).  One pipeline stage per group, placed behind the group boundary: epilogue of tile qw of group g
+    // (4 logits per lane) with the 7 MFMAs of tile qw of group g+1 between its two chunks.
+    // (a quarter wave's accumulator tile lives in LDS between groups: as loop-carried registers it cost the full-tile waves
+    // of the same kernel spills inside their main loop)
+    char* qslot = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + (QW ? max(qw, 0) : 0) * 1024 + lane * 16;
+    auto q_real = [&](int g) { return 64 * g + 16 * qw < a.Np32; };
+    auto q_mfma = [&](int g) {
+        const char* lb = smem + (g & 1) * UNIT + a_off + qw * 1024;
+        const float4 c0 = *(const float4*)(smem + (g & 1) * UNIT + KTC * 4096 + qw * 64 + q * 16);
+        f32x4 acc = (f32x4){c0.x, c0.y, c0.z, c0.w};
+#pragma unroll
+        for (int ks = 0; ks < KTC; ++ks) acc = mfma16(*(const uint4*)(lb + ks * 4096), bfr[ks], acc);
+        *(f32x4*)qslot = acc;
+    };
+    auto q_stage = [&](int g, bool mf) {       // epilogue of group g (its logits wait in qslot); mf: then the MFMAs of group g + 1
+        const int hq = 2 * g + (qw >> 1), sub = qw & 1;
+        const float4 x4 = *(const float4*)(lxrow + hq * 128 + sub * 16);
+        const f32x4 lc = *(const f32x4*)qslot;
+        const int f0 = 64 * g + 16 * qw + 4 * q;
+        const float xm4[4] = {x4.x, x4.y, x4.z, x4.w};
+        float s_xl = 0.0f, s_al = 0.0f, prod = 1.0f, sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float l = lc[j];
+            const float e = exp2_raw(-fabsf(l * LOG2E_F));
+            const bool in = f0 + j < a.Xdim;
+            s_al += fabsf(l);
+            s_xl = fmaf(xm4[j], l, s_xl);
+            const float ope = 1.0f + e;
+            prod *= in ? ope : 1.0f;
+            const float hh = __builtin_copysignf(rcp_fast(ope) - 0.5f, l);
+            sv[j] = in ? xm4[j] - hh : 0.0f;
+        }
+        if (KEEP && valid) *(uint2*)(a.YP + (size_t)row * a.ldYP + 32 * hq + 8 * q + 4 * sub) = make_uint2(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]));
+        rowacc += s_xl - 0.5f * s_al - LN2_F * log2_raw(prod);
+        if (mf) q_mfma(g + 1);
+    };
+    const bool fullw = !QW || qw < 0;
+
     wait_all_vmem();
     __syncthreads();
     if (2 < H) dma_group(1, 1);
-    {       // half 0: MFMAs only
-        const char* lb = smem + a_off;
-        const char* lbias = smem + KTC * 4096 + q * 16;
-        const float4 c0 = *(const float4*)lbias, c1 = *(const float4*)(lbias + 64);
-        accA[0] = (f32x4){c0.x, c0.y, c0.z, c0.w};
-        accA[1] = (f32x4){c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-        for (int i = 0; i < NF; ++i) accA[i & 1] = mfma16(*(const uint4*)(lb + ((i >> 1) * 4 + (i & 1)) * 1024), bfr[i >> 1], accA[i & 1]);
-    }
+    if (fullw) mfma_only(0, 0, accA);      // half 0: MFMAs only
+    else if (q_real(0)) q_mfma(0);
 
     // at the top of an odd half: half h+1 opens group gN -- its weights must have landed, and group gN-1's buffer is free
     // for group gN+1 once every wave is here; the s fragments of the two previous halves go out now (deferred by a group:
@@ -961,29 +1014,38 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
             __syncthreads();
             if (2 * (gN + 1) < H) dma_group(gN + 1, (gN & 1) ^ 1);
         }
-        if (h >= 3) store_s(h - 2, st[1]);
-        store_s(h - 1, st[0]);
+        if (fullw) {
+            if (h >= 3) store_s(h - 2, st[1]);
+            store_s(h - 1, st[0]);
+        }
     };
     float4 xbq[2] = {*(const float4*)lxrow, *(const float4*)(lxrow + 16)};
     const int Hmain = min(a.Xdim >> 5, H - 1) & ~1;      // halves [0, Hmain): all 32 pixels real, a next half to multiply; in pairs
     int h = 0;
     for (; h < Hmain; h += 2) {
         const int buf = (h >> 1) & 1;
-        stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, st[0]);          // MFMAs: tiles 2, 3 of this group
+        if (fullw) stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, st[0]);          // MFMAs: tiles 2, 3 of this group
         {       // boundary(h + 1, true) with st[1] still holding half h - 1
             wait_all_vmem();
             __syncthreads();
             const int gN = (h >> 1) + 1;
             if (2 * (gN + 1) < H) dma_group(gN + 1, buf);
-            if (h >= 2) store_s(h - 1, st[1]);
-            store_s(h, st[0]);
+            if (fullw) {
+                if (h >= 2) store_s(h - 1, st[1]);
+                store_s(h, st[0]);
+            }
         }
-        stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbq, st[1]);   // tiles 0, 1 of the next group
+        if (fullw) stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbq, st[1]);   // tiles 0, 1 of the next group
+        else if (q_real(h >> 1)) q_stage(h >> 1, q_real((h >> 1) + 1));
     }
     for (; h < H; ++h) {        // the last halves (masked epilogue; the very last one has nothing left to multiply)
         const int nh = h + 1, bufN = (nh >> 1) & 1, tbN = (nh & 1) * 2;
         const bool domf = nh < H;
         if (h & 1) boundary(h, domf);
+        if (!fullw) {
+            if ((h & 1) && q_real(h >> 1)) q_stage(h >> 1, domf && q_real((h >> 1) + 1));
+            continue;
+        }
         uint4 sp = make_uint4(0, 0, 0, 0);
         if (domf) {
             if (h & 1) stage(std::true_type{}, std::true_type{}, accB, accA, h, bufN, tbN, xbq, sp);
@@ -994,12 +1056,24 @@ __global__ __launch_bounds__(512, 4) void bern_pipe_kernel(DenseArgs a) {
         }
         if (h & 1) st[1] = sp; else st[0] = sp;
     }
-    if (H & 1) { if (H >= 2) store_s(H - 2, st[1]); store_s(H - 1, st[0]); }
-    else store_s(H - 1, st[1]);
+    if (fullw) {
+        if (H & 1) { if (H >= 2) store_s(H - 2, st[1]); store_s(H - 1, st[0]); }
+        else store_s(H - 1, st[1]);
+    } else if ((H & 1) && q_real((H - 1) >> 1)) {
+        q_stage((H - 1) >> 1, false);       // the last group opened at an even half: its epilogue is still due
+    }
 
     float v = rowacc;
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
+    if constexpr (QW) {         // tile 12: the four quarter waves' sums, added in wave order
+        __syncthreads();        // (every wave is past its last LDS read: buffer 0 is free)
+        float* part = (float*)smem;
+        if (qw >= 0 && q == 0) part[qw * 16 + rho] = v;
+        __syncthreads();
+        if (qw == 0) v = part[rho] + part[16 + rho] + part[32 + rho] + part[48 + rho];
+        if (qw > 0) return;
+    }
     if (q == 0 && valid) a.lpxz[row] = v;
 }
 
@@ -2489,7 +2563,11 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     const size_t lds = 2 * DENSE_UNIT;
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
-        if (a.pre_img1) {       // the whole decoder in one launch
+        if (a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8) {       // 16-wave / 200-row shape (see QW)
+            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096;
+            if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
+            else LAUNCH_EV((bern_pipe_kernel<7, false, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
+        } else if (a.pre_img1) {       // the whole decoder in one launch
             if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true>), dim3(grid.x), dim3(512), ldsb, st, a);
             else LAUNCH_EV((bern_pipe_kernel<7, false, true>), dim3(grid.x), dim3(512), ldsb, st, a);
         } else if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, false>), dim3(grid.x), dim3(512), ldsb, st, a);

@@ -146,6 +146,8 @@ struct iwae_model {
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
+    int num_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    bool bern_qw = true;             // IWAE_NO_BERN_QW=1: the decoder kernel's 8-wave / 128-row shape instead of 16 waves / 200 rows (A/B measurements)
     bool allow_dec_fused = true;     // IWAE_NO_DEC_FUSED=1: the two tanh layers of the decoder stay dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
@@ -724,6 +726,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         }
         a.logits_out = nullptr;
         a.pipe = m->allow_bern_pipe ? 1 : 0;
+        if (a.pipe && m->bern_qw) {      // the 16-wave / 200-row shape is one workgroup per CU: only where its last round is nearly full
+            const int nwg = (M + 199) / 200, ncu = std::max(1, m->num_cus);
+            const int rounds = (nwg + ncu - 1) / ncu;
+            if ((double)nwg >= 0.9 * (double)rounds * ncu) a.pipe = 2;
+        }
         if (want && want->logits) {
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
             a.logits_out = ptr<float>(m->scratch);
@@ -1064,6 +1071,11 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
+    m->bern_qw = getenv("IWAE_NO_BERN_QW") == nullptr;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) m->num_cus = ncu;
+    }
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_EPS_BLOCKS")) m->eps_blocks = std::max(0, atoi(e));
