@@ -834,8 +834,12 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         // one tanh layer: groups of 64 out-features (4 accumulator tiles), data operand bin[0..KTin), result as the next
         // layer's operand fragments bout[] (tile pair 2p, 2p+1 of group mg = k-step 2mg + p) and as P-layout rows in Gout
         uint4 g1f[KTC];
-        auto hidden = [&](auto nb_tag, const uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout) {
+        // Quarter waves (QW) take tile qw of every 64-feature group of BOTH layers for the shared tile 12 -- the units are
+        // barrier-separated, so only a per-unit split keeps the four SIMDs level -- and exchange the 8-byte fragment halves
+        // through LDS (xch_out; read back as whole fragments behind the next layer's first barrier: xch_in).
+        auto hidden = [&](auto nb_tag, uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout, const char* xch_in, char* xch_out) {
             constexpr int NB = decltype(nb_tag)::value;
+            const bool quarter = QW && qw >= 0;
 #pragma unroll
             for (int mg = 0; mg < MGH; ++mg) {
                 const int u = ubase + mg, buf = u & 1;
@@ -844,6 +848,24 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                 dma_unit(u + 1, buf ^ 1);          // behind the last unit of layer 2 comes the output layer's group 0
                 const char* lb = smem + buf * UNIT + a_off;
                 const char* lbias = smem + buf * UNIT + KTin * 4096 + q * 16;
+                if (quarter) {
+                    if (mg == 0 && xch_in) {
+#pragma unroll
+                        for (int ks = 0; ks < NB; ++ks) bin[ks] = *(const uint4*)(xch_in + ks * 1024 + lane * 16);
+                    }
+                    const float4 c = *(const float4*)(lbias + 64 * qw);
+                    f32x4 acc1 = (f32x4){c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int ks = 0; ks < NB; ++ks)
+                        if (ks < KTin) acc1 = mfma16(*(const uint4*)(lb + (ks * 4 + qw) * 1024), bin[ks], acc1);
+                    const int ft = 4 * mg + qw, kso = ft >> 1, hh = ft & 1;
+                    if (kso < KTC) {
+                        const uint2 piece = make_uint2(pack2(tanh_fast(acc1[0]), tanh_fast(acc1[1])), pack2(tanh_fast(acc1[2]), tanh_fast(acc1[3])));
+                        *(uint2*)(xch_out + kso * 1024 + lane * 16 + 8 * hh) = valid ? piece : make_uint2(0, 0);
+                        if (valid) *(uint2*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8 + 4 * hh) = piece;
+                    }
+                    continue;
+                }
                 f32x4 acc[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -867,8 +889,10 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                 }
             }
         };
-        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1);
-        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2);
+        char* xch1 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096;      // g1 / g2 of the shared tile: 7 KiB each
+        char* xch2 = xch1 + KTC * 1024;
+        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1);
+        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2, xch1, xch2);
     }
 
     f32x4 accA[2], accB[2];      // the two tile pairs swap roles every stage (multiply into one, epilogue from the other)
@@ -1001,6 +1025,13 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     wait_all_vmem();
     __syncthreads();
     if (2 < H) dma_group(1, 1);
+    if constexpr (PRE && QW) {
+        if (qw >= 0) {      // the shared tile's g2 fragments, assembled from the four quarter waves' pieces
+            const char* xch2 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096 + KTC * 1024;
+#pragma unroll
+            for (int ks = 0; ks < KTC; ++ks) bfr[ks] = *(const uint4*)(xch2 + ks * 1024 + lane * 16);
+        }
+    }
     if (fullw) mfma_only(0, 0, accA);      // half 0: MFMAs only
     else if (q_real(0)) q_mfma(0);
 
@@ -2564,7 +2595,7 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
         if (a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8) {       // 16-wave / 200-row shape (see QW)
-            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096;
+            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024;
             if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
             else LAUNCH_EV((bern_pipe_kernel<7, false, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
         } else if (a.pre_img1) {       // the whole decoder in one launch
