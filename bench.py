@@ -35,7 +35,7 @@ M_ROWS = B_PER_GPU * K_SAMPLES
 #                  s = x - sigmoid(l) out (2X) + log p(x|z), log p(z), log q(z|x) out (12);   FLOP 2(DH + HH + HX)
 #   out_bwd        (out_bwd_s_kernel): s in (2X) + g2 in (2H) + row weight (4) + dpre2 out (2H);   FLOP 2HX
 KERNELS = {
-    "bernoulli_fwd": {"name": "bern_pipe_kernel<7,true,true> (whole decoder forward: z = mu + sigma*eps, two tanh layers, output layer + "
+    "bernoulli_fwd": {"name": "bern_pipe_kernel<7,true,true,true> (whole decoder forward, 16-wave / 200-row workgroups: z = mu + sigma*eps, two tanh layers, output layer + "
                               "Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
                       "bytes": M_ROWS * (4 * N_LATENT + (8.0 * N_LATENT + 2.0 * X_DIM) / K_SAMPLES + 2 * N_LATENT + 4 * N_HIDDEN + 2 * X_DIM + 12),
                       "flop": 2 * M_ROWS * (N_LATENT * N_HIDDEN + N_HIDDEN * N_HIDDEN + N_HIDDEN * X_DIM),
