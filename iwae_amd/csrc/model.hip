@@ -147,6 +147,7 @@ struct iwae_model {
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
     int num_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    bool bern_qw_force = false;      // IWAE_BERN_QW_FORCE=1: that shape at every row count it exists for (tests)
     bool bern_qw = true;             // IWAE_NO_BERN_QW=1: the decoder kernel's 8-wave / 128-row shape instead of 16 waves / 200 rows (A/B measurements)
     bool allow_dec_fused = true;     // IWAE_NO_DEC_FUSED=1: the two tanh layers of the decoder stay dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
@@ -729,7 +730,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         if (a.pipe && m->bern_qw) {      // the 16-wave / 200-row shape is one workgroup per CU: only where its last round is nearly full
             const int nwg = (M + 199) / 200, ncu = std::max(1, m->num_cus);
             const int rounds = (nwg + ncu - 1) / ncu;
-            if ((double)nwg >= 0.9 * (double)rounds * ncu) a.pipe = 2;
+            if ((double)nwg >= 0.9 * (double)rounds * ncu || m->bern_qw_force) a.pipe = 2;
         }
         if (want && want->logits) {
             CHK(ensure(m->scratch, (size_t)M * X * 4, st));
@@ -1072,6 +1073,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
     m->bern_qw = getenv("IWAE_NO_BERN_QW") == nullptr;
+    m->bern_qw_force = getenv("IWAE_BERN_QW_FORCE") != nullptr;
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) m->num_cus = ncu;

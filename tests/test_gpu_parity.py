@@ -136,8 +136,9 @@ def test_large_row_count_kernels_match_oracle(gpu):
     m.close()
 
 
+@pytest.mark.parametrize("force_qw", [False, True])
 @pytest.mark.parametrize("B,k,xd", [(170, 50, 100), (260, 33, 1000), (2, 5000, 784), (175, 48, 48)])
-def test_pipelined_bernoulli_forward_shapes(gpu, B, k, xd):
+def test_pipelined_bernoulli_forward_shapes(gpu, monkeypatch, B, k, xd, force_qw):
     """bern_pipe_kernel (>= 8 192 rows, hidden 200, k >= 32) beyond the reference's 784 pixels and k = 50: pixel counts whose
     last 32-pixel half is partial (100 = 3 x 32 + 4) or that fill an even / minimal number of halves (1000 -> 32, 48 -> 2),
     blocks of 128 rows that straddle images at other k, a ragged last block, and k = 5000 (the test-LLH evaluator's regime:
@@ -146,7 +147,12 @@ def test_pipelined_bernoulli_forward_shapes(gpu, B, k, xd):
     nh, nl = 200, 20
     x, P, eps = MG.inputs(1, nh, nl, xd, B, k, 77 + xd)
     res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
+    # force_qw: the 16-wave / 200-row workgroup shape (12 full-tile waves + four waves sharing the 13th tile), which the
+    # library otherwise takes only where its workgroups fill the machine's CUs evenly (the full-size benchmark shape)
+    if force_qw:
+        monkeypatch.setenv("IWAE_BERN_QW_FORCE", "1")
     m = _model(1, nh, nl, xd)
+    monkeypatch.delenv("IWAE_BERN_QW_FORCE", raising=False)
     m.set_params(O.flatten_params(P))
     r0 = m.forward(x, k, 1.0, eps=eps, want=("lpxz",))
     assert np.max(np.abs(r0["lpxz"] - res_e["lpxz"])) < EMU_ROW_ATOL
@@ -220,7 +226,7 @@ def test_kernel_variants_agree(gpu, monkeypatch):
 
     e0, g0 = run({})
     for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
-                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_NO_BERN_QW": "1"}):
+                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
