@@ -41,21 +41,33 @@ typedef enum {
     IWAE_OBJ_DREG = 4          /* tasks/task02.py:61-101 (1-layer only) */
 } iwae_objective;
 
-/* iwae1.IWAE(n_hidden, n_latent) src/iwae1.py:89-96 / iwae2.IWAE(n_hidden[2], n_latent[2]) src/iwae2.py:100-107 */
+/* arithmetic of the GEMMs.  The reference computes everything in float32 (Keras Dense defaults, src/iwae1.py:31-34,72-75);
+ * BASELINE.json configs[1] asks for bf16 operands. */
+typedef enum {
+    IWAE_PREC_BF16 = 0,        /* bf16 GEMM operands, fp32 accumulation (v_mfma_f32_16x16x32_bf16): the fast training path */
+    IWAE_PREC_FP32 = 1         /* exact float32 GEMMs (v_mfma_f32_16x16x4_f32): every product as the reference's float32 graph */
+} iwae_precision;
+
+/* iwae1.IWAE(n_hidden, n_latent) src/iwae1.py:89-96 / iwae2.IWAE(n_hidden[2], n_latent[2]) src/iwae2.py:100-107.
+ * struct_size MUST be set to sizeof(iwae_config) by the caller: iwae_create rejects any other value, so a binding
+ * compiled against an older or newer layout fails loudly instead of reading past its struct. */
 typedef struct {
+    uint32_t struct_size;      /* = sizeof(iwae_config) (64); ABI guard */
     int32_t n_layers;          /* 1 or 2 stochastic layers (main.py:17) */
     int32_t n_hidden[2];       /* main.py:86,90 : {200} / {200,100}; each <= 256 */
     int32_t n_latent[2];       /* main.py:85,89 : {100} / {100,50};  each <= 128 */
     int32_t x_dim;             /* 784 */
     int32_t device;            /* HIP device ordinal */
     uint64_t seed;             /* Philox key for the reparameterisation noise (main.py:40-41 seeds TF) */
-    int32_t world_size;        /* data-parallel ranks (1 = single GPU) */
-    int32_t rank;
+    int32_t world_size;        /* data-parallel ranks (1 = single GPU); iwae_comm_init must be given the same values */
+    int32_t rank;              /* this process's rank: images [rank*B, (rank+1)*B) of every global batch (noise keys) */
     int32_t cond_dim;          /* 0, or C > 0: the conditional model of tasks/task05.py:101-168 (1-layer only): the encoder
                                   sees concat(x, y), the decoder concat(z, y), y [B, C] set with iwae_set_condition
                                   (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
     int32_t cond_prior;        /* with cond_dim > 0: 1 = the learned conditional prior p(z|y) of tasks/task04.py:101-173 (a BasicBlock on y,
                                   created after the decoder) replaces N(0,1) in lpz; sample(z, y) maps z through it (:190-196) */
+    int32_t precision;         /* iwae_precision of train / forward calls (iwae_eval_llh always evaluates in float32) */
+    int32_t reserved;          /* 0 */
 } iwae_config;
 
 /* scalar entries of the result dict (src/iwae1.py:141-144, tasks/task02.py:78-79) and the
@@ -138,6 +150,10 @@ int iwae_grad_devptr(iwae_handle h, void** dev_ptr, size_t* n);
 int iwae_forward_backward_split(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, int32_t objective,
                                 const float* eps, void** side_stream, size_t* side_offset);
 int iwae_adam_step(iwae_handle h, float lr, float grad_scale);      /* keras Adam(lr, epsilon=1e-4), main.py:93 */
+/* keras.optimizers.Adam(learning_rate, beta_1, beta_2, epsilon) hyper-parameters of this handle's optimizer; the default
+ * is what the reference trains with: Adam(lr, epsilon=1e-4) = (0.9, 0.999, 1e-4), main.py:93.  Keras form: epsilon is
+ * added to sqrt(v) outside the bias correction. */
+int iwae_set_adam(iwae_handle h, float beta_1, float beta_2, float epsilon);
 /* conditional model (cond_dim > 0): y [n, cond_dim] (host or device) for the NEXT forward / train step / eval_llh / decode
  * of n images -- tasks/task05.py:108-118 (y_onehot), :185-190 (sample(z, y)).  Stays set until replaced. */
 int iwae_set_condition(iwae_handle h, const float* y, int32_t n);

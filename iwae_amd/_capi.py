@@ -7,12 +7,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libiwae_amd.so")
 
 OBJECTIVES = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "dreg": 4}
+PRECISIONS = {"bf16": 0, "fp32": 1}
 
 
 class Config(C.Structure):
-    _fields_ = [("n_layers", C.c_int32), ("n_hidden", C.c_int32 * 2), ("n_latent", C.c_int32 * 2),
+    _fields_ = [("struct_size", C.c_uint32), ("n_layers", C.c_int32), ("n_hidden", C.c_int32 * 2), ("n_latent", C.c_int32 * 2),
                 ("x_dim", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
-                ("world_size", C.c_int32), ("rank", C.c_int32), ("cond_dim", C.c_int32), ("cond_prior", C.c_int32)]
+                ("world_size", C.c_int32), ("rank", C.c_int32), ("cond_dim", C.c_int32), ("cond_prior", C.c_int32),
+                ("precision", C.c_int32), ("reserved", C.c_int32)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(Config)       # the ABI guard iwae_create checks
 
 
 class Scalars(C.Structure):
@@ -53,6 +59,7 @@ SYMBOLS = {
     "iwae_forward_backward_split": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "iwae_grad_devptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "iwae_adam_step": (C.c_int, [_P, C.c_float, C.c_float]),
+    "iwae_set_adam": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "iwae_eval_llh": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), _P]),
     "iwae_decode": (C.c_int, [_P, _P, C.c_int32, _P]),

@@ -46,9 +46,11 @@ class BaseIWAE:
     n_layers = 1
     scalar_keys = ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14")
 
-    def __init__(self, n_hidden, n_latent, x_dim=784, seed=123, device=0, output_bias=None, cond_dim=0, cond_prior=False, **kwargs):
+    def __init__(self, n_hidden, n_latent, x_dim=784, seed=123, device=0, output_bias=None, cond_dim=0, cond_prior=False,
+                 precision="bf16", world_size=1, rank=0, **kwargs):
         self._net = NativeModel(self.n_layers, n_hidden, n_latent, x_dim=x_dim, device=device, seed=seed, cond_dim=cond_dim,
-                                cond_prior=cond_prior)
+                                cond_prior=cond_prior, precision=precision, world_size=world_size, rank=rank)
+        self._adam_hyper = (0.9, 0.999, 1e-4)      # the device optimizer's defaults (main.py:93)
         if output_bias is not None:
             self._net.set_output_bias(output_bias)
         self._table = self._net.tensor_table()
@@ -116,9 +118,17 @@ class BaseIWAE:
     def val_step(self, x, n_samples, beta, outputs=None):
         return self.call(x, n_samples, beta, outputs=outputs)
 
+    def _bind_optimizer(self, optimizer):
+        """Hand the Keras-style optimizer's (beta_1, beta_2, epsilon) to the device optimizer when they change."""
+        hyper = optimizer.hyper() if hasattr(optimizer, "hyper") else self._adam_hyper
+        if hyper != self._adam_hyper:
+            self._net.set_adam(*hyper)
+            self._adam_hyper = hyper
+
     def train_step(self, x, n_samples, beta, optimizer, objective="vae_elbo", outputs=None, eps=None):
         if objective not in self.scalar_keys:
             raise KeyError(objective)          # res[objective] in the reference (src/iwae1.py:157)
+        self._bind_optimizer(optimizer)
         raw = self._net.train_step(np.asarray(x, dtype=np.float32), int(n_samples), float(beta),
                                    float(optimizer.learning_rate), objective, eps=eps, want=self._want(outputs))
         optimizer.iterations += 1
@@ -139,6 +149,7 @@ class BaseIWAE:
     def train_step_dataset(self, start, batch_size, n_samples, beta, optimizer, objective="vae_elbo"):
         if objective not in self.scalar_keys and objective != "dreg":
             raise KeyError(objective)
+        self._bind_optimizer(optimizer)
         raw = self._net.train_step_dataset(start, batch_size, int(n_samples), float(beta), float(optimizer.learning_rate), objective)
         optimizer.iterations += 1
         res = {k: as_tensor(raw[k]) for k in self.scalar_keys if k in raw}

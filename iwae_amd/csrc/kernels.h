@@ -183,10 +183,10 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
 // per_b != null: one extra block turns the per-image values into the batch means (scalars) of the step.
 // fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread.
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
-                 float alpha, float gscale, float eps, int do_update, hipStream_t st);
+                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st);
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st);
 void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st);
 void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st);

@@ -2696,8 +2696,8 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
 }
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
-    const AdamCoef c = {alpha, 1.0f, 0.9f, 0.999f, eps, fuse_adam};
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
+    const AdamCoef c = {alpha, 1.0f, beta1, beta2, eps, fuse_adam};
     const MeansArgs mn = {per_b, B, beta, scalars};
     LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
 }
@@ -2705,8 +2705,8 @@ void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
 }
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
-                 float alpha, float gscale, float eps, int do_update, hipStream_t st) {
-    const AdamCoef c = {alpha, gscale, 0.9f, 0.999f, eps, do_update};
+                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st) {
+    const AdamCoef c = {alpha, gscale, beta1, beta2, eps, do_update};
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, c);
 }
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st) {

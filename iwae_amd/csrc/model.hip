@@ -10,13 +10,15 @@
 #include <string>
 #include <vector>
 #include <random>
+#include <memory>
 #include "../../include/iwae_amd.h"
 #include "kernels.h"
 #include "layout.h"
 
 using namespace iwae;
 
-static_assert(sizeof(iwae_config) == 56 && offsetof(iwae_config, seed) == 32 && offsetof(iwae_config, cond_dim) == 48 && offsetof(iwae_config, cond_prior) == 52, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
+static_assert(sizeof(iwae_config) == 64 && offsetof(iwae_config, struct_size) == 0 && offsetof(iwae_config, seed) == 32 && offsetof(iwae_config, cond_dim) == 48 &&
+              offsetof(iwae_config, cond_prior) == 52 && offsetof(iwae_config, precision) == 56, "iwae_config layout is part of the ABI (iwae_amd/_capi.py)");
 static_assert(sizeof(iwae_scalars) == 64 && sizeof(iwae_tensors) == 12 * sizeof(void*), "ABI struct layout");
 
 static thread_local std::string g_err;
@@ -85,6 +87,7 @@ struct iwae_model {
     DevBuf condP;              // y as bf16 P-layout [Bp][32*ceil(C/32)] (the prior block's input)
     float *param = nullptr, *grad = nullptr, *mom = nullptr, *vel = nullptr;
     int64_t adam_t = 0;
+    float adam_b1 = 0.9f, adam_b2 = 0.999f, adam_eps = 1e-4f;   // keras Adam(lr, epsilon=1e-4) of main.py:93 unless iwae_set_adam says otherwise
     uint32_t noise_step = 0, batch_offset = 0;
     // layer descriptor table
     std::vector<LayerDesc> descs;
@@ -325,7 +328,7 @@ int build_descs(iwae_model* m) {
 
 int refresh_images(iwae_model* m) {   // rebuild bf16 A-images from the fp32 master weights
     if (m->descs_dirty) CHK(build_descs(m));
-    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, 0.f, 1.f, 1e-4f, 0, m->stream);
+    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, 0.f, 1.f, m->adam_b1, m->adam_b2, m->adam_eps, 0, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -815,7 +818,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
 float adam_alpha(iwae_model* m, float lr) {      // keras Adam: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t); advances t
     m->adam_t += 1;
     const double t = (double)m->adam_t;
-    return (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    return (float)((double)lr * sqrt(1.0 - pow((double)m->adam_b2, t)) / (1.0 - pow((double)m->adam_b1, t)));
 }
 
 // fused_lr >= 0: the optimizer update runs inside the slab reduction (single-GPU train step); < 0: gradient only
@@ -933,7 +936,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     if (early) {
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
-                            m->vel, 0.0f, 1e-4f, 0, nullptr, 0, 0.f, nullptr, m->side);
+                            m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->side);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
@@ -941,7 +944,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
     launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                        alpha, 1e-4f, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+                        alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     if (early && !split) CHK(join_side(m));
     if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
@@ -950,7 +953,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         // the encoder's backward pass / update and the next step's encoder forward.
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
-                            m->vel, alpha, 1e-4f, 1, nullptr, 0, 0.f, nullptr, m->side);
+                            m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side);
         m->dec_pending = true;
     }
     HIPCHK(hipGetLastError());
@@ -1031,7 +1034,7 @@ int check_objective(iwae_model* m, int objective) {
 int adam_impl(iwae_model* m, float lr, float gscale) {
     if (m->descs_dirty) CHK(build_descs(m));
     const float alpha = adam_alpha(m, lr);
-    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gscale, 1e-4f, 1, m->stream);
+    launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gscale, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -1046,6 +1049,13 @@ int iwae_version(void) { return 1; }
 
 int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (!cfg || !out) return fail(IWAE_ERR_ARG, "iwae_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(iwae_config))
+        return fail(IWAE_ERR_ARG, "iwae_create: iwae_config.struct_size is " + std::to_string(cfg->struct_size) + ", this library's iwae_config has " +
+                                      std::to_string(sizeof(iwae_config)) + " bytes (binding built against another include/iwae_amd.h?)");
+    if (cfg->reserved != 0) return fail(IWAE_ERR_ARG, "iwae_config.reserved must be 0");
+    if (cfg->precision != IWAE_PREC_BF16 && cfg->precision != IWAE_PREC_FP32) return fail(IWAE_ERR_ARG, "precision must be IWAE_PREC_BF16 or IWAE_PREC_FP32");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(IWAE_ERR_ARG, "need world_size >= 1 and 0 <= rank < world_size");
     if (cfg->n_layers != 1 && cfg->n_layers != 2) return fail(IWAE_ERR_ARG, "n_layers must be 1 or 2 (main.py:17)");
     for (int i = 0; i < cfg->n_layers; ++i) {
         if (cfg->n_hidden[i] < 1 || cfg->n_hidden[i] > 256) return fail(IWAE_ERR_ARG, "n_hidden must be in [1,256]");
@@ -1060,8 +1070,13 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(IWAE_ERR_HIP, "no HIP device: the IWAE hot path needs an AMD GPU (there is no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(IWAE_ERR_ARG, "device " + std::to_string(cfg->device) + " out of range (" + std::to_string(ndev) + " HIP devices)");
     HIPCHK(hipSetDevice(cfg->device));
-    iwae_model* m = new iwae_model();
+    // the half-built model is owned by `guard` until the very end: every failing path below (HIPCHK / CHK return) frees
+    // its streams, events and device memory through iwae_destroy
+    std::unique_ptr<iwae_model, void (*)(iwae_model*)> guard(new iwae_model(), iwae_destroy);
+    iwae_model* m = guard.get();
     m->cfg = *cfg;
     if (const char* e = getenv("IWAE_DENSE_STAMPS")) sscanf(e, "%d:%d", &m->dstamp_epi, &m->dstamp_kt);
     m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
@@ -1119,10 +1134,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         add_block(m, m->dec2, "dec2", m->D[1], m->H[1], m->D[0], true);
         add_mlp3(m, m->dec1, "dec1", m->D[0], m->H[0], m->X);
     }
-    for (Linear* L : all_linears(m)) {
-        int rc = alloc_linear(*L);
-        if (rc != IWAE_OK) { iwae_destroy(m); return rc; }
-    }
+    for (Linear* L : all_linears(m)) CHK(alloc_linear(*L));
     const size_t nb = m->nparam * 4;
     HIPCHK(hipMalloc((void**)&m->param, nb));
     HIPCHK(hipMalloc((void**)&m->grad, nb));
@@ -1145,10 +1157,9 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         for (size_t i = 0; i < (size_t)kl.Kin * kl.Nout; ++i) init[kl.offW + i] = (float)U(rng);
     }
     HIPCHK(hipMemcpy(m->param, init.data(), nb, hipMemcpyHostToDevice));
-    int rc = refresh_images(m);
-    if (rc != IWAE_OK) { iwae_destroy(m); return rc; }
+    CHK(refresh_images(m));
     HIPCHK(hipStreamSynchronize(m->stream));
-    *out = m;
+    *out = guard.release();
     return IWAE_OK;
 }
 
@@ -1334,6 +1345,13 @@ int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(join_side(m));
     return adam_impl(m, lr, grad_scale);
+}
+
+int iwae_set_adam(iwae_handle m, float beta1, float beta2, float epsilon) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(epsilon > 0.f)) return fail(IWAE_ERR_ARG, "set_adam: need 0 <= beta < 1, epsilon > 0");
+    m->adam_b1 = beta1; m->adam_b2 = beta2; m->adam_eps = epsilon;
+    return IWAE_OK;
 }
 
 int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float beta, float lr, int32_t objective, const float* eps,

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import OBJECTIVES, Config, Scalars, Tensors, check
+from ._capi import OBJECTIVES, PRECISIONS, Config, Scalars, Tensors, check
 
 _SCALAR_NAMES = ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14", "inference_loss",
                  "mean_lpxz", "mean_lpz", "mean_lqzx", "mean_kl")
@@ -18,7 +18,7 @@ def _f32(a):
 
 
 class NativeModel:
-    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0, cond_prior=False):
+    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0, cond_prior=False, precision="bf16"):
         self.lib = _capi.load()
         cfg = Config()
         cfg.n_layers = int(n_layers)
@@ -31,6 +31,8 @@ class NativeModel:
         cfg.world_size, cfg.rank = int(world_size), int(rank)
         cfg.cond_dim = int(cond_dim)
         cfg.cond_prior = 1 if cond_prior else 0
+        cfg.precision = PRECISIONS[precision]
+        self.precision = precision
         self.cond_dim = int(cond_dim)
         self.n_layers, self.x_dim = cfg.n_layers, cfg.x_dim
         self.n_hidden, self.n_latent = nh[:cfg.n_layers], nl[:cfg.n_layers]
@@ -170,6 +172,10 @@ class NativeModel:
         out = self._scalars_dict(s)
         out.update(bufs)
         return out
+
+    def set_adam(self, beta_1=0.9, beta_2=0.999, epsilon=1e-4):
+        """keras.optimizers.Adam hyper-parameters of the device optimizer (default: the reference's, main.py:93)."""
+        check(self.lib.iwae_set_adam(self.h, float(beta_1), float(beta_2), float(epsilon)))
 
     def adam_step(self, lr, grad_scale=1.0):
         check(self.lib.iwae_adam_step(self.h, float(lr), float(grad_scale)))

@@ -1,6 +1,6 @@
 """The slice of keras.optimizers.Adam that main.py touches (main.py:93-94,128-133):
 Adam(lr, epsilon=1e-4), .learning_rate.numpy(), .learning_rate.assign(v).  The moment
-buffers and the update itself live on the GPU inside the model handle (adam_kernel)."""
+buffers and the update itself live on the GPU inside the model handle (adam_element in kernels.hip)."""
 import numpy as np
 
 
@@ -20,11 +20,15 @@ class _LearningRate:
 
 
 class Adam:
+    """keras.optimizers.Adam(learning_rate, beta_1, beta_2, epsilon) -- Keras defaults; the reference passes epsilon=1e-4
+    (main.py:93).  The hyper-parameters travel to the device optimizer (iwae_set_adam) with the first train_step."""
+
     def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **kwargs):
-        if abs(beta_1 - 0.9) > 1e-12 or abs(beta_2 - 0.999) > 1e-12:
-            raise ValueError("iwae_amd Adam: beta_1/beta_2 are fixed to the Keras defaults 0.9/0.999")
-        if abs(epsilon - 1e-4) > 1e-12:
-            raise ValueError("iwae_amd Adam: epsilon is fixed to 1e-4, the value the reference trains with (main.py:93)")
+        if not (0.0 <= beta_1 < 1.0 and 0.0 <= beta_2 < 1.0 and epsilon > 0.0):
+            raise ValueError("Adam: need 0 <= beta_1, beta_2 < 1 and epsilon > 0")
         self.learning_rate = _LearningRate(learning_rate)
-        self.epsilon = epsilon
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
         self.iterations = 0
+
+    def hyper(self):
+        return (self.beta_1, self.beta_2, self.epsilon)

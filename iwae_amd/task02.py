@@ -11,6 +11,7 @@ class IWAEDReG(IWAE):
     scalar_keys = ("iwae_elbo", "inference_loss")      # tasks/task02.py:78-79
 
     def train_step(self, x, n_samples, beta, optimizer, outputs=None, eps=None):
+        self._bind_optimizer(optimizer)
         raw = self._net.train_step(np.asarray(x, dtype=np.float32), int(n_samples), float(beta),
                                    float(optimizer.learning_rate), "dreg", eps=eps, want=self._want(outputs))
         optimizer.iterations += 1

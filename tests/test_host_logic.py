@@ -82,8 +82,10 @@ def test_utils_and_optimizer_shim():
     assert np.isclose(opt.learning_rate.numpy(), 1e-3)
     opt.learning_rate.assign(5e-4)
     assert np.isclose(float(opt.learning_rate), 5e-4)
+    assert opt.hyper() == (0.9, 0.999, 1e-4)
+    assert Adam(1e-3).hyper() == (0.9, 0.999, 1e-7)      # Keras defaults are accepted and handed to the device optimizer (iwae_set_adam)
     with pytest.raises(ValueError):
-        Adam(1e-3)            # Keras default epsilon 1e-7 is not what the reference trains with
+        Adam(1e-3, beta_1=1.0)
 
 
 def test_main_cli_flags_identical_to_reference():
