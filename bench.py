@@ -1,13 +1,14 @@
 """bench.py -- images/sec of the IWAE train step (forward + backward + Adam [+ RCCL all-reduce]).
 
-  python bench.py --gpus 1 --steps 100 --warmup 10
+  python bench.py --gpus 1 --steps 100 --warmup 10 [--config c1]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): 1-layer IWAE, k=50, batch 1024 PER GPU (weak scaling; N=8 is
-configs[4], global batch 8192), bf16 GEMM operands with fp32 accumulation, objective iwae_elbo,
-synthetic binarised 28x28 images already resident in HBM, Keras-style random-init weights.
-Rank 0 prints ONE JSON line.  The oracle is used only for the cpu_baseline leg.
+Default workload (BASELINE.json configs[1], --config c1): 1-layer IWAE, k=50, batch 1024 PER GPU (weak scaling; N=8
+is configs[4], global batch 8192), bf16 GEMM operands with fp32 accumulation, objective iwae_elbo, synthetic binarised
+28x28 images already resident in HBM, Keras-style random-init weights.  The other BASELINE configs are selectable
+(--config c0 | c2 | c3: the reference's default regime B=20,k=1; the 2-layer model; the DReG step) and print the same
+line for their own workload.  Rank 0 prints ONE JSON line.  The oracle is used only for the cpu_baseline leg.
 """
 import argparse
 import json
@@ -21,29 +22,77 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-B_PER_GPU, K_SAMPLES, N_HIDDEN, N_LATENT, X_DIM = 1024, 50, 200, 100, 784
-OBJ_IWAE_ELBO = 1
-# algorithmic GEMM FLOPs of one step: 3*(473600*B + 433600*B*k) - 313600*B
-FLOP_PER_STEP = 3 * (473600 * B_PER_GPU + 433600 * B_PER_GPU * K_SAMPLES) - 313600 * B_PER_GPU
-TIMING_EVERY = 8             # HIP events bracket the candidate kernels on every 8th step of the timed region
-PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain device copy reaches ~4.8 TB/s
-M_ROWS = B_PER_GPU * K_SAMPLES
-# The two heaviest kernels of the step, both below the roofline ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B), i.e. HBM-bound
-# by the model.  Algorithmic bytes per data row (unpadded):
-#   bernoulli_fwd  (bern_pipe_kernel<7,true,true>: the WHOLE decoder forward in one launch): the step's draws in (4D) + the image's
-#                  encoder head and x, shared by its k rows ((8D + 2X)/k) + z, g1, g2 out for the backward pass (2D + 2H + 2H) +
-#                  s = x - sigmoid(l) out (2X) + log p(x|z), log p(z), log q(z|x) out (12);   FLOP 2(DH + HH + HX)
-#   out_bwd        (out_bwd_s_kernel): s in (2X) + g2 in (2H) + row weight (4) + dpre2 out (2H);   FLOP 2HX
-KERNELS = {
-    "bernoulli_fwd": {"name": "bern_pipe_kernel<7,true,true,true> (whole decoder forward, 16-wave / 200-row workgroups: z = mu + sigma*eps, two tanh layers, output layer + "
-                              "Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
-                      "bytes": M_ROWS * (4 * N_LATENT + (8.0 * N_LATENT + 2.0 * X_DIM) / K_SAMPLES + 2 * N_LATENT + 4 * N_HIDDEN + 2 * X_DIM + 12),
-                      "flop": 2 * M_ROWS * (N_LATENT * N_HIDDEN + N_HIDDEN * N_HIDDEN + N_HIDDEN * X_DIM),
-                      "match": "bern_pipe_kernel"},
-    "out_bwd": {"name": "out_bwd_s_kernel<7> (decoder output-layer backward from the stored s)",
-                "bytes": M_ROWS * (2 * X_DIM + 2 * N_HIDDEN + 4 + 2 * N_HIDDEN), "flop": 2 * M_ROWS * N_HIDDEN * X_DIM,
-                "match": "out_bwd"},
+X_DIM = 784
+TIMING_EVERY = 8             # HIP events bracket the timed kernels on every 8th step of the timed region
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain device copy reaches ~4.8 TB/s on this box
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
+PEAK_FP32_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 (precision fp32)
+RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)      # 312 FLOP/B
+
+CONFIGS = {
+    # BASELINE.json configs[0..3]; B is per GPU
+    "c0": dict(layers=1, B=20, k=1, obj="vae_elbo", nh=200, nl=100,
+               label="1-layer IWAE k=1 (VAE ELBO) batch 20 (BASELINE configs[0], the reference's default regime)"),
+    "c1": dict(layers=1, B=1024, k=50, obj="iwae_elbo", nh=200, nl=100,
+               label="1-layer IWAE k=50 batch 1024 per GPU (BASELINE configs[1]; N=8 is configs[4])"),
+    "c2": dict(layers=2, B=1024, k=50, obj="iwae_elbo", nh=[200, 100], nl=[100, 50],
+               label="2-layer IWAE k=50 batch 1024 (BASELINE configs[2], src/iwae2.py)"),
+    "c3": dict(layers=1, B=1024, k=50, obj="dreg", nh=200, nl=100,
+               label="1-layer IWAE k=50 batch 1024 with the DReG estimator (BASELINE configs[3], tasks/task02.py)"),
 }
+OBJ_ID = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "dreg": 4}
+
+
+def step_flops(cfg):
+    """Algorithmic GEMM FLOPs of one train step: fwd = encoder on B images + per-sample work on B*k rows,
+    bwd = 2x fwd minus the dX of the first encoder layer.  1-layer: 433 600 FLOP per sample, 2-layer: 563 600."""
+    per_sample = 433600 if cfg["layers"] == 1 else 563600
+    return 3 * (473600 * cfg["B"] + per_sample * cfg["B"] * cfg["k"]) - 313600 * cfg["B"]
+
+
+def step_algorithmic_bytes(cfg):
+    """compulsory bytes of a step (x in, parameters + Adam state read and written) + save-for-backward
+    traffic if the per-sample activations (1-layer: z, g1, g2 as bf16) are written once and read once."""
+    B, M = cfg["B"], cfg["B"] * cfg["k"]
+    nparam = 455384 if cfg["layers"] == 1 else 521084
+    compulsory = 4 * X_DIM * B + 7 * 4 * nparam
+    if cfg["layers"] == 1:
+        acts = 2 * M * (2 * 100 + 2 * 200 + 2 * 200)
+    else:   # z1, z2, the two per-sample blocks' h1, h2 (100 wide) and the decoder's g1, g2
+        acts = 2 * M * (2 * 100 + 2 * 50 + 4 * 2 * 100 + 2 * 200 + 2 * 200)
+    return compulsory, acts
+
+
+def kernel_models(cfg):
+    """Timed kernels of the step (names: include/iwae_amd.h, iwae_kernel_time): what each is, its ALGORITHMIC bytes per launch
+    (unpadded operands read once + results written once) and GEMM FLOPs, and the substring of its
+    device-side name (to pair with rocprofv3 rows).  D, H, X: latent, hidden, pixels of the z -> x decoder; M data rows."""
+    M, k, D, H, X = cfg["B"] * cfg["k"], cfg["k"], 100, 200, X_DIM
+    fused_z = cfg["layers"] == 1 and cfg["obj"] != "dreg" and M >= 8192      # the decoder kernel makes z itself from the draws
+    zin = 4 * D + (8.0 * D + 2.0 * X) / k + 2 * D + 8 if fused_z else 2 * D + 2.0 * X / k      # draws + head + x in, z + 2 densities out | z in
+    big = M >= 8192
+    out = {
+        "decoder_fwd": dict(
+            name=("bern_pipe_kernel<7,true,true,*> (whole decoder forward in one launch: " if big else "dense_kernel<EPI_BERN> (output layer: ") +
+                 ("z = mu + sigma*eps, " if fused_z else "") + ("two tanh layers, " if big else "") +
+                 "Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
+            bytes=M * (zin + (4 * H if big else 2 * H) + 2 * X + 4),
+            flop=2 * M * ((D * H + H * H if big else 0) + H * X), match="bern_pipe_kernel" if big else "dense_kernel<4"),
+        "out_bwd": dict(name="out_bwd_s_kernel<7> (output-layer backward from the stored s: dg2 = s W^T, dpre2)",
+                        bytes=M * (2 * X + 2 * H + 4 + 2 * H), flop=2 * M * H * X, match="out_bwd_s_kernel"),
+        "wgrad_out": dict(name="wgradp_kernel<16,true> (output-layer weight gradient dV3 = g2^T (g_r s), side stream)" if big else
+                               "wgradp_kernel<8,true> (output-layer weight gradient, side stream)",
+                          bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradp_kernel<16, true" if big else "wgradp_kernel<8, true"),
+        "dx_hidden": dict(name="dense_kernel<EPI_DX,7> (dpre1 = (dpre2 V2^T) * (1 - g1^2))", bytes=M * 6 * H, flop=2 * M * H * H, match="dense_kernel<2, 7"),
+        "dx_latent": dict(name="dense_kernel<EPI_F32,7> (dz = dpre1 V1^T, fp32)", bytes=M * (2 * H + 4 * D), flop=2 * M * H * D, match="dense_kernel<3, 7"),
+        "wgrad_hidden": dict(name="wgradp_kernel<*,false> (dV2 = g1^T dpre2, side stream)", bytes=M * 4 * H + 4 * (H * H + H), flop=2 * M * H * H, match="wgradp_kernel"),
+        "wgrad_latent": dict(name="wgradp_kernel<*,false> (dV1 = z^T dpre1, side stream)", bytes=M * (2 * D + 2 * H) + 4 * (D * H + H), flop=2 * M * D * H, match="wgradp_kernel"),
+        "latent_bwd": dict(name="latent_bwd_kernel (d mu, d sigma per image: sum over the k samples)", bytes=M * (4 * D + 4 * D + 16), flop=0, match="latent_bwd_kernel"),
+        "encoder_fwd": dict(name="block_fwd_kernel (encoder BasicBlock on the B images, one launch)",
+                            bytes=cfg["B"] * (4 * X + 4 * H + 8 * D) + 2 * (X * H + H * H + 2 * H * D), flop=2 * cfg["B"] * (X * H + H * H + 2 * H * D), match="block_fwd_kernel"),
+        "reduce_adam": dict(name="reduce_grads_kernel (main-stream slab reduction + fused Adam + weight-image refresh)", bytes=0, flop=0, match="reduce_grads_kernel"),
+    }
+    return out
 
 
 def synthetic_batch(n, seed):
@@ -66,26 +115,47 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(cfg, budget_s=12.0):
     """The same train step on the host cores (oracle/iwae_torch.py, fp32, autograd + Adam(eps=1e-4)):
-    a bounded sample of the SAME workload (B=1024, k=50), reported, never the target."""
+    a bounded sample of the SAME workload, reported, never the target."""
     from oracle import iwae_np as O, iwae_torch as T
     threads = host_cores()
     torch.set_num_threads(threads)
-    x_np, p = synthetic_batch(B_PER_GPU, 7)
-    P = O.init_params(1, N_HIDDEN, N_LATENT, 123, x_mean=p)
-    tr = T.CpuTrainer(P, 1, lr=1e-3, threads=threads)
+    x_np, p = synthetic_batch(cfg["B"], 7)
+    P = O.init_params(cfg["layers"], cfg["nh"], cfg["nl"], 123, x_mean=p)
+    tr = T.CpuTrainer(P, cfg["layers"], lr=1e-3, threads=threads)
     x = torch.tensor(x_np)
-    tr.step(x, K_SAMPLES)      # warm-up
+    obj = "iwae_elbo" if cfg["obj"] == "dreg" else cfg["obj"]     # the DReG port's cost is the iwae_elbo step's (same graph, two gradient targets)
+    tr.step(x, cfg["k"], obj)      # warm-up
     t0 = time.time()
     n = 0
-    while n < 3 or (time.time() - t0 < budget_s and n < 200):
-        tr.step(x, K_SAMPLES)
+    while n < 3 or (time.time() - t0 < budget_s and n < 2000):
+        tr.step(x, cfg["k"], obj)
         n += 1
     dt = time.time() - t0
-    return {"value": round(B_PER_GPU * n / dt, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d train steps of the same workload (B=1024, k=50, 1-layer, fp32 torch-CPU autograd + Adam) in %.1f s; "
-                      "TF2 (the reference runtime) is not installed, this is the oracle port" % (n, dt)}
+    return {"value": round(cfg["B"] * n / dt, 1), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of the same workload (B=%d, k=%d, %d-layer, fp32 torch-CPU autograd + Adam) in %.1f s; "
+                      "TF2 (the reference runtime) is not installed, this is the oracle port" % (n, cfg["B"], cfg["k"], cfg["layers"], dt)}
+
+
+def load_profile_traffic(kernel_match, config):
+    """HBM bytes per launch of the kernel whose device-side name contains `kernel_match`, from the PMC passes of
+    tools/profile_bench.sh kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: MI355X_MICROARCH.md, HBM).  Returned WITH its
+    source, or None when no kept profile holds that instantiation (the number is a profile artefact, not a live measurement)."""
+    for tag in ("r02",):
+        path = os.path.join(ROOT, "profiles", "%s_kernel_traffic.json" % tag)
+        if not os.path.exists(path):
+            continue
+        try:
+            tab = json.load(open(path))
+        except Exception:
+            continue
+        if tab.get("config", "c1") != config:
+            continue
+        for ent in tab.get("kernels", []):
+            if kernel_match in ent.get("kernel", ""):
+                return ent.get("hbm_bytes_per_launch"), "profiles/%s_kernel_traffic.json: %s" % (tag, ent["kernel"]), tab.get("step_hbm_bytes")
+    return None, None, None
 
 
 def main():
@@ -93,9 +163,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c1", help="BASELINE.json configs[0..3] (default c1 = configs[1], the headline)")
+    ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16", help="GEMM arithmetic (iwae_config.precision); the headline is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llh-eval", action="store_true", help="skip the untimed k = 5000 evaluator run (profiling: keeps its kernels out of the statistics)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    B, K = cfg["B"], cfg["k"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,21 +186,22 @@ def main():
     from iwae_amd.parallel import DataParallelStep
     from iwae_amd import utils
 
-    x_np, p = synthetic_batch(B_PER_GPU * world, 123)
-    lo = rank * B_PER_GPU
-    x_dev = torch.tensor(x_np[lo:lo + B_PER_GPU], device="cuda")       # inputs resident in HBM before timing
-    net = NativeModel(1, N_HIDDEN, N_LATENT, x_dim=X_DIM, device=local_rank, seed=123, world_size=world, rank=rank)
+    x_np, p = synthetic_batch(B * world, 123)
+    lo = rank * B
+    x_dev = torch.tensor(x_np[lo:lo + B], device="cuda")       # inputs resident in HBM before timing
+    net = NativeModel(cfg["layers"], cfg["nh"], cfg["nl"], x_dim=X_DIM, device=local_rank, seed=123, world_size=world, rank=rank,
+                      precision=args.precision)
     net.set_output_bias(utils.bias_from_mean(p))                       # identical init on every rank (same seed)
     dp = DataParallelStep(net, rank, world)
     lr = 1e-3
+    obj_id = OBJ_ID[cfg["obj"]]
 
     def step():
-        dp.step(x_dev.data_ptr(), B_PER_GPU, K_SAMPLES, 1.0, lr, OBJ_IWAE_ELBO)
+        dp.step(x_dev.data_ptr(), B, K, 1.0, lr, obj_id)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    # HIP events around out_bwd on every TIMING_EVERY-th step of the timed region (each record is a small stream bubble)
     net.enable_timing(int(os.environ.get("IWAE_BENCH_TIMING", TIMING_EVERY)))
     if dist:
         dist.barrier()
@@ -134,6 +209,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    net.sync()                    # the library's own streams (a deferred decoder update may still run on its side stream)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -143,55 +219,70 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ktimes = {k: net.kernel_time(k) for k in KERNELS}
+    models = kernel_models(cfg)
+    ktimes = {k: net.kernel_time(k) for k in models}
     net.enable_timing(0)
-    elbo = net.forward(x_np[lo:lo + B_PER_GPU], K_SAMPLES)["iwae_elbo"]
+    elbo = net.forward(x_np[lo:lo + B], K)["iwae_elbo"]
     llh_eval = None
-    if world == 1 and not args.no_llh_eval:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
+    if world == 1 and not args.no_llh_eval and cfg["layers"] == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
         n_eval = 1000
         net.eval_llh(x_np[:32], 5000)
-        torch.cuda.synchronize()
+        net.sync()
         t1 = time.perf_counter()
-        llh = net.eval_llh(x_np[:n_eval], 5000)
+        llh = net.eval_llh(np.tile(x_np, (n_eval // x_np.shape[0] + 1, 1))[:n_eval], 5000)
         dt_eval = time.perf_counter() - t1
         llh_eval = {"k": 5000, "images": n_eval, "images_per_s": round(n_eval / dt_eval, 1), "llh": round(float(llh), 3),
+                    "gemm_tflops": round(n_eval * 2168473600.0 / dt_eval / 1e12, 1),
                     "note": "forward-only evaluator on synthetic images with the just-trained weights; 10 000 images take %.2f s" % (dt_eval * 10000 / n_eval)}
 
     if rank == 0:
         ms = dt * 1e3 / args.steps
-        value = B_PER_GPU * world * args.steps / dt
-        dom = max(KERNELS, key=lambda k: ktimes[k][0])          # the kernel with the longest average launch
-        dom_us, dom_n = ktimes[dom]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_kernel_traffic.json")     # PMC passes of tools/profile_bench.sh
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        ach = KERNELS[dom]["bytes"] / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+        value = B * world * args.steps / dt
+        launched = {k: v for k, v in ktimes.items() if v[1] > 0}
+        dom = max(launched, key=lambda k: launched[k][0]) if launched else None    # the kernel with the longest average launch, over ALL timed kernels
+        flop_step = step_flops(cfg)
+        comp_b, act_b = step_algorithmic_bytes(cfg)
+        peak_tf = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
         out = {
             "metric": "images/sec (train step) IWAE k=50 batch 1024 @1/2/4/8 GPU; test LLH@k=5000",
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "1-layer IWAE k=50 batch 1024 per GPU (BASELINE configs[1]; N=8 is configs[4]), "
-                                   "objective iwae_elbo, train step = forward + backward + Adam(eps=1e-4)"
-                                   + (" + RCCL all-reduce of 455384 fp32 grads" if world > 1 else ""),
-                       "global_batch": B_PER_GPU * world, "n_samples": K_SAMPLES, "parallelism": "dp%d" % world,
-                       "step_gemm_tflops": round(FLOP_PER_STEP * world / (dt / args.steps) / 1e12, 1),
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": cfg["label"] + ", objective %s, train step = forward + backward + Adam(eps=1e-4)" % cfg["obj"]
+                                   + (" + RCCL all-reduce of the flat fp32 gradient" if world > 1 else ""),
+                       "config_id": args.config, "global_batch": B * world, "n_samples": K, "parallelism": "dp%d" % world,
+                       "step_gemm_tflops": round(flop_step * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3), "llh_eval_k5000": llh_eval},
-            "roofline": {"bound": "hbm", "kernel": KERNELS[dom]["name"],
-                         "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
-                         "avg_launch_us": round(dom_us, 2), "launches": dom_n,
-                         "algorithmic_bytes_per_launch": int(KERNELS[dom]["bytes"]),
-                         "flop_per_launch": KERNELS[dom]["flop"],
-                         "mfma_tflops": round(KERNELS[dom]["flop"] / (dom_us * 1e-6) / 1e12, 1) if dom_us > 0 else 0.0,
-                         "other": {k: round(v[0], 2) for k, v in ktimes.items() if k != dom}},
         }
+        if dom:
+            dom_us, dom_n = launched[dom]
+            km = models[dom]
+            hbm_bound = km["flop"] / max(km["bytes"], 1) < RIDGE
+            traffic, tsrc, step_hbm = load_profile_traffic(km["match"], args.config)
+            ach = km["bytes"] / (dom_us * 1e-6) / 1e9 if hbm_bound else km["flop"] / (dom_us * 1e-6) / 1e12
+            peak = PEAK_HBM_GBS if hbm_bound else peak_tf
+            out["roofline"] = {
+                "bound": "hbm" if hbm_bound else "mfma", "kernel": km["name"], "timed_as": dom,
+                "stream": "side" if dom.startswith("wgrad") else "main",
+                "achieved": round(ach, 1), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_us": round(dom_us, 2), "launches": dom_n,
+                "algorithmic_bytes_per_launch": int(km["bytes"]), "flop_per_launch": km["flop"],
+                "mfma_tflops": round(km["flop"] / (dom_us * 1e-6) / 1e12, 1) if dom_us > 0 else 0.0,
+                # every timed kernel: average launch (us), algorithmic GB/s and its fraction of the HBM peak
+                "all_kernels": {k: {"us": round(v[0], 2), "GBps": round(models[k]["bytes"] / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0,
+                                    "hbm_frac": round(models[k]["bytes"] / (v[0] * 1e-6) / 1e9 / PEAK_HBM_GBS, 3) if v[0] > 0 else 0.0,
+                                    "tflops": round(models[k]["flop"] / (v[0] * 1e-6) / 1e12, 1) if v[0] > 0 else 0.0}
+                                for k, v in launched.items()},
+                # the step as a whole (per GPU): GEMM FLOP / step time against the MFMA peak, SURVEY 8(d)'s algorithmic bytes
+                # (compulsory + activations written once and read once) / step time against the HBM peak, and -- from the
+                # kept profile, when it is of this configuration -- the bytes the step really moved
+                "step": {"gemm_flop": flop_step, "mfma_frac": round(flop_step / (ms * 1e-3) / (peak_tf * 1e12), 4),
+                         "algorithmic_bytes": int(comp_b + act_b), "algorithmic_hbm_frac": round((comp_b + act_b) / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                         "measured_hbm_bytes": step_hbm, "measured_hbm_frac": round(step_hbm / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if step_hbm else None},
+            }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

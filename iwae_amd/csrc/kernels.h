@@ -49,7 +49,7 @@ struct DenseArgs {
     const char* pre_img1; int pre_KT1;   // first decoder layer: forward image, k-steps of its input (latent, <= 4)
     const char* pre_img2;                // second decoder layer (KT k-steps in and out)
     const uint16_t* pre_Z;               // z rows, P-layout [M][32*pre_KT1] (when zhead == null; else z is made in the kernel, see ZIN fields)
-    uint16_t *pre_G1, *pre_G2;           // the layers' activations, P-layout [M][32*KT], kept for the backward pass
+    uint16_t *pre_G1, *pre_G2;           // the layers' activations, P-layout [M][32*KT], kept for the backward pass (null: forward only, not stored)
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                     if (kso < KTC) {
                         const uint2 piece = make_uint2(pack2(tanh_fast(acc1[0]), tanh_fast(acc1[1])), pack2(tanh_fast(acc1[2]), tanh_fast(acc1[3])));
                         *(uint2*)(xch_out + kso * 1024 + lane * 16 + 8 * hh) = valid ? piece : make_uint2(0, 0);
-                        if (valid) *(uint2*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8 + 4 * hh) = piece;
+                        if (valid && Gout) *(uint2*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8 + 4 * hh) = piece;
                     }
                     continue;
                 }
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                         for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
                         const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
                         bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
-                        if (valid && storer) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;
+                        if (valid && storer && Gout) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;     // forward-only calls keep nothing (Gout = null)
                     }
                 }
             }

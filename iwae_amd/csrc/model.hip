@@ -69,6 +69,11 @@ struct MlpWs {     // decode_z_to_x applied to M rows
 
 }  // namespace
 
+// kernels iwae_enable_timing brackets with HIP events (on the stream each is launched on); names: iwae_kernel_time
+enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_COUNT };
+static const char* const kTimedNames[T_COUNT] = {"out_bwd", "decoder_fwd", "wgrad_out", "dx_hidden", "dx_latent", "wgrad_hidden", "wgrad_latent",
+                                                 "latent_bwd", "encoder_fwd", "reduce_adam"};
+
 struct iwae_model {
     iwae_config cfg;
     int X, Xp32;
@@ -159,8 +164,8 @@ struct iwae_model {
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
     int64_t timing_calls = 0;
     bool time_this = false;
-    std::vector<hipEvent_t> ev_start[3], ev_stop[3];   // 0 out_bwd, 1 bernoulli fwd, 2 wgrad(out)
-    size_t ev_used[3] = {0, 0, 0};
+    std::vector<hipEvent_t> ev_start[T_COUNT], ev_stop[T_COUNT];   // per timed kernel (enum TimedKernel)
+    size_t ev_used[T_COUNT] = {};
     bool want_stamps = false;
     float* d_scalars = nullptr;
     float* h_scalars = nullptr;   // pinned
@@ -621,6 +626,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
 
     // ---- encoder over images (iwae1.py:57 / iwae2.py:59)
     CHK(block_alloc(m, m->enc1, m->wenc1, B, Bp, bwd, false));
+    {
+    ScopedTimer tm_enc(m, T_ENC_FWD);
     if (xf_pending) {
         bool took = false;
         CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, xf_pending, X, &took));
@@ -630,6 +637,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         }
     } else {
         CHK(block_fwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B));
+    }
     }
 
     for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
@@ -745,7 +753,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         if (m->allow_dec_fused && a.pipe && m->C == 0 && m->dec1[0].KT <= 4 && m->dec1[0].Kp32 == m->Dp[0] &&
             m->dec1[0].Np32 == L.Kp32 && m->dec1[1].Kp32 == L.Kp32 && m->dec1[1].Np32 == L.Kp32) {
             a.pre_img1 = m->dec1[0].imgF; a.pre_KT1 = m->dec1[0].KT; a.pre_img2 = m->dec1[1].imgF;
-            a.pre_Z = ptr<uint16_t>(m->zP[0]); a.pre_G1 = ptr<uint16_t>(w.g1P); a.pre_G2 = ptr<uint16_t>(w.g2P);
+            a.pre_Z = ptr<uint16_t>(m->zP[0]);
+            // g1, g2 are kept for the backward pass only: a forward-only call (val_step, the k = 5000 evaluator) never reads them back
+            a.pre_G1 = bwd ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = bwd ? ptr<uint16_t>(w.g2P) : nullptr;
             if (fuse_z) {
                 a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zD = zin.D; a.zDp = zin.Dp;
                 a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq;
@@ -761,7 +771,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
-            { ScopedTimer tm(m, 1); launch_dense(EPI_BERN, a, st); }
+            { ScopedTimer tm(m, T_DEC_FWD); launch_dense(EPI_BERN, a, st); }
         HIPCHK(hipGetLastError());
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
@@ -854,7 +864,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
             // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
-            { ScopedTimer tm(m, 0); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
+            { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
@@ -862,14 +872,13 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     if (m->early_wout) {     // forked behind lse_kernel (forward_impl)
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
-        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, ptr<float>(m->gx))); }
+        { ScopedTimer tm(m, T_WGRAD_OUT, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, ptr<float>(m->gx))); }
     } else {
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
-        { ScopedTimer tm(m, 2, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
+        { ScopedTimer tm(m, T_WGRAD_OUT, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
     }
-    CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr));
-    set_launch_stop_event(m->ev_fork2);
-    CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz)));
+    { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
+    { ScopedTimer tm(m, T_DX_LAT); set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
     // ONE event behind both dX kernels (every record costs the main stream a ~6 us bubble): the first decoder layer's weight
     // gradient needs dpre1 (dX of d2) and sits behind two other weight gradients on the side stream anyway; the deferred
     // decoder update further down that stream must come after dX of d1, the last reader of the decoder's weight images.
@@ -878,9 +887,9 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // covers out_bwd (dpre2), dX of d2 (dpre1) and dX of d1, and out_bwd carries no event at all -- one bubble less on the
     // main stream, one wait less on the side stream.
     if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side));
+    { ScopedTimer tm(m, T_WGRAD_HID, m->side); CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side)); }
     if (!m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side));
+    { ScopedTimer tm(m, T_WGRAD_LAT, m->side); CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side)); }
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -921,7 +930,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
         a.DHP = ptr<uint16_t>(m->wenc1.dheadP);
         if (m->has_prior) { a.prior_head = ptr<float>(m->wprior.head); a.DHP2 = ptr<uint16_t>(m->wprior.dheadP); }
-        launch_latent_bwd(a, st);
+        { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
@@ -943,8 +952,11 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         HIPCHK(hipEventRecord(m->ev_join, m->side));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
-    launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                        alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+    {
+        ScopedTimer tm_red(m, T_REDUCE);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+    }
     if (early && !split) CHK(join_side(m));
     if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
@@ -1191,7 +1203,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->d_zero) (void)hipFree(m->d_zero);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < T_COUNT; ++i) {
         for (hipEvent_t e : m->ev_start[i]) (void)hipEventDestroy(e);
         for (hipEvent_t e : m->ev_stop[i]) (void)hipEventDestroy(e);
     }
@@ -1537,15 +1549,24 @@ int iwae_enable_timing(iwae_handle m, int32_t enable) {
     m->timing = enable > 0 ? enable : 0;
     m->timing_calls = 0;
     m->time_this = false;
-    for (int i = 0; i < 3; ++i) m->ev_used[i] = 0;
+    for (int i = 0; i < T_COUNT; ++i) m->ev_used[i] = 0;
     return IWAE_OK;
 }
 
 int iwae_kernel_time(iwae_handle m, const char* name, double* avg_us, int64_t* launches) {
     if (!m || !name || !avg_us) return fail(IWAE_ERR_ARG, "kernel_time: null argument");
-    const int id = !strcmp(name, "out_bwd") ? 0 : !strcmp(name, "bernoulli_fwd") ? 1 : !strcmp(name, "wgrad_out") ? 2 : -1;
-    if (id < 0) return fail(IWAE_ERR_ARG, "kernel_time: unknown kernel (out_bwd | bernoulli_fwd | wgrad_out)");
+    int id = -1;
+    for (int i = 0; i < T_COUNT; ++i)
+        if (!strcmp(name, kTimedNames[i])) id = i;
+    if (!strcmp(name, "bernoulli_fwd")) id = T_DEC_FWD;      // round-1 name of the decoder forward kernel
+    if (id < 0) {
+        std::string all;
+        for (int i = 0; i < T_COUNT; ++i) all += std::string(i ? " | " : "") + kTimedNames[i];
+        return fail(IWAE_ERR_ARG, "kernel_time: unknown kernel (" + all + ")");
+    }
+    CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // the weight gradients are timed on the side stream
     double tot = 0.0;
     for (size_t i = 0; i < m->ev_used[id]; ++i) {
         float ms = 0.f;

@@ -49,6 +49,21 @@ def grad_summary(grads):
     return np.array(rows)
 
 
+def probe_indices(grads, per_tensor=256, seed=20240229):
+    """Fixed (seeded) positions in the FLAT gradient, up to `per_tensor` per dW / db: the full-size fixtures keep the gradient's
+    values there, so the GPU test compares element by element (a sign flip or a permuted tensor cannot hide behind a norm)
+    without storing 455k floats per objective."""
+    rng = np.random.default_rng(seed)
+    idx, off = [], 0
+    for dW, db in grads:
+        for g in (dW, db):
+            n = g.size
+            take = np.arange(n) if n <= per_tensor else np.sort(rng.choice(n, per_tensor, replace=False))
+            idx.append(off + take)
+            off += n
+    return np.concatenate(idx).astype(np.int64)
+
+
 def run(n_layers, nh, nl, x_dim, B, k, seed, objective, beta, rnd, cond=0, cond_prior=False):
     y = None
     if cond:
@@ -78,6 +93,8 @@ def save(name, n_layers, nh, nl, x_dim, B, k, seed, objectives, beta=1.0, full_a
                 if np.ndim(v) == 0 or key in ("lpxz", "lpz", "lqzx", "lpxz1", "lpz1z2", "lpz2", "lqz1x", "lqz2z1", "al") or full_arrays:
                     out[pre + key] = np.asarray(v)
             out[pre + "grad_summary"] = grad_summary(g)
+            out["grad_probe_idx"] = probe_indices(g)
+            out[pre + "grad_probe"] = gflat[out["grad_probe_idx"]]
             out[pre + "adam_param_sum"] = np.array([p1.sum(), np.abs(p1).sum()])
             if full_arrays:
                 out[pre + "grad_flat"] = gflat

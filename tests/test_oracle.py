@@ -70,6 +70,8 @@ def test_oracle_reproduces_golden(name):
                 if pre + key in g:
                     np.testing.assert_allclose(res[key], g[pre + key], rtol=1e-10, atol=1e-10)
             np.testing.assert_allclose(MG.grad_summary(gr), g[pre + "grad_summary"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_array_equal(MG.probe_indices(gr), g["grad_probe_idx"])
+            np.testing.assert_allclose(gflat[g["grad_probe_idx"]], g[pre + "grad_probe"], rtol=1e-9, atol=1e-13)
             if "x" in g:      # fixtures that carry their inputs: the regenerated inputs must be those
                 np.testing.assert_array_equal(x, g["x"])
                 np.testing.assert_allclose(O.flatten_params(P), g["params_flat"], rtol=0, atol=0)
