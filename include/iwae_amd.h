@@ -182,7 +182,7 @@ int iwae_train_step_dataset(iwae_handle h, int32_t start, int32_t B, int32_t k, 
 /* HIP-event timing of the step's heavy kernels, each on the stream it is launched on (used by bench.py's roofline
  * object): enable, run steps, then read the average launch duration.  enable = n > 0 brackets the kernels of every n-th
  * step (an event record costs a few us of stream bubble, so bench.py samples rather than timing every launch); 0 switches
- * it off.  name: "decoder_fwd" (whole decoder forward + log-likelihood), "out_bwd" (output-layer backward), "wgrad_out",
+ * it off.  name: "decoder_fwd" (whole decoder forward + log-likelihood), "out_bwd" (output-layer backward), "decoder_bwd" (the decoder's whole dX chain where it is one launch), "wgrad_out",
  * "dx_hidden", "dx_latent", "wgrad_hidden", "wgrad_latent" (the decoder's other backward kernels), "latent_bwd",
  * "encoder_fwd", "reduce_adam" (main-stream slab reduction + Adam).  A kernel a configuration does not launch reports 0 launches. */
 int iwae_enable_timing(iwae_handle h, int32_t enable);

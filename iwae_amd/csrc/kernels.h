@@ -81,6 +81,15 @@ struct OutBwdArgs {
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
+struct DecBwdArgs {                  // dec_bwd_kernel: out_bwd_s + dX of the two tanh layers in one launch
+    OutBwdArgs o;                     // SP (s), G2, gx, img1 (W3^T image), M, KT, NG, Xp32, ldG, DPP (dpre2 out); part = null
+    const char* imgB2;                // backward image of the second tanh layer ((KT+1)/2 64-out-feature groups over hidden, KT k-steps each)
+    const uint16_t* G1;               // stored first-layer activation, P-layout [M][32*KT]
+    uint16_t* D1P;                    // dpre1 out, P-layout [M][32*KT]
+    const char* imgB1; int MG1;       // backward image of the first decoder layer (out = latent groups, k = hidden)
+    float* DZ; int ldDZ;              // dz fp32 [M][ldDZ]
+};
+
 struct WgradPArgs {
     const uint16_t* X; int ldX; int IT;     // layer input, P-layout [rows][ldX]; IT = ldX/16 i-tiles
     const uint16_t* G; int ldG; int JT;     // dpre of layer output, P-layout [rows][ldG]
@@ -167,7 +176,8 @@ void set_launch_stop_event(hipEvent_t e);
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 bool bern_pipe_ok(const DenseArgs& a);  // shapes bern_pipe_kernel covers (launch_dense falls back to dense_kernel<EPI_BERN> otherwise)
-bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel
+bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel / dec_bwd_kernel
+void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st);
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);

@@ -1666,6 +1666,193 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// dec_bwd_kernel: the decoder's whole dX chain in ONE launch (large row counts, s kept by the forward pass):
+//   dg2 = s W3^T ; dpre2 = g_r * dg2 * (1 - g2^2)            (out_bwd_s_kernel's product, iwae1.py:74-75,111)
+//   dpre1 = (dpre2 V2^T) * (1 - g1^2)                         (dense_kernel<EPI_DX>'s)
+//   dz    = dpre1 V1^T                                        (dense_kernel<EPI_F32>'s)
+// A converted accumulator IS the next product's B operand (layout.h), so dpre2 and dpre1 go from product to product in
+// registers; they are stored once (the hidden layers' weight gradients read them) and never read back here.  As three
+// launches the chain was 40 + 29 + 18 us with a boundary, a tail and a 22 MB re-read between each pair; the weights of all
+// three products stream through the same two LDS buffers as one sequence of 29 KiB units (13 pixel groups of W3^T read
+// through the transposing ds_read_b64_tr_b16, then the 4 + 2 out-feature groups of the backward images of V2 and V1).
+// 4 waves x 32 rows, two workgroups per CU (<= 256 registers): dg2 accumulators 112, then dpre2 / dpre1 fragments 56 each.
+// ---------------------------------------------------------------------------------
+template <int KTC>
+__global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const OutBwdArgs& a = d.o;
+    constexpr int KT = KTC, MT = 2 * KTC;
+    constexpr int unit = KT * 4096 + 1024;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * 32;
+    int row[2], rowc[2];
+    bool valid[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
+    const int tr_off = (4 * q + (rho >> 2)) * 64 + (((rho & 3) ^ hperm(q)) * 16);
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    constexpr int MG2 = (KTC + 1) / 2;                             // 64-feature groups of the hidden width (32*KTC features)
+    const int U1 = a.NG, U2 = U1 + MG2, U3 = U2 + d.MG1;          // unit ranges of the three products
+
+    constexpr int NP = unit / 1024, NIDX = (NP + 3) / 4;
+    auto dma_piece = [&](int u, int idx) {
+        const int p = wave + 4 * idx;                 // wave-uniform
+        if (p >= NP) return;
+        const char* src = u < U1 ? a.img1 + (size_t)u * unit : u < U2 ? d.imgB2 + (size_t)(u - U1) * unit : d.imgB1 + (size_t)(u - U2) * unit;
+        glds16(src + (size_t)p * 1024 + lane * 16,
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (u & 1) * unit) + (uint32_t)p * 1024u)));
+    };
+    auto load_s = [&](int ng, uint4 (&sf)[2][2]) {   // clamped rows, zeroed by a select: no branch per load
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                sf[kk][g] = make_uint4(0, 0, 0, 0);
+                const int fbase = 64 * ng + 32 * kk;      // wave-uniform guard
+                if (fbase < a.Xp32) {
+                    const uint4 v = *(const uint4*)(a.SP + (size_t)rowc[g] * a.Xp32 + fbase + 8 * q);
+                    sf[kk][g] = valid[g] ? v : make_uint4(0, 0, 0, 0);
+                }
+            }
+    };
+#pragma unroll
+    for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, idx);
+    uint4 d2f[KT][2], d1f[KT][2];
+    {
+        // ---------------- product 1: dg2 = s W3^T over the pixel groups
+        uint4 sf[2][2], sf_n[2][2];
+        load_s(0, sf);
+        f32x4 acc2[MT][2];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ng = 0; ng < U1; ++ng) {
+            const int buf = ng & 1;
+            wait_all_vmem();
+            __syncthreads();
+            if (ng + 1 < U1) load_s(ng + 1, sf_n);
+            const char* l2 = smem + buf * unit + tr_off;
+            lds_pipeline<2 * MT, 8>(
+                [&](int i) {       // A fragment (hidden tile mt, pixel k-step kk) = two transposed 4x16 blocks of pixel tiles 2kk, 2kk+1
+                    const int kk = i / MT, mt = i % MT;
+                    typedef __attribute__((ext_vector_type(4))) short v4s;
+                    const char* p0 = l2 + ((mt >> 1) * 4 + 2 * kk) * 1024 + 8 * (mt & 1);
+                    const v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+                    const v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 1024));
+                    const uint2 lo = __builtin_bit_cast(uint2, t0), hi = __builtin_bit_cast(uint2, t1);
+                    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+                },
+                [&](int i, const uint4& av) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc2[i % MT][g] = mfma16(av, (i / MT) ? sf[1][g] : sf[0][g], acc2[i % MT][g]);
+                },
+                [&](int i) { if ((i & 1) == 0 && (i >> 1) < NIDX) dma_piece(ng + 1, i >> 1); });      // unit U1 (first group of V2's image) follows the last pixel group
+#pragma unroll
+            for (int idx = MT; idx < NIDX; ++idx) dma_piece(ng + 1, idx);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) sf[kk][g] = sf_n[kk][g];
+        }
+        // dpre2 = gx * dg2 * (1 - g2^2); the lane's 8 features of hidden k-step ks are tiles 2ks (j < 4) and 2ks+1 (j >= 4)
+        float gxv[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) gxv[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint4 y8 = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = bf_at(y8, j);
+                    v[j] = gxv[g] * acc2[2 * ks + (j >> 2)][g][j & 3] * (1.0f - y * y);
+                }
+                const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                d2f[ks][g] = valid[g] ? frag : make_uint4(0, 0, 0, 0);
+                if (valid[g]) *(uint4*)(a.DPP + (size_t)row[g] * a.ldG + ks * 32 + 8 * q) = frag;
+            }
+        }
+    }
+    // ---------------- products 2 and 3: Y^T = backward image x X^T with X in registers, one 64-out-feature group per unit
+    constexpr int NF = KT * 4, STEP = (NF / NIDX > 0) ? NF / NIDX : 1;
+    auto group_mfma = [&](int u, const uint4 (&xin)[KT][2], f32x4 (&acc)[4][2]) {
+        const int buf = u & 1;
+        wait_all_vmem();
+        __syncthreads();
+        const bool more = u + 1 < U3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        const char* lb = smem + buf * unit + a_off;
+        lds_pipeline<NF, 8>(
+            [&](int i) { return *(const uint4*)(lb + i * 1024); },
+            [&](int i, const uint4& av) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, xin[i >> 2][g], acc[i & 3][g]);
+            },
+            [&](int i) { if (more && i % STEP == 0 && i / STEP < NIDX) dma_piece(u + 1, i / STEP); });
+        if (more) {
+#pragma unroll
+            for (int idx = (NF + STEP - 1) / STEP; idx < NIDX; ++idx) dma_piece(u + 1, idx);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) d1f[ks][g] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int mg = 0; mg < MG2; ++mg) {
+        // stored g1 of this group's 64 features: requested before the MFMAs, used after them
+        uint4 y8[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                y8[p][g] = make_uint4(0, 0, 0, 0);
+                if (2 * mg + p < KT) y8[p][g] = *(const uint4*)(d.G1 + (size_t)rowc[g] * a.ldG + (2 * mg + p) * 32 + q * 8);
+            }
+        f32x4 acc[4][2];
+        group_mfma(U1 + mg, d2f, acc);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int kso = 2 * mg + p;
+            if (kso < KT) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float y = bf_at(y8[p][g], j);
+                        v[j] = acc[2 * p + (j >> 2)][g][j & 3] * (1.0f - y * y);
+                    }
+                    const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                    d1f[kso][g] = valid[g] ? frag : make_uint4(0, 0, 0, 0);       // (kso is a compile-time value: the group loop is unrolled)
+                    if (valid[g]) *(uint4*)(d.D1P + (size_t)row[g] * a.ldG + kso * 32 + 8 * q) = frag;
+                }
+            }
+        }
+    }
+    for (int mg = 0; mg < d.MG1; ++mg) {
+        f32x4 acc[4][2];
+        group_mfma(U2 + mg, d1f, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f0 = 64 * mg + 16 * t + 4 * q;
+            if (64 * mg + 16 * t < d.ldDZ) {       // wave-uniform
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    if (valid[g]) *(float4*)(d.DZ + (size_t)row[g] * d.ldDZ + f0) = make_float4(acc[t][g][0], acc[t][g][1], acc[t][g][2], acc[t][g][3]);
+            }
+        }
+    }
+}
+
 // dpre2 = gx * (sum of the partial dg2 slices) * (1 - g2^2), elementwise in P order: one thread per 8-feature chunk
 __global__ __launch_bounds__(256) void out_bwd_finish_kernel(OutBwdArgs a, int nparts) {
     const int nch = a.ldG / 8;
@@ -1703,12 +1890,34 @@ __global__ __launch_bounds__(256) void out_bwd_finish_kernel(OutBwdArgs a, int n
 #ifndef WGRAD_WI_SC
 #define WGRAD_WI_SC 2
 #endif
+// counted wait: all but the wave's n youngest vector-memory operations (here: LDS-DMA pieces, issued in stage order) are done
+__device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0..8
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+// Staging: the operands move through a RING of WG_NST LDS stages of WG_SR = 32 data rows each; while stage c is multiplied the
+// DMA of stage c + 3 is issued (pieces spread between the MFMAs), and the top of stage c + 1 waits only for ITS pieces
+// (s_waitcnt vmcnt(n) with the two younger stages' pieces still in flight).  Round 1 double-buffered 64-row chunks and
+// waited for chunk c + 1 right after issuing its last piece: every chunk exposed one full HBM round trip (~1.5-2 us under
+// load against ~1 us of MFMA + LDS work; 3.9 us per chunk measured on the output layer's gradient = 0.13 of the HBM peak).
+#define WG_SR 32
+#define WG_NST 4
 template <int NW, bool SC>     // SC: G rows carry a per-row weight (a.rowscale), staged through LDS with the tiles
 __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int XT_BYTES = 64 * 512;                 // X tile: 64 rows x 512 B (256 features)
+    constexpr int XT_BYTES = WG_SR * 512;              // X tile: 32 rows x 512 B (256 features)
     constexpr int GROW = NW * 32;                      // G strip row bytes (512 for 16 waves, 256 for 8)
-    constexpr int GT_BYTES = 64 * GROW;
+    constexpr int GT_BYTES = WG_SR * GROW;
     constexpr int BUF = XT_BYTES + GT_BYTES + (SC ? 1024 : 0);
     constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, NPC = XP + GP + (SC ? 1 : 0), NIDX = (NPC + NW - 1) / NW;
     typedef __attribute__((ext_vector_type(4))) short v4s;
@@ -1721,14 +1930,17 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     const int split = bz;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.M, rbeg + a.rows_per_split);
-    const int nchunk = (rend - rbeg + 63) / 64;
+    const int nstage = (rend - rbeg + WG_SR - 1) / WG_SR;
     const int xcol0 = it0 * 16, gcol0 = bx * NW * 16;       // first feature (= P position, both multiples of 32) of the tiles
+    int my_pieces = 0;                                       // DMA pieces this wave issues per stage (wave-uniform)
+#pragma unroll
+    for (int idx = 0; idx < NIDX; ++idx) my_pieces += (wave + NW * idx < NPC) ? 1 : 0;
 
     // one DMA piece = 1 KiB of LDS = 2 X rows (32 slots each) or 1024/GROW G rows
-    auto dma_piece = [&](int c, int buf, int idx) {
+    auto dma_piece = [&](int c, int idx) {
         const int pc = wave + NW * idx;               // wave-uniform
         if (pc >= NPC) return;
-        const int r0 = rbeg + c * 64;
+        const int r0 = rbeg + c * WG_SR;
         const char* src;
         if (pc < XP) {
             const int rl = 2 * pc + (lane >> 5), s = lane & 31;
@@ -1736,8 +1948,8 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             const int col = xcol0 + cch * 8;
             const bool ok = (r0 + rl) < rend && col < a.ldX;
             src = ok ? (const char*)a.X + ((size_t)(r0 + rl) * a.ldX + col) * 2 : a.zero + (lane & 31) * 16;
-        } else if (SC && pc == XP + GP) {                                // the chunk's 64 row weights (256 B; the pad rows of gx are finite)
-            src = lane < 16 ? (const char*)(a.rowscale + r0) + lane * 16 : a.zero + (lane & 31) * 16;
+        } else if (SC && pc == XP + GP) {                                // the stage's 32 row weights (128 B; the pad rows of gx are finite)
+            src = lane < WG_SR / 4 ? (const char*)(a.rowscale + r0) + lane * 16 : a.zero + (lane & 31) * 16;
         } else {
             constexpr int SPR = GROW / 16, RPP = 1024 / GROW;            // slots per row, rows per piece
             const int rl = RPP * (pc - XP) + lane / SPR, s = lane % SPR;
@@ -1746,7 +1958,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             const bool ok = (r0 + rl) < rend && col < a.ldG;
             src = ok ? (const char*)a.G + ((size_t)(r0 + rl) * a.ldG + col) * 2 : a.zero + (lane & 31) * 16;
         }
-        glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * BUF) + (uint32_t)pc * 1024u)));
+        glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (c % WG_NST) * BUF) + (uint32_t)pc * 1024u)));
     };
 
     f32x4 acc[AI][BJ];
@@ -1757,40 +1969,39 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     float bsum[BJ];
 #pragma unroll
     for (int u = 0; u < BJ; ++u) bsum[u] = 0.0f;
-    if (nchunk > 0) {
+    for (int c = 0; c < min(nstage, WG_NST - 1); ++c) {
 #pragma unroll
-        for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, 0, idx);
+        for (int idx = 0; idx < NIDX; ++idx) dma_piece(c, idx);
     }
     // lane-constant parts of the transposing-read addresses: row 4q+q' of a 16-row half-step, piece p
     const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
 
-    for (int c = 0; c < nchunk; ++c) {
-        const int buf = c & 1;
-        wait_all_vmem();
-        __syncthreads();
-        const bool more = c + 1 < nchunk;
+    for (int c = 0; c < nstage; ++c) {
+        const int buf = c % WG_NST;
+        wait_vmem_but(my_pieces * min(WG_NST - 2, nstage - 1 - c));      // stage c has landed; the (<= 2) younger stages may still fly
+        __syncthreads();                                                 // ... for every wave; and everyone is done reading stage c - 1
+        const bool more = c + WG_NST - 1 < nstage;                       // stage c + 3 goes into the buffer stage c - 1 has just left
         int dma_idx = 0;
         auto dma_next = [&]() {
-            if (more && dma_idx < NIDX) dma_piece(c + 1, buf ^ 1, dma_idx);
+            if (more && dma_idx < NIDX) dma_piece(c + WG_NST - 1, dma_idx);
             ++dma_idx;
         };
         const char* xb = smem + buf * BUF + xrow_off + p * 16;
         const char* gbase = smem + buf * BUF + XT_BYTES + grow_off;
-#pragma unroll
-        for (int rs = 0; rs < 2; ++rs) {
+        {
             // B fragments: 8 data rows (two 4-row blocks) of each of this wave's BJ j-tiles (local tile jl -> chunk 4*(jl>>1)+p, half jl&1)
             uint4 g[BJ];
 #pragma unroll
             for (int u = 0; u < BJ; ++u) {
                 const int jl = jg * BJ + u;
                 const char* gb = gbase + ((((4 * (jl >> 1)) ^ (qp << 2)) + p) * 16) + 8 * (jl & 1);
-                const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs) * GROW));
-                const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + (32 * rs + 16) * GROW));
+                const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)gb);
+                const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + 16 * GROW));
                 const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
                 g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
             }
-            if (SC) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row step (output layer: G = s, weight = dLoss/dlpxz)
-                const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 32 * rs + 4 * q;
+            if (SC) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row stage (output layer: G = s, weight = dLoss/dlpxz)
+                const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 4 * q;
                 const float4 s0 = *(const float4*)scl, s1 = *(const float4*)(scl + 16);
 #pragma unroll
                 for (int u = 0; u < BJ; ++u)
@@ -1805,7 +2016,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
             lds_pipeline<AI, (AI < 3 ? AI : 3)>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
-                    const char* p0 = xb + (32 * rs) * 512 + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
+                    const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
                     const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
                     const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 16 * 512));
                     const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
@@ -1817,7 +2028,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
                         for (int u = 0; u < BJ; ++u) acc[t][u] = mfma16(av, g[u], acc[t][u]);
                     }
                 },
-                [&](int t) { if (t == 0 || (AI > 1 && t == AI / 2)) dma_next(); });
+                [&](int t) { if (t == 0 || (AI > 1 && t == AI / 2) || (AI > 3 && t == AI - 1)) dma_next(); });
         }
         while (dma_idx < NIDX) dma_next();
     }
@@ -2616,6 +2827,16 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     }
 }
 bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
+void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st) {
+    const size_t lds = 2 * ((size_t)d.o.KT * 4096 + 1024);
+    dim3 grid((d.o.M + 127) / 128);
+    switch (d.o.KT) {
+        case 7: LAUNCH_EV(dec_bwd_kernel<7>, grid, dim3(256), lds, st, d); break;
+        case 4: LAUNCH_EV(dec_bwd_kernel<4>, grid, dim3(256), lds, st, d); break;
+        case 2: LAUNCH_EV(dec_bwd_kernel<2>, grid, dim3(256), lds, st, d); break;
+        default: break;      // the host only asks where out_bwd_has_s_mode(KT)
+    }
+}
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     if (a.SP) {      // the forward pass kept s = x - sigmoid(l): one product, B operand from HBM
         const size_t lds = 2 * ((size_t)a.KT * 4096 + 1024);
@@ -2658,16 +2879,16 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
     int mx = 0, my = 0;
     for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
-    hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), 2 * (64 * 512 + 64 * 256), st, g);
+    hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, g);
 }
 void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
     dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);
     if (a.rowscale) {
-        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, true>), grid, dim3(1024), 2 * (64 * 512 + 64 * 512 + 1024), st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, true>), grid, dim3(512), 2 * (64 * 512 + 64 * 256 + 1024), st, a);
+        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, true>), grid, dim3(1024), WG_NST * (WG_SR * 512 + WG_SR * 512 + 1024), st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, true>), grid, dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256 + 1024), st, a);
     } else {
-        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, false>), grid, dim3(1024), 2 * (64 * 512 + 64 * 512), st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, false>), grid, dim3(512), 2 * (64 * 512 + 64 * 256), st, a);
+        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, false>), grid, dim3(1024), WG_NST * (WG_SR * 512 + WG_SR * 512), st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, false>), grid, dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, a);
     }
 }
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st) {

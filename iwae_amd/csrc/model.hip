@@ -70,9 +70,9 @@ struct MlpWs {     // decode_z_to_x applied to M rows
 }  // namespace
 
 // kernels iwae_enable_timing brackets with HIP events (on the stream each is launched on); names: iwae_kernel_time
-enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_COUNT };
+enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_DEC_BWD, T_COUNT };
 static const char* const kTimedNames[T_COUNT] = {"out_bwd", "decoder_fwd", "wgrad_out", "dx_hidden", "dx_latent", "wgrad_hidden", "wgrad_latent",
-                                                 "latent_bwd", "encoder_fwd", "reduce_adam"};
+                                                 "latent_bwd", "encoder_fwd", "reduce_adam", "decoder_bwd"};
 
 struct iwae_model {
     iwae_config cfg;
@@ -152,6 +152,7 @@ struct iwae_model {
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
+    bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
     int num_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -843,6 +844,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     CHK(ensure(w.d2P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.dz, (size_t)Mp * m->Dp[0] * 4, st));
+    bool fused_dx = false;
     {
         Linear& L = m->dec1[2];
         OutBwdArgs a;
@@ -863,32 +865,43 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             CHK(ensure(m->stamps, (size_t)(Mp / 64) * 4 * 8 * 8, st));
             a.stamps = ptr<unsigned long long>(m->stamps);
         }
+            // One launch for out_bwd + dX of d2 + dX of d1 (dec_bwd_kernel) where it exists: large row counts, s kept by the forward
+            // pass, hidden width with an instantiation; dpre2 / dpre1 stay in registers from product to product.
+            fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && M >= 8192 && !a.stamps && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
+                       m->dec1[0].KT_B == L.KT && m->dec1[1].Kp32 == L.Kp32 && m->dec1[0].Np32 == L.Kp32;
+            if (fused_dx) {
+                DecBwdArgs d;
+                memset(&d, 0, sizeof(d));
+                d.o = a;
+                d.imgB2 = m->dec1[1].imgB; d.G1 = ptr<uint16_t>(w.g1P); d.D1P = ptr<uint16_t>(w.d1P);
+                d.imgB1 = m->dec1[0].imgB; d.MG1 = m->dec1[0].MG_B; d.DZ = ptr<float>(w.dz); d.ldDZ = m->dec1[0].Kp32;
+                ScopedTimer tm(m, T_DEC_BWD);
+                set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
+                launch_dec_bwd(d, st);
+            } else {
             // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
             { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
+            }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    if (m->early_wout) {     // forked behind lse_kernel (forward_impl)
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
-        { ScopedTimer tm(m, T_WGRAD_OUT, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, ptr<float>(m->gx))); }
-    } else {
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));      // ev_fork rode on out_bwd's dispatch packet
-        { ScopedTimer tm(m, T_WGRAD_OUT, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
+    if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
+    else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
+    { ScopedTimer tm(m, T_WGRAD_OUT, m->side); CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr)); }
+    if (!fused_dx) {
+        { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
+        { ScopedTimer tm(m, T_DX_LAT); set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
     }
-    { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
-    { ScopedTimer tm(m, T_DX_LAT); set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
-    // ONE event behind both dX kernels (every record costs the main stream a ~6 us bubble): the first decoder layer's weight
-    // gradient needs dpre1 (dX of d2) and sits behind two other weight gradients on the side stream anyway; the deferred
-    // decoder update further down that stream must come after dX of d1, the last reader of the decoder's weight images.
-    // It rides on that kernel's dispatch packet (set_launch_stop_event above).
-    // Forked early, the side stream is busy with the output layer's gradient until after dX of d1: ONE wait (ev_fork2) then
-    // covers out_bwd (dpre2), dX of d2 (dpre1) and dX of d1, and out_bwd carries no event at all -- one bubble less on the
-    // main stream, one wait less on the side stream.
+    // ONE event (ev_fork2) behind the whole dX chain -- the last of its kernels carries it on its dispatch packet (every separate
+    // record costs the main stream a ~6 us bubble): the hidden layers' weight gradients need dpre2 and dpre1, and the deferred
+    // decoder update further down the side stream must come after dX of d1, the last reader of the decoder's weight images.
+    // Forked early, the side stream is busy with the output layer's gradient until after that: ONE wait then covers everything,
+    // and out_bwd carries no event at all -- one bubble less on the main stream, one wait less on the side stream.
     if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     { ScopedTimer tm(m, T_WGRAD_HID, m->side); CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side)); }
-    if (!m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+    if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
     { ScopedTimer tm(m, T_WGRAD_LAT, m->side); CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side)); }
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
@@ -1096,6 +1109,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
+    m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
