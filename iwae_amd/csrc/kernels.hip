@@ -1936,28 +1936,41 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
 #pragma unroll
     for (int idx = 0; idx < NIDX; ++idx) my_pieces += (wave + NW * idx < NPC) ? 1 : 0;
 
-    // one DMA piece = 1 KiB of LDS = 2 X rows (32 slots each) or 1024/GROW G rows
+    // one DMA piece = 1 KiB of LDS = 2 X rows (32 slots each) or 1024/GROW G rows.  A lane fetches the same (row in stage,
+    // 16-byte chunk) of its pieces in every stage: the source address is a per-lane base + stage * (32 rows of bytes), both
+    // precomputed (as per-stage 64-bit index arithmetic it was ~25 vector instructions per piece, 96 per wave and stage in
+    // all against 16 MFMAs -- SQ_INSTS_VALU of the round-2 profile).
+    const char* zsrc = a.zero + (lane & 31) * 16;
+    const char* pbase[NIDX];       // lane's source at stage 0
+    int plim[NIDX];                // the piece's row is valid in stage c iff c * WG_SR < plim
+    int pstride[NIDX];             // bytes per stage (wave-uniform)
+#pragma unroll
+    for (int idx = 0; idx < NIDX; ++idx) {
+        const int pc = wave + NW * idx;               // wave-uniform
+        pbase[idx] = zsrc; plim[idx] = -(1 << 30); pstride[idx] = 0;
+        if (pc < XP) {
+            const int rl = 2 * pc + (lane >> 5), sl = lane & 31;
+            const int col = xcol0 + (sl ^ ((rl & 3) << 2)) * 8;           // source 16-byte chunk of this LDS slot
+            pbase[idx] = (const char*)a.X + ((size_t)(rbeg + rl) * a.ldX + col) * 2;
+            plim[idx] = col < a.ldX ? rend - rbeg - rl : -(1 << 30);
+            pstride[idx] = WG_SR * a.ldX * 2;
+        } else if (SC && pc == XP + GP) {                                // the stage's 32 row weights (128 B; the pad rows of gx are finite)
+            pbase[idx] = (const char*)(a.rowscale + rbeg) + (lane & 7) * 16;
+            plim[idx] = lane < WG_SR / 4 ? (1 << 30) : -(1 << 30);
+            pstride[idx] = WG_SR * 4;
+        } else if (pc < NPC) {
+            constexpr int SPR = GROW / 16, RPP = 1024 / GROW;            // slots per row, rows per piece
+            const int rl = RPP * (pc - XP) + lane / SPR, sl = lane % SPR;
+            const int col = gcol0 + (sl ^ ((rl & 3) << 2)) * 8;
+            pbase[idx] = (const char*)a.G + ((size_t)(rbeg + rl) * a.ldG + col) * 2;
+            plim[idx] = col < a.ldG ? rend - rbeg - rl : -(1 << 30);
+            pstride[idx] = WG_SR * a.ldG * 2;
+        }
+    }
     auto dma_piece = [&](int c, int idx) {
         const int pc = wave + NW * idx;               // wave-uniform
         if (pc >= NPC) return;
-        const int r0 = rbeg + c * WG_SR;
-        const char* src;
-        if (pc < XP) {
-            const int rl = 2 * pc + (lane >> 5), s = lane & 31;
-            const int cch = s ^ ((rl & 3) << 2);                          // source 16-byte chunk of this LDS slot
-            const int col = xcol0 + cch * 8;
-            const bool ok = (r0 + rl) < rend && col < a.ldX;
-            src = ok ? (const char*)a.X + ((size_t)(r0 + rl) * a.ldX + col) * 2 : a.zero + (lane & 31) * 16;
-        } else if (SC && pc == XP + GP) {                                // the stage's 32 row weights (128 B; the pad rows of gx are finite)
-            src = lane < WG_SR / 4 ? (const char*)(a.rowscale + r0) + lane * 16 : a.zero + (lane & 31) * 16;
-        } else {
-            constexpr int SPR = GROW / 16, RPP = 1024 / GROW;            // slots per row, rows per piece
-            const int rl = RPP * (pc - XP) + lane / SPR, s = lane % SPR;
-            const int cch = s ^ ((rl & 3) << 2);
-            const int col = gcol0 + cch * 8;
-            const bool ok = (r0 + rl) < rend && col < a.ldG;
-            src = ok ? (const char*)a.G + ((size_t)(r0 + rl) * a.ldG + col) * 2 : a.zero + (lane & 31) * 16;
-        }
+        const char* src = (c * WG_SR < plim[idx]) ? pbase[idx] + (size_t)c * (size_t)pstride[idx] : zsrc;
         glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (c % WG_NST) * BUF) + (uint32_t)pc * 1024u)));
     };
 

@@ -143,6 +143,9 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
+    hipEvent_t ev_s2 = nullptr;
+    bool use_side2 = true;
     hipEvent_t ev_lse = nullptr;
     bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
@@ -899,10 +902,21 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // decoder update further down the side stream must come after dX of d1, the last reader of the decoder's weight images.
     // Forked early, the side stream is busy with the output layer's gradient until after that: ONE wait then covers everything,
     // and out_bwd carries no event at all -- one bubble less on the main stream, one wait less on the side stream.
-    if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    { ScopedTimer tm(m, T_WGRAD_HID, m->side); CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, m->side)); }
+    // The hidden layers' weight gradients need dpre2 / dpre1 (ev_fork2), not the output layer's gradient: forked early, that one
+    // keeps `side` busy well past the end of the dX chain, so they go to a second side stream and run beside it; `side` picks
+    // them up again (ev_s2) in front of whatever follows on it (the decoder's slab reduction / the join).
+    hipStream_t ws = m->side;
+    if (m->early_wout && m->use_side2) {
+        HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
+        ws = m->side2;
+    } else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+    { ScopedTimer tm(m, T_WGRAD_HID, ws); CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, ws)); }
     if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    { ScopedTimer tm(m, T_WGRAD_LAT, m->side); CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, m->side)); }
+    { ScopedTimer tm(m, T_WGRAD_LAT, ws); CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, ws)); }
+    if (ws == m->side2) {
+        HIPCHK(hipEventRecord(m->ev_s2, m->side2));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_s2, 0));
+    }
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -1141,6 +1155,9 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int prio = getenv("IWAE_SIDE_PRIO_NORMAL") ? 0 : least;
         HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
+        HIPCHK(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_s2, hipEventDisableTiming));
+        m->use_side2 = getenv("IWAE_NO_SIDE2") == nullptr;
     }
     HIPCHK(hipEventCreateWithFlags(&m->ev_lse, hipEventDisableTiming));
     m->allow_early_wout = getenv("IWAE_NO_EARLY_WOUT") == nullptr;
@@ -1221,6 +1238,8 @@ void iwae_destroy(iwae_handle m) {
         for (hipEvent_t e : m->ev_start[i]) (void)hipEventDestroy(e);
         for (hipEvent_t e : m->ev_stop[i]) (void)hipEventDestroy(e);
     }
+    if (m->side2) { (void)hipStreamSynchronize(m->side2); (void)hipStreamDestroy(m->side2); }
+    if (m->ev_s2) (void)hipEventDestroy(m->ev_s2);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
@@ -1580,7 +1599,8 @@ int iwae_kernel_time(iwae_handle m, const char* name, double* avg_us, int64_t* l
     }
     CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // the weight gradients are timed on the side stream
+    if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // the weight gradients are timed on the side streams
+    if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
     double tot = 0.0;
     for (size_t i = 0; i < m->ev_used[id]; ++i) {
         float ms = 0.f;
