@@ -178,7 +178,8 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
 bool bern_pipe_ok(const DenseArgs& a);  // shapes bern_pipe_kernel covers (launch_dense falls back to dense_kernel<EPI_BERN> otherwise)
 bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel / dec_bwd_kernel
 void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st);
-void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st);
+void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st);      // shape: see wgradp_strip
+int wgradp_strip(int shape);          // j-tiles (16 out-features each) per block of a shape: 8 -> 8, 16 / 7 -> 16
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,

@@ -1887,11 +1887,8 @@ __global__ __launch_bounds__(256) void out_bwd_finish_kernel(OutBwdArgs a, int n
 // either way) and reads 16/WI + WI fragments per 32-row step instead of 16 + 1 -- the transposing LDS reads (2-way bank
 // conflict by construction) were what a 64-row chunk waited for (4 352 LDS cycles per chunk against 2 048 MFMA cycles per
 // SIMD at 16 x 1).  The row-weighted variant scales every G fragment it reads, so it takes the 8 x 2 shape.
-#ifndef WGRAD_WI_SC
-#define WGRAD_WI_SC 2
-#endif
 // counted wait: all but the wave's n youngest vector-memory operations (here: LDS-DMA pieces, issued in stage order) are done
-__device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0..8
+__device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0..12
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -1901,7 +1898,11 @@ __device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0
         case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     }
 }
 
@@ -1912,26 +1913,34 @@ __device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0
 // load against ~1 us of MFMA + LDS work; 3.9 us per chunk measured on the output layer's gradient = 0.13 of the HBM peak).
 #define WG_SR 32
 #define WG_NST 4
-template <int NW, bool SC>     // SC: G rows carry a per-row weight (a.rowscale), staged through LDS with the tiles
+// Shapes <NW waves, IGC i-groups, AI x BJ accumulator tiles per wave>: the waves form an IGC x (NW/IGC) grid, the workgroup's
+// output tile is IGC*AI i-tiles x (NW/IGC)*BJ j-tiles.  A 32-row stage costs a wave AI + BJ fragment reads for AI*BJ MFMAs:
+//   <16, 4, 4, 4>  256 x 256 features, 0.50 reads per MFMA (round 1's shape; the hidden layers at large row counts)
+//   <16, 2, 8, 2>  the same tile for the row-weighted variant (scales its 2 G fragments), 0.63
+//   < 8, 2, 7, 4>  224 x 256 features with EIGHT waves (two per SIMD, 28 accumulator tiles each): 0.39 reads per MFMA -- below the
+//                  0.5 at which the LDS (2-way conflict of the transposing reads: 128 B/clk) keeps up with the MFMA pipes -- and
+//                  half the waves at every barrier; for layers whose input is <= 224 features wide (the decoder's)
+//   < 8, 4, 4, 4>  256 x 128 features, 8 waves: small row counts (grouped launch for an encoder block)
+template <int NW, int IGC, int AI, int BJ, bool SC>     // SC: G rows carry a per-row weight (a.rowscale), staged through LDS with the tiles
 __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int XT_BYTES = WG_SR * 512;              // X tile: 32 rows x 512 B (256 features)
-    constexpr int GROW = NW * 32;                      // G strip row bytes (512 for 16 waves, 256 for 8)
+    constexpr int JGC = NW / IGC, STRIP = JGC * BJ;    // j-tiles of the workgroup's G strip
+    constexpr int GROW = STRIP * 32;                   // G strip row bytes (512 for 16 j-tiles, 256 for 8)
     constexpr int GT_BYTES = WG_SR * GROW;
     constexpr int BUF = XT_BYTES + GT_BYTES + (SC ? 1024 : 0);
     constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, NPC = XP + GP + (SC ? 1 : 0), NIDX = (NPC + NW - 1) / NW;
     typedef __attribute__((ext_vector_type(4))) short v4s;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
-    constexpr int WI = SC ? WGRAD_WI_SC : 4, AI = 16 / WI, BJ = WI;
-    const int ig = wave % WI, jg = wave / WI;          // the wave's i-tiles ig*AI .. +AI-1, local j-tiles jg*BJ .. +BJ-1
+    const int ig = wave % IGC, jg = wave / IGC;        // the wave's i-tiles ig*AI .. +AI-1, local j-tiles jg*BJ .. +BJ-1
     const int it0 = by * 16;
-    const int nit = min(16, a.IT - it0);
+    const int nit = min(IGC * AI, a.IT - it0);
     const int split = bz;
     const int rbeg = split * a.rows_per_split;
     const int rend = min(a.M, rbeg + a.rows_per_split);
     const int nstage = (rend - rbeg + WG_SR - 1) / WG_SR;
-    const int xcol0 = it0 * 16, gcol0 = bx * NW * 16;       // first feature (= P position, both multiples of 32) of the tiles
+    const int xcol0 = it0 * 16, gcol0 = bx * STRIP * 16;    // first feature (= P position, both multiples of 32) of the tiles
     int my_pieces = 0;                                       // DMA pieces this wave issues per stage (wave-uniform)
 #pragma unroll
     for (int idx = 0; idx < NIDX; ++idx) my_pieces += (wave + NW * idx < NPC) ? 1 : 0;
@@ -2050,7 +2059,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
 #pragma unroll
     for (int u = 0; u < BJ; ++u) {
-        const int jt = bx * NW + jg * BJ + u;
+        const int jt = bx * STRIP + jg * BJ + u;
         if (jt < a.JT) {
 #pragma unroll
             for (int t = 0; t < AI; ++t) {
@@ -2071,8 +2080,8 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
     }
 }
 
-template <int NW, bool SC>
-__global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
+template <int NW, int IGC, int AI, int BJ, bool SC>
+__global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_kernel(WgradPArgs a) {
     // XCD-aware block order: the hardware deals workgroups round-robin to the 8 XCDs (private L2 each).  Renumber
     // so that blocks which share operands -- the j-blocks / i-blocks of one row split -- sit on ONE XCD and are
     // dispatched back to back: the shared X tile then comes from HBM once instead of once per j-block.
@@ -2083,7 +2092,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void wgradp_kernel(WgradPArgs a) {
         const int V = (L & 7) * (nb >> 3) + (L >> 3);
         bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
     }
-    wgradp_body<NW, SC>(a, bx, by, bz);
+    wgradp_body<NW, IGC, AI, BJ, SC>(a, bx, by, bz);
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
@@ -2092,7 +2101,7 @@ __global__ __launch_bounds__(512, 2) void wgradp_group_kernel(WgradPGroup g) {
     int l = 0;
     while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
     if ((int)blockIdx.x >= g.gx[l] || (int)blockIdx.y >= g.gy[l]) return;
-    wgradp_body<8, false>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
+    wgradp_body<8, 4, 4, 4, false>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -2894,14 +2903,23 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
     for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
     hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, g);
 }
-void launch_wgradp(const WgradPArgs& a, int nsplit, int nw, hipStream_t st) {
-    dim3 grid((a.JT + nw - 1) / nw, (a.IT + 15) / 16, nsplit);
-    if (a.rowscale) {
-        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, true>), grid, dim3(1024), WG_NST * (WG_SR * 512 + WG_SR * 512 + 1024), st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, true>), grid, dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256 + 1024), st, a);
+// shape: 8 = 8 waves / 8 j-tiles per block (small), 16 = 16 waves / 16 j-tiles, 7 = 8 waves / 16 j-tiles with 7 x 4 tiles per wave (IT <= 14)
+int wgradp_strip(int shape) { return shape == 8 ? 8 : 16; }
+void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st) {
+    dim3 grid((a.JT + wgradp_strip(shape) - 1) / wgradp_strip(shape), (a.IT + 15) / 16, nsplit);
+    const size_t sc = a.rowscale ? 1024 : 0;
+    if (shape == 7) {
+        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
+        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<8, 2, 7, 4, true>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, 2, 7, 4, false>), grid, dim3(512), lds, st, a);
+    } else if (shape == 16) {
+        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
+        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<16, 4, 4, 4, false>), grid, dim3(1024), lds, st, a);
     } else {
-        if (nw == 16) hipLaunchKernelGGL((wgradp_kernel<16, false>), grid, dim3(1024), WG_NST * (WG_SR * 512 + WG_SR * 512), st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, false>), grid, dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, a);
+        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 256 + sc);
+        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<8, 4, 4, 4, true>), grid, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((wgradp_kernel<8, 4, 4, 4, false>), grid, dim3(512), lds, st, a);
     }
 }
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st) {

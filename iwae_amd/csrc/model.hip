@@ -155,6 +155,7 @@ struct iwae_model {
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
+    bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
@@ -454,16 +455,18 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R,
 
 // ---------------------------------------------------------------- backward pieces
 // weight gradient from the P-layout operands (wgradp_kernel); XP/GP row-major bf16, `rows` valid rows.
-// wgradp_plan sizes the row splits and the slabs and fills the argument block; nw = waves per block (8 / 16).
+// wgradp_plan sizes the row splits and the slabs and fills the argument block; nw = the kernel shape (launch_wgradp:
+// 8 = small, 16 = 16 waves, 7 = 8 waves with 7 x 4 accumulator tiles each, for inputs <= 224 features wide).
 int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, WgradPArgs& a, int& nsplit, int& nw) {
     const int chunks = (rows + 63) / 64;
     nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
-    const int blocks = ((L.JT + nw - 1) / nw) * ((L.IT + 15) / 16);
+    if (nw == 16 && L.IT <= 14 && m->allow_wg7) nw = 7;
+    const int blocks = ((L.JT + wgradp_strip(nw) - 1) / wgradp_strip(nw)) * ((L.IT + 15) / 16);
     // Workgroup targets (measured at k=50, B=1024).  Early builds, the weight gradients alone on the machine: 64 -> 0.501,
     // 128 -> 0.425, 256 -> 0.406, 384 -> 0.443 ms/step (fewer leaves CUs idle, more pays a full fp32 slab per extra split).
     // Since they run beside the dX chain and with the register-blocked kernel: 160 (see wg_target16); the
     // single-block-wide hidden layers prefer 128.
-    const int target = (nw == 16) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : m->wg_target8;
+    const int target = (nw != 8) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : m->wg_target8;
     nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
@@ -1124,6 +1127,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
+    m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
