@@ -2002,7 +2002,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
         const int buf = c % WG_NST;
         wait_vmem_but(my_pieces * min(WG_NST - 2, nstage - 1 - c));      // stage c has landed; the (<= 2) younger stages may still fly
         __syncthreads();                                                 // ... for every wave; and everyone is done reading stage c - 1
-        const bool more = c + WG_NST - 1 < nstage;                       // stage c + 3 goes into the buffer stage c - 1 has just left
+        const bool more = c + WG_NST - 1 < nstage && !(a.dbg & 1);       // stage c + 3 goes into the buffer stage c - 1 has just left
         int dma_idx = 0;
         auto dma_next = [&]() {
             if (more && dma_idx < NIDX) dma_piece(c + WG_NST - 1, dma_idx);
@@ -2022,7 +2022,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
                 const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
                 g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
             }
-            if (SC) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row stage (output layer: G = s, weight = dLoss/dlpxz)
+            if (SC && !(a.dbg & 8)) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row stage (output layer: G = s, weight = dLoss/dlpxz)
                 const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 4 * q;
                 const float4 s0 = *(const float4*)scl, s1 = *(const float4*)(scl + 16);
 #pragma unroll
@@ -2030,12 +2030,12 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
                     g[u] = make_uint4(pack2(bflo(g[u].x) * s0.x, bfhi(g[u].x) * s0.y), pack2(bflo(g[u].y) * s0.z, bfhi(g[u].y) * s0.w),
                                       pack2(bflo(g[u].z) * s1.x, bfhi(g[u].z) * s1.y), pack2(bflo(g[u].w) * s1.z, bfhi(g[u].w) * s1.w));
             }
-            if (ig == 0) {       // bias gradient = column sums of G: one wave per j-tile (wave-uniform branch)
+            if (ig == 0 && !(a.dbg & 4)) {       // bias gradient = column sums of G: one wave per j-tile (wave-uniform branch)
 #pragma unroll
                 for (int u = 0; u < BJ; ++u)
                     bsum[u] += bflo(g[u].x) + bfhi(g[u].x) + bflo(g[u].y) + bfhi(g[u].y) + bflo(g[u].z) + bfhi(g[u].z) + bflo(g[u].w) + bfhi(g[u].w);
             }
-            lds_pipeline<AI, (AI < 3 ? AI : 3)>(
+            if (!(a.dbg & 2)) lds_pipeline<AI, (AI < 3 ? AI : 3)>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
                     const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
@@ -2057,6 +2057,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
 
     // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
     float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
+    if (a.dbg & 16) return;
 #pragma unroll
     for (int u = 0; u < BJ; ++u) {
         const int jt = bx * STRIP + jg * BJ + u;
@@ -2093,6 +2094,204 @@ __global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_k
         bx = V % gx; by = (V / gx) % gy; bz = V / (gx * gy);
     }
     wgradp_body<NW, IGC, AI, BJ, SC>(a, bx, by, bz);
+}
+
+// ---------------------------------------------------------------------------------
+// wgradws_kernel: the weight gradient of a layer whose input is <= 224 features wide (the decoder's three layers) at large
+// row counts, with SPECIALISED waves.  Ablations of wgradp_kernel on the output layer (alone on the machine, 90 us): without its
+// MFMAs and A-fragment reads 92 us, without the DMA 73, without the row scaling 74, without the bias sums 82, with none of the
+// four 29 -- every wave's own instruction stream (DMA issue ~14 instructions per 1 KiB piece, 80 vector instructions of row
+// scaling, 64 of bias sums, ~100 scalar ones of loop skeleton, per 28 MFMAs) is what a 32-row stage takes, run in sequence by
+// waves that a barrier keeps in lockstep; the MFMA pipe idles 3/4 of the time.  Here:
+//   * 8 COMPUTE waves (2 x 4 grid, 7 x 4 accumulator tiles each = 224 x 256 features) only read fragments and multiply; the bias
+//     gradient (column sums of G) comes out of the matrix pipe too (one MFMA per G fragment against an all-ones A fragment);
+//   * 4 LOADER waves issue all LDS-DMA of the stage ring (3 stages ahead) and -- row-weighted variant -- scale the G rows THEY
+//     fetched in place (bf16, one rounding: dl = bf16(g_r * s)) once their own pieces have landed, one stage ahead of the
+//     compute waves; the row weights come by plain (asm) loads, two stages ahead, so nothing a loader waits for is young.
+// One barrier per stage: behind it the compute waves own stage c + 1 (landed, scaled) and the loaders own the buffer of
+// stage c (to refill) and stage c + 2 (to scale).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n in {0, 8, 12, 16, 20}
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    }
+}
+template <bool SC>
+__global__ __launch_bounds__(768, 3) void wgradws_kernel(WgradPArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int AI = 7, BJ = 4, IGC = 2, NCW = 8, NLW = 4, STRIP = 16;
+    constexpr int XT_BYTES = WG_SR * 512, GROW = 512, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
+    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, PPL = (XP + GP) / NLW, XPL = XP / NLW, GPL = GP / NLW;     // pieces per loader: 8 = 4 X + 4 G
+    typedef __attribute__((ext_vector_type(4))) short v4s;
+    int bx = blockIdx.x, bz = blockIdx.z;
+    {   // XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
+        const int gx = gridDim.x, nb = gx * (int)gridDim.z;
+        if ((nb & 7) == 0) {
+            const int L = bx + gx * bz;
+            const int V = (L & 7) * (nb >> 3) + (L >> 3);
+            bx = V % gx; bz = V / gx;
+        }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rbeg = bz * a.rows_per_split;
+    const int rend = min(a.M, rbeg + a.rows_per_split);
+    const int nstage = (rend - rbeg + WG_SR - 1) / WG_SR;
+    const int gcol0 = bx * STRIP * 16;
+
+    if (wave >= NCW) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - NCW;
+        const char* zsrc = a.zero + (lane & 31) * 16;
+        const char* pbase[PPL];
+        int plim[PPL];
+        const int xstride = WG_SR * a.ldX * 2, gstride = WG_SR * a.ldG * 2;
+#pragma unroll
+        for (int i = 0; i < PPL; ++i) {
+            const bool isx = i < XPL;
+            const int pc = isx ? lw * XPL + i : lw * GPL + (i - XPL);          // piece index inside the X tile / the G strip
+            const int rl = 2 * pc + (lane >> 5), sl = lane & 31;
+            const int col = (isx ? 0 : gcol0) + (sl ^ ((rl & 3) << 2)) * 8;     // source 16-byte chunk of this LDS slot
+            const int ld = isx ? a.ldX : a.ldG;
+            pbase[i] = (const char*)(isx ? a.X : a.G) + ((size_t)(rbeg + rl) * ld + col) * 2;
+            plim[i] = col < ld ? rend - rbeg - rl : -(1 << 30);
+        }
+        auto issue = [&](int st) {
+#pragma unroll
+            for (int i = 0; i < PPL; ++i) {
+                const bool isx = i < XPL;
+                const int pc = isx ? lw * XPL + i : XP + lw * GPL + (i - XPL);
+                const char* src = (st * WG_SR < plim[i]) ? pbase[i] + (size_t)st * (size_t)(isx ? xstride : gstride) : zsrc;
+                glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)pc * 1024u)));
+            }
+        };
+        // row weights of the lane's rows in this loader's G pieces of a stage (asm loads: the waits below count them by hand)
+        // Two register sets, alternating by stage parity: a set is overwritten (by loads issued two stages ahead) only after the
+        // stage it served has been scaled, and is read only behind the wait that covers its loads -- no copies of in-flight registers.
+        float s0[GPL], s1[GPL];
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) { s0[i] = 0.0f; s1[i] = 0.0f; }
+        auto load_sc = [&](int st, float (&dst)[GPL]) {
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) {
+                const int r = min(rbeg + st * WG_SR + 2 * (lw * GPL + i) + (lane >> 5), a.M - 1);
+                const float* pr = a.rowscale + r;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(dst[i]) : "v"(pr) : "memory");
+            }
+        };
+        auto scale_stage = [&](int st, float (&sc)[GPL]) {
+            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));      // (behind the wait: the loads are complete from here on)
+            if (a.dbg & 8) return;
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) {
+                uint4* pz = (uint4*)(smem + (st % WG_NST) * BUF + (XP + lw * GPL + i) * 1024 + lane * 16);
+                const uint4 v = *pz;
+                const float f = sc[i];
+                *pz = make_uint4(pack2(bflo(v.x) * f, bfhi(v.x) * f), pack2(bflo(v.y) * f, bfhi(v.y) * f),
+                                 pack2(bflo(v.z) * f, bfhi(v.z) * f), pack2(bflo(v.w) * f, bfhi(v.w) * f));
+            }
+        };
+        constexpr int NSC = SC ? GPL : 0;
+        // prologue: sc(0) P(0) sc(1) P(1) P(2); stage 0 ready (scaled) behind the first barrier.  Stage st's weights live in set st & 1.
+        if (SC) load_sc(0, s0);
+        if (0 < nstage) issue(0);
+        if (SC && 1 < nstage) load_sc(1, s1);
+        if (1 < nstage) issue(1);
+        if (2 < nstage) issue(2);
+        wait_vmem_but_ws((1 < nstage ? PPL + NSC : 0) + (2 < nstage ? PPL : 0));
+        if (SC) scale_stage(0, s0);
+        __syncthreads();
+        // iteration c: owned now are the buffer stage c - 1 has left (refill with stage c + 3) and stage c + 1 (scale it);
+        // issue order sc(c+2), P(c+3), so that the wait for stage c + 1 may leave P(c+2), sc(c+2), P(c+3) in flight
+        auto iter = [&](int c, float (&cur)[GPL], float (&nxt)[GPL]) {      // cur: weights of stage c + 1; nxt: receives those of stage c + 2
+            if (SC && c + 2 < nstage) load_sc(c + 2, nxt);
+            const bool refill = c + 3 < nstage && !(a.dbg & 1);
+            if (refill) issue(c + 3);
+            if (c + 1 < nstage) {
+                wait_vmem_but_ws((c + 2 < nstage ? PPL + NSC : 0) + (refill ? PPL : 0));
+                if (SC) scale_stage(c + 1, cur);
+            }
+            __syncthreads();
+        };
+        for (int c = 0; c < nstage; c += 2) {
+            iter(c, s1, s0);
+            if (c + 1 < nstage) iter(c + 1, s0, s1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
+    const int ig = wave % IGC, jg = wave / IGC;        // the wave's i-tiles ig*7 .. +6, local j-tiles jg*4 .. +3
+    f32x4 acc[AI][BJ], accb[BJ];
+#pragma unroll
+    for (int u = 0; u < BJ; ++u) {
+        accb[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < AI; ++t) acc[t][u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
+    const bool do_bias = ig == 0 && !(a.dbg & 4);
+    __syncthreads();
+    for (int c = 0; c < nstage; ++c) {
+        const int buf = c % WG_NST;
+        const char* xb = smem + buf * BUF + xrow_off + p * 16;
+        const char* gbase = smem + buf * BUF + XT_BYTES + grow_off;
+        uint4 g[BJ];
+#pragma unroll
+        for (int u = 0; u < BJ; ++u) {
+            const int jl = jg * BJ + u;
+            const char* gb = gbase + ((((4 * (jl >> 1)) ^ (qp << 2)) + p) * 16) + 8 * (jl & 1);
+            const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)gb);
+            const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + 16 * GROW));
+            const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
+            g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
+        }
+        if (!(a.dbg & 2)) {
+            lds_pipeline<AI, 3>(
+                [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
+                    const int i = ig * AI + t;
+                    const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
+                    const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+                    const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 16 * 512));
+                    const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
+                    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+                },
+                [&](int t, const uint4& av) {
+#pragma unroll
+                    for (int u = 0; u < BJ; ++u) acc[t][u] = mfma16(av, g[u], acc[t][u]);
+                });
+        }
+        if (do_bias) {      // column sums of G through the matrix pipe: every row of ones x G is sum_r G[r][j] (wave-uniform branch)
+#pragma unroll
+            for (int u = 0; u < BJ; ++u) accb[u] = mfma16(ones, g[u], accb[u]);
+        }
+        __syncthreads();
+    }
+    if (a.dbg & 16) return;
+    // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
+    float* slab = a.slabW + (size_t)bz * a.IT * 16 * a.JT * 16;
+#pragma unroll
+    for (int u = 0; u < BJ; ++u) {
+        const int jt = bx * STRIP + jg * BJ + u;
+        if (jt < a.JT) {
+#pragma unroll
+            for (int t = 0; t < AI; ++t) {
+                const int it = ig * AI + t;
+                if (it < a.IT) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+                        slab[(size_t)(it * 16 + 4 * q + ii) * (a.JT * 16) + jt * 16 + l16] = acc[t][u][ii];
+                }
+            }
+            if (ig == 0 && q == 0) a.slabB[(size_t)bz * a.JT * 16 + jt * 16 + l16] = accb[u][0];
+        }
+    }
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
@@ -2908,10 +3107,10 @@ int wgradp_strip(int shape) { return shape == 8 ? 8 : 16; }
 void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st) {
     dim3 grid((a.JT + wgradp_strip(shape) - 1) / wgradp_strip(shape), (a.IT + 15) / 16, nsplit);
     const size_t sc = a.rowscale ? 1024 : 0;
-    if (shape == 7) {
-        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
-        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<8, 2, 7, 4, true>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, 2, 7, 4, false>), grid, dim3(512), lds, st, a);
+    if (shape == 7) {        // specialised waves: 8 compute + 4 loader (needs IT <= 14, one i-block)
+        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512);
+        if (a.rowscale) hipLaunchKernelGGL((wgradws_kernel<true>), grid, dim3(768), lds, st, a);
+        else hipLaunchKernelGGL((wgradws_kernel<false>), grid, dim3(768), lds, st, a);
     } else if (shape == 16) {
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
         if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);

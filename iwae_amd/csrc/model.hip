@@ -155,6 +155,7 @@ struct iwae_model {
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
+    int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
@@ -477,6 +478,7 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     if (oldW != L.slabW.p || oldB != L.slabB.p || nsplit != L.nsplit) { L.nsplit = nsplit; m->descs_dirty = true; }
     a.X = XP; a.ldX = L.Kp32; a.IT = L.IT; a.G = GP; a.ldG = L.Np32; a.JT = L.JT; a.M = rows; a.rows_per_split = cps * 64;
     a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero; a.rowscale = nullptr;
+    a.dbg = m->wg_debug;
     return IWAE_OK;
 }
 
@@ -1128,6 +1130,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
+    if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
