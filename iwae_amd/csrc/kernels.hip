@@ -1077,14 +1077,12 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             if ((h & 1) && q_real(h >> 1)) q_stage(h >> 1, domf && q_real((h >> 1) + 1));
             continue;
         }
+        // (the tail always multiplies from accA into accB and copies back: the main loop's role swap would cost two more
+        // instantiations of the stage here, and their register pressure -- 13 spilled registers in round 1 -- for <= 3 halves)
         uint4 sp = make_uint4(0, 0, 0, 0);
-        if (domf) {
-            if (h & 1) stage(std::true_type{}, std::true_type{}, accB, accA, h, bufN, tbN, xbq, sp);
-            else stage(std::true_type{}, std::true_type{}, accA, accB, h, bufN, tbN, xbq, sp);
-        } else {
-            if (h & 1) stage(std::true_type{}, std::false_type{}, accB, accA, h, bufN, tbN, xbq, sp);
-            else stage(std::true_type{}, std::false_type{}, accA, accB, h, bufN, tbN, xbq, sp);
-        }
+        if (domf) stage(std::true_type{}, std::true_type{}, accA, accB, h, bufN, tbN, xbq, sp);
+        else stage(std::true_type{}, std::false_type{}, accA, accB, h, bufN, tbN, xbq, sp);
+        accA[0] = accB[0]; accA[1] = accB[1];
         if (h & 1) st[1] = sp; else st[0] = sp;
     }
     if (fullw) {

@@ -118,7 +118,7 @@ struct iwae_model {
     // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
     DevBuf ds_data, ds_order;
     int ds_N = 0;
-    int wg_target16_1 = 128;   // same, for layers that are a single 16-wave block wide (IWAE_WG16_1)
+    int wg_target16_1 = 64;    // same, for layers that are a single block wide (IWAE_WG16_1): the hidden layers' gradients -- with the specialised-wave kernel 64 row splits (12.8 MB of slabs each) beat 128 (0.259 -> 0.249-0.254 ms/step); 48 and 32 are slower again
     int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
     int wg_target8 = 256;      // same for the 8-wave launches (small row counts: the encoder's layers) (IWAE_WG8)
     int wg_target16 = 128;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
