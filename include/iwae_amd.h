@@ -159,6 +159,21 @@ int iwae_set_adam(iwae_handle h, float beta_1, float beta_2, float epsilon);
 int iwae_set_condition(iwae_handle h, const float* y, int32_t n);
 int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /* Philox counter words */
 
+/* Data-parallel training INSIDE the library (BASELINE configs[4]; no reference counterpart, main.py:32 is single-device): one
+ * process per GPU, every rank holds a handle created with the same seed / parameters and iwae_config.world_size / rank.
+ * Rank 0 obtains an opaque id blob (iwae_comm_unique_id: RCCL ncclGetUniqueId, one per internal communicator), the caller
+ * ships it to the other ranks by any means (MPI, a file, torch.distributed's store), and EVERY rank calls iwae_comm_init
+ * with it (collective: ncclCommInitRank).  From then on iwae_train_step / iwae_train_step_dataset take the rank's shard
+ * of the global batch (B = global batch / world_size images; noise keyed by the global image index: batch_offset of
+ * iwae_set_step + rank * B) and all-reduce the flat fp32 gradient with ncclAllReduce on the library's own streams before Adam
+ * (grad_scale 1/world_size, identical on every rank: replicas stay bit-identical): the decoder's segment (done early, on the
+ * side stream) is exchanged and applied there, beside the encoder's backward pass and the next encoder forward, exactly as
+ * the single-GPU step defers it; the encoder's segment follows on the main stream.  RCCL is loaded at run time (dlopen):
+ * the library itself does not link against it.  iwae_comm_destroy (or iwae_destroy) releases the communicators. */
+int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes);
+int iwae_comm_init(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
+int iwae_comm_destroy(iwae_handle h);
+
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
  * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
 int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);

@@ -198,7 +198,7 @@ void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, 
                          float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
-                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st);
+                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block = 0);   // blocks [first_block, first_block + nblocks) of the elementwise grid
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st);
 void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st);
 void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st);

@@ -2881,11 +2881,12 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* laye
 
 // Keras Adam (main.py:93): theta -= lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps), eps = 1e-4;
 // then refresh the bf16 A-images the GEMM kernels stream (forward W^T and backward W).
-__global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, const float* grad, float* mom, float* vel, AdamCoef c) {
+__global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, const float* grad, float* mom, float* vel, AdamCoef c, int first_block) {
+    const int bid = (int)blockIdx.x + first_block;       // the grid covers blocks [first_block, first_block + gridDim.x) of the layer table
     int l = 0;
-    while (l + 1 < nlayers && (int)blockIdx.x >= layers[l + 1].block_begin) ++l;
+    while (l + 1 < nlayers && bid >= layers[l + 1].block_begin) ++l;
     const LayerDesc L = layers[l];
-    const int e = ((int)blockIdx.x - L.block_begin) * blockDim.x + threadIdx.x;
+    const int e = (bid - L.block_begin) * blockDim.x + threadIdx.x;
     const int nW = L.Kin * L.Nout;
     if (e >= nW + L.Nout) return;
     const bool is_b = e >= nW;
@@ -3154,9 +3155,9 @@ void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);
 }
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
-                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st) {
+                 float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block) {
     const AdamCoef c = {alpha, gscale, beta1, beta2, eps, do_update};
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, c);
+    LAUNCH_EV(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, c, first_block);
 }
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st) {
     hipLaunchKernelGGL(export_rows_kernel, grid1((size_t)B * k, 256), dim3(256), 0, st, in, B, k, out);

@@ -11,6 +11,8 @@
 #include <vector>
 #include <random>
 #include <memory>
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types only: RCCL is loaded with dlopen at iwae_comm_init, the library does not link against it
 #include "../../include/iwae_amd.h"
 #include "kernels.h"
 #include "layout.h"
@@ -69,6 +71,40 @@ struct MlpWs {     // decode_z_to_x applied to M rows
 
 }  // namespace
 
+// RCCL entry points, resolved at run time (the process may already hold torch's copy of librccl: that one is reused)
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int load_rccl() {
+    if (g_rccl.lib) return IWAE_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;       // already in the process (e.g. torch's)
+    if (!lib) for (const char* n : names) if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
+    if (!lib) return fail(IWAE_ERR_STATE, std::string("RCCL not found (dlopen librccl.so): ") + (dlerror() ? dlerror() : ""));
+    RcclApi r;
+    r.lib = lib;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) return fail(IWAE_ERR_STATE, "librccl.so lacks an expected symbol");
+    g_rccl = r;
+    return IWAE_OK;
+}
+#define NCCLCHK(expr)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                                  \
+        if (r_ != ncclSuccess) return fail(IWAE_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));    \
+    } while (0)
+
 // kernels iwae_enable_timing brackets with HIP events (on the stream each is launched on); names: iwae_kernel_time
 enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_DEC_BWD, T_COUNT };
 static const char* const kTimedNames[T_COUNT] = {"out_bwd", "decoder_fwd", "wgrad_out", "dx_hidden", "dx_latent", "wgrad_hidden", "wgrad_latent",
@@ -92,6 +128,9 @@ struct iwae_model {
     DevBuf condP;              // y as bf16 P-layout [Bp][32*ceil(C/32)] (the prior block's input)
     float *param = nullptr, *grad = nullptr, *mom = nullptr, *vel = nullptr;
     int64_t adam_t = 0;
+    // data-parallel training inside the library (iwae_comm_init): one communicator per stream that carries a collective
+    ncclComm_t comm_main = nullptr, comm_side = nullptr;
+    int comm_world = 1, comm_rank = 0;
     float adam_b1 = 0.9f, adam_b2 = 0.999f, adam_eps = 1e-4f;   // keras Adam(lr, epsilon=1e-4) of main.py:93 unless iwae_set_adam says otherwise
     uint32_t noise_step = 0, batch_offset = 0;
     // layer descriptor table
@@ -1083,6 +1122,32 @@ int adam_impl(iwae_model* m, float lr, float gscale) {
     return IWAE_OK;
 }
 
+// Data-parallel step, second half (the gradient of this rank's shard is in m->grad; backward_impl(split) left the decoder's
+// segment on the side stream, unjoined): all-reduce + Adam(grad_scale 1/N) of the decoder's layers on the SIDE stream -- they run
+// beside the encoder's backward pass and the next encoder forward, as the single-GPU step's deferred update does -- and of the
+// encoder's layers on the main stream.  Models without such a segment: one all-reduce + Adam on the main stream.
+int dp_finish(iwae_model* m, float lr) {
+    const float alpha = adam_alpha(m, lr);
+    const float gs = 1.0f / (float)m->comm_world;
+    if (m->descs_dirty) CHK(build_descs(m));
+    const size_t n = m->nparam, off = m->split_offset;
+    if (off < n && m->dec_pending) {
+        const int b0 = m->descs[m->dec1[0].sub[0]].block_begin;
+        NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->side));
+        set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
+        launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
+                    m->side, b0);
+        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
+        launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
+    } else {
+        CHK(join_side(m));
+        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, n, ncclFloat32, ncclSum, m->comm_main, m->stream));
+        launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
+    }
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
 }  // namespace
 
 // =================================================================== C ABI
@@ -1218,6 +1283,8 @@ void iwae_destroy(iwae_handle m) {
     (void)hipSetDevice(m->cfg.device);
     if (m->side) (void)hipStreamSynchronize(m->side);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm_main && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm_main);
+    if (m->comm_side && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm_side);
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
@@ -1412,7 +1479,11 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(check_objective(m, objective));
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
-    if (want) {
+    if (m->comm_main) {                         // data-parallel step: exchange between gradient and update (iwae_comm_init)
+        CHK(backward_impl(m, objective, -1.0f, true));
+        if (want) CHK(fetch_outputs(m, nullptr, want));
+        CHK(dp_finish(m, lr));
+    } else if (want) {
         CHK(backward_impl(m, objective));
         CHK(fetch_outputs(m, nullptr, want));   // tensors refer to the pre-update forward (src/iwae1.py:162)
         CHK(adam_impl(m, lr, 1.0f));
@@ -1421,6 +1492,46 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     }
     CHK(fetch_outputs(m, scalars, nullptr));
     m->noise_step += 1;
+    return IWAE_OK;
+}
+
+int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes) {
+    if (!id_out || !id_bytes || cap < 2 * sizeof(ncclUniqueId)) return fail(IWAE_ERR_ARG, "comm_unique_id: need a buffer of >= 256 bytes");
+    CHK(load_rccl());
+    ncclUniqueId ids[2];
+    NCCLCHK(g_rccl.GetUniqueId(&ids[0]));
+    NCCLCHK(g_rccl.GetUniqueId(&ids[1]));
+    memcpy(id_out, ids, sizeof(ids));
+    *id_bytes = sizeof(ids);
+    return IWAE_OK;
+}
+
+int iwae_comm_init(iwae_handle m, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank) {
+    if (!m || !unique_id || id_bytes != 2 * sizeof(ncclUniqueId)) return fail(IWAE_ERR_ARG, "comm_init: bad id blob (iwae_comm_unique_id makes it)");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(IWAE_ERR_ARG, "comm_init: need 0 <= rank < world_size");
+    if (world_size != m->cfg.world_size || rank != m->cfg.rank)
+        return fail(IWAE_ERR_ARG, "comm_init: world_size / rank differ from the iwae_config this handle was created with");
+    if (m->comm_main) return fail(IWAE_ERR_STATE, "comm_init: communicators already exist (iwae_comm_destroy first)");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(load_rccl());
+    CHK(join_side(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    ncclUniqueId ids[2];
+    memcpy(ids, unique_id, sizeof(ids));
+    NCCLCHK(g_rccl.CommInitRank(&m->comm_main, world_size, ids[0], rank));
+    NCCLCHK(g_rccl.CommInitRank(&m->comm_side, world_size, ids[1], rank));
+    m->comm_world = world_size; m->comm_rank = rank;
+    return IWAE_OK;
+}
+
+int iwae_comm_destroy(iwae_handle m) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    CHK(join_side(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+    if (m->comm_main) { NCCLCHK(g_rccl.CommDestroy(m->comm_main)); m->comm_main = nullptr; }
+    if (m->comm_side) { NCCLCHK(g_rccl.CommDestroy(m->comm_side)); m->comm_side = nullptr; }
+    m->comm_world = 1; m->comm_rank = 0;
     return IWAE_OK;
 }
 

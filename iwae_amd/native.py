@@ -109,6 +109,26 @@ class NativeModel:
         y = _f32(y).reshape(-1, self.cond_dim)
         check(self.lib.iwae_set_condition(self.h, y.ctypes.data, y.shape[0]))
 
+    # ---- data-parallel training inside the library (RCCL) -------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the opaque id blob every rank passes to comm_init (ship it with any channel)."""
+        lib = _capi.load()
+        buf = C.create_string_buffer(1024)
+        n = C.c_size_t()
+        check(lib.iwae_comm_unique_id(buf, 1024, C.byref(n)))
+        return buf.raw[:n.value]
+
+    def comm_init(self, unique_id, world_size, rank):
+        """Collective over all ranks: from now on train_step all-reduces the gradient inside the library."""
+        blob = bytes(unique_id)
+        check(self.lib.iwae_comm_init(self.h, blob, len(blob), int(world_size), int(rank)))
+        self.comm = True
+
+    def comm_destroy(self):
+        check(self.lib.iwae_comm_destroy(self.h))
+        self.comm = False
+
     def set_step(self, noise_step, batch_offset=0):
         check(self.lib.iwae_set_step(self.h, int(noise_step), int(batch_offset)))
 

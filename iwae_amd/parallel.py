@@ -1,11 +1,16 @@
-"""Data-parallel training step: one process per GPU (torch.distributed, backend "nccl" = RCCL
-over xGMI).  The reference has no counterpart (single device, main.py:32); the path shards
-naturally because the loss is a mean over images (src/iwae1.py:120-134):
+"""Data-parallel training step: one process per GPU, gradients exchanged with RCCL over xGMI.  The reference has no
+counterpart (single device, main.py:32); the path shards naturally because the loss is a mean over images
+(src/iwae1.py:120-134):
 
   rank r takes images [r*B/N, (r+1)*B/N) -> forward + backward on its shard (mean over ITS images)
   all-reduce(SUM) of the flat fp32 gradient buffer (455,384 floats, in place on the device) in two messages: the
   decoder's layers (done early, on the library's side stream) beside the encoder's backward pass, then the encoder's
   Adam with grad_scale = 1/N on every rank (replicas stay bit-identical)
+
+Default: the collective is issued BY THE LIBRARY (iwae_comm_init: ncclAllReduce on its own streams, the decoder segment's
+exchange + update deferred beside the next encoder forward like the single-GPU step's); torch.distributed only ships the
+128-byte RCCL ids to the ranks.  IWAE_DP_TORCH=1 (or a failing RCCL initialisation) selects the round-1 path instead:
+iwae_forward_backward -> torch.distributed.all_reduce of iwae_grad_devptr() -> iwae_adam_step.
 
 Noise is keyed by the GLOBAL image index (batch_offset), so N ranks draw the same eps as 1 rank.
 The helpers take plain torch tensors so the host logic is testable on CPU with gloo."""
@@ -60,26 +65,48 @@ def exchange_split_(flat, side_offset, side_stream, group=None):
     return flat
 
 
+def share_comm_id(make_id, rank, group=None):
+    """Rank 0 makes the RCCL id blob (NativeModel.comm_unique_id), every rank receives it: the only thing torch.distributed
+    carries for the in-library exchange.  Works on any backend (gloo on CPU in the host-logic tests)."""
+    box = [make_id() if rank == 0 else None]
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
 class DataParallelStep:
-    def __init__(self, net, rank, world_size, group=None, overlap=None):
+    def __init__(self, net, rank, world_size, group=None, overlap=None, in_library=None):
         self.net, self.rank, self.world, self.group = net, int(rank), int(world_size), group
+        self.step_idx = 0
+        self._side = None
+        self.overlap = False
+        forced = bool(os.environ.get("IWAE_BENCH_FORCE_DIST"))
+        want_lib = (os.environ.get("IWAE_DP_TORCH") is None) if in_library is None else bool(in_library)
+        self.in_library = False
+        if (self.world > 1 or forced) and want_lib:
+            try:
+                blob = share_comm_id(type(net).comm_unique_id, self.rank, group)
+                net.comm_init(blob, self.world, self.rank)
+                self.in_library = True
+                return
+            except Exception as e:      # an RCCL that cannot be loaded / initialised: the torch.distributed path still works
+                print("iwae_amd.parallel: in-library RCCL exchange unavailable (%s); using torch.distributed.all_reduce" % e, flush=True)
         ptr, n = net.grad_devptr()
         self.grad = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         # run the library on torch's current stream so the collective is ordered after the backward
         net.set_stream(torch.cuda.current_stream().cuda_stream)
-        self.step_idx = 0
         # overlap (opt-in, IWAE_DP_OVERLAP=1): the decoder's 54 % of the gradient bytes are exchanged beside the encoder's
         # backward pass.  Off by default: with one rank (trivial collectives) the two messages and their three cross-stream
         # waits cost +22 us per step (0.338 -> 0.360 ms), the one-message path's exposed all-reduce could not be measured
         # on the one-GPU development box, so the default stays the path with the fewest stream hand-offs.
         self.overlap = (os.environ.get("IWAE_DP_OVERLAP") is not None) if overlap is None else bool(overlap)
-        self._side = None
 
     def step(self, x_devptr, b_local, k, beta, lr, objective_id, global_batch_offset=0):
         """x_devptr: this rank's shard, already resident in HBM ([b_local, x_dim] float32)."""
         self.net.set_step(self.step_idx, global_batch_offset + self.rank * b_local)
-        if self.world == 1 and not os.environ.get("IWAE_BENCH_FORCE_DIST"):
-            # nothing to exchange: the library's own train step (Adam fused into the gradient reduction)
+        if self.in_library or (self.world == 1 and not os.environ.get("IWAE_BENCH_FORCE_DIST")):
+            # the library's own train step: single GPU (Adam fused into the gradient reduction) or, after comm_init, with its
+            # ncclAllReduce between gradient and update
             self.net.train_step_devptr(x_devptr, b_local, k, beta, lr, objective_id)
         elif self.overlap:
             side, off = self.net.forward_backward_split_devptr(x_devptr, b_local, k, beta, objective_id)

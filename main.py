@@ -7,6 +7,16 @@ Differences that are forced by the environment, not by design: MNIST is read fro
 mnist.npz (IWAE_MNIST_PATH, ~/.keras/datasets/mnist.npz) because the Keras download is not
 available offline, with a synthetic grey-level stand-in otherwise; scalars go to a CSV under
 /tmp/iwae/<run>/ instead of TensorBoard; --gpu selects the HIP device ordinal.
+
+Data-parallel (BASELINE configs[4]; the reference is single-device, main.py:32): launch one process per GPU with torchrun,
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+           main.py --n_samples 50 --batch_size 8192
+
+--batch_size is then the GLOBAL batch: rank r trains on images [r*B/N, (r+1)*B/N) of every batch (same shuffle on every
+rank, noise keyed by the global image index), the library all-reduces the gradient with RCCL (iwae_comm_init) and every
+rank applies the same Adam step.  A gloo group (CPU) only ships the RCCL ids and sums the test-set estimate; it is created
+before anything touches the GPU.
 """
 import argparse
 import csv
@@ -30,11 +40,24 @@ parser.add_argument("--objective", type=str, default="iwae_elbo", choices=["vae_
 parser.add_argument("--gpu", type=str, default='0', help="Choose GPU")
 
 
+def _init_data_parallel():
+    """(rank, world, dist or None) from torchrun's environment; world 1 without it."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=world)      # CPU only: ships ids, sums scalars
+    return int(os.environ["RANK"]), world, dist
+
+
 def main(argv=None):
     args = parser.parse_args(argv)
-    print(args)
+    rank, world, dist = _init_data_parallel()
+    if rank == 0:
+        print(args)
     string = "main_{0}_{1}_{2}".format(args.objective, args.stochastic_layers, args.n_samples)
-    device = int(str(args.gpu).split(",")[0])
+    device = int(os.environ["LOCAL_RANK"]) if world > 1 else int(str(args.gpu).split(",")[0])
 
     # ---- set random seeds (main.py:40-41)
     np.random.seed(123)
@@ -65,26 +88,33 @@ def main(argv=None):
     objective = args.objective
     n_samples = args.n_samples
     batch_size = args.batch_size
+    if batch_size % world:
+        raise SystemExit("--batch_size {0} (the global batch) must be divisible by the {1} ranks".format(batch_size, world))
     steps_pr_epoch = Ntrain // batch_size
     total_steps = steps_pr_epoch * epochs
 
     current_time = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
     log_dir = "/tmp/iwae/{0}/".format(string) + current_time
     os.makedirs(log_dir, exist_ok=True)
-    log_f = open(os.path.join(log_dir, "scalars.csv"), "w", newline="")
+    log_f = open(os.path.join(log_dir, "scalars.csv") if rank == 0 else os.devnull, "w", newline="")
     log_w = None
 
     # ---- instantiate the model, optimizer and metrics (main.py:84-94)
     bias = utils.get_bias(Xtrain)
     if args.stochastic_layers == 1:
-        model = iwae1.IWAE(200, 100, device=device, output_bias=bias)
+        model = iwae1.IWAE(200, 100, device=device, output_bias=bias, world_size=world, rank=rank)
     else:
         if objective == "vae_elbo_kl":
             raise KeyError(objective)      # src/iwae2.py:154-173 has no such key
-        model = iwae2.IWAE([200, 100], [100, 50], device=device, output_bias=bias)
+        model = iwae2.IWAE([200, 100], [100, 50], device=device, output_bias=bias, world_size=world, rank=rank)
+
+    if world > 1:      # the gradient exchange happens inside the library from here on (RCCL over xGMI)
+        from iwae_amd.parallel import share_comm_id
+        model._net.comm_init(share_comm_id(type(model._net).comm_unique_id, rank), world, rank)
 
     optimizer = Adam(learning_rate_dict[0], epsilon=1e-4)
-    print("Initial learning rate: ", optimizer.learning_rate.numpy())
+    if rank == 0:
+        print("Initial learning rate: ", optimizer.learning_rate.numpy())
 
     # ---- binarize the test data once (main.py:108)
     Xtest = utils.bernoullisample(Xtest)
@@ -101,15 +131,24 @@ def main(argv=None):
         if args.epochs == -1 and epoch in learning_rate_dict:
             new_learning_rate = learning_rate_dict[epoch]
             old_learning_rate = optimizer.learning_rate.numpy()
-            print("Changing learning rate from {0} to {1}".format(old_learning_rate, new_learning_rate))
+            if rank == 0:
+                print("Changing learning rate from {0} to {1}".format(old_learning_rate, new_learning_rate))
             optimizer.learning_rate.assign(new_learning_rate)
 
         for _step, lo in enumerate(range(0, Ntrain, batch_size)):
             step = _step + steps_pr_epoch * epoch
             beta = 1.0
-            res = model.train_step_dataset(lo, min(batch_size, Ntrain - lo), n_samples, beta, optimizer, objective=objective)
+            nb = min(batch_size, Ntrain - lo)
+            if world > 1:
+                nb = (nb // world)                       # this rank's shard of the global batch (a ragged last batch drops < world images)
+                model._net.set_step(step, rank * nb)     # noise keyed by the global image index: N ranks draw what one rank would
+                if nb == 0:
+                    continue
+                res = model.train_step_dataset(lo + rank * nb, nb, n_samples, beta, optimizer, objective=objective)
+            else:
+                res = model.train_step_dataset(lo, nb, n_samples, beta, optimizer, objective=objective)
 
-            if step % 200 == 0:
+            if step % 200 == 0 and rank == 0:
                 test_res = model.val_step(Xtest, n_samples, beta)
                 row = {"split": "train", **model.write_to_tensorboard(res, step)}
                 row_t = {"split": "test", **model.write_to_tensorboard(test_res, step)}
@@ -125,12 +164,23 @@ def main(argv=None):
                       .format(epoch, epochs, step, total_steps, res[objective].numpy(), test_res[objective], took))
 
     # ---- save final weights (main.py:165)
-    model.save_weights('/tmp/iwae/{0}/final_weights'.format(string))
+    if rank == 0:
+        model.save_weights('/tmp/iwae/{0}/final_weights'.format(string))
 
-    # ---- test-set llh estimate using 5000 samples (main.py:170-184)
+    # ---- test-set llh estimate using 5000 samples (main.py:170-184); data-parallel: every rank takes a slice of the test set
     L = 5000
-    test_set_llh = model.eval_llh(Xtest, L)
-    print("Test-set {0} sample log likelihood estimate: {1:.4f}".format(L, test_set_llh))
+    if world > 1:
+        import torch
+        mine = Xtest[rank::world]
+        model._net.set_step(1 << 20, 0)
+        part = torch.tensor([model.eval_llh(mine, L) * mine.shape[0], float(mine.shape[0])], dtype=torch.float64)
+        dist.all_reduce(part)
+        test_set_llh = float(part[0] / part[1])
+        dist.destroy_process_group()
+    else:
+        test_set_llh = model.eval_llh(Xtest, L)
+    if rank == 0:
+        print("Test-set {0} sample log likelihood estimate: {1:.4f}".format(L, test_set_llh))
     return test_set_llh
 
 

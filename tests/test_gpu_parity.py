@@ -248,6 +248,47 @@ def test_kernel_variants_agree(gpu, monkeypatch):
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
 
 
+@pytest.mark.parametrize("B,k,layers", [(170, 50, 1), (20, 5, 1), (24, 6, 2)])
+def test_in_library_data_parallel_step_world1_is_bitwise_the_single_gpu_step(gpu, B, k, layers):
+    """iwae_comm_init + iwae_train_step (the data-parallel step inside the library: ncclAllReduce on the library's streams between
+    gradient and Adam, the decoder segment's exchange + update deferred on the side stream) rehearsed with ONE rank -- all this
+    box has -- against the single-GPU step: 12 steps on device noise must land on bit-identical parameters and Adam state
+    (grad_scale 1/1, a one-rank all-reduce is the identity), with parameter reads in between seeing completed updates."""
+    from iwae_amd.native import NativeModel
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x = O.synthetic_binarized(B, 13)
+    P = O.init_params(layers, nh, nl, 21, x_mean=O.synthetic_pixel_means())
+    outs = []
+    for dp in (False, True):
+        m = _model(layers, nh, nl)
+        m.set_params(O.flatten_params(P))
+        if dp:
+            m.comm_init(NativeModel.comm_unique_id(), 1, 0)
+            with pytest.raises(RuntimeError):
+                m.comm_init(NativeModel.comm_unique_id(), 1, 0)          # already initialised: call order error, not a second communicator
+        for t in range(12):
+            m.set_step(t, 0)
+            r = m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=(t % 4 == 0))
+            if t == 5:
+                m.get_params()
+        outs.append((m.get_params().copy(), m.get_adam_state(), m.get_grads().copy()))
+        if dp:
+            m.comm_destroy()
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo")                    # back on the single-GPU step
+        m.close()
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1][0], outs[1][1][0])
+    np.testing.assert_array_equal(outs[0][1][1], outs[1][1][1])
+    assert outs[0][1][2] == outs[1][1][2] == 12
+    with pytest.raises(ValueError):
+        m2 = _model(1, 200, 100)
+        try:
+            m2.comm_init(NativeModel.comm_unique_id(), 2, 1)              # does not match the handle's iwae_config (world_size 1)
+        finally:
+            m2.close()
+
+
 @pytest.mark.parametrize("B,k", [(170, 50), (20, 5)])
 def test_split_backward_equals_joined_backward(gpu, B, k):
     """iwae_forward_backward_split (the data-parallel step's entry: decoder gradient completed on the side stream, unjoined,

@@ -141,6 +141,9 @@ def _dp_worker(rank, world, port, q):
     lst = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(lst, t)
     assert all(torch.equal(lst[0], o) for o in lst)
+    # the RCCL id blob of the in-library exchange (iwae_comm_init) travels the same way: rank 0 makes it, every rank gets it
+    blob = parallel.share_comm_id(lambda: bytes(range(256)), rank)
+    assert blob == bytes(range(256)), (rank, blob[:8])
     dist.destroy_process_group()
 
 
