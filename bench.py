@@ -160,7 +160,33 @@ def load_profile_traffic(kernel_match, config):
     return None, None, None
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is made; the contract is ONE JSON line there.
+    Everything before the result line runs with file descriptor 1 pointing at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
+    with _StdoutToStderr():
+        out, dist = run()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -285,9 +311,8 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
-    if dist:
-        dist.destroy_process_group()
+        return out, dist
+    return None, dist
 
 
 if __name__ == "__main__":

@@ -66,7 +66,7 @@ typedef struct {
                                   (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
     int32_t cond_prior;        /* with cond_dim > 0: 1 = the learned conditional prior p(z|y) of tasks/task04.py:101-173 (a BasicBlock on y,
                                   created after the decoder) replaces N(0,1) in lpz; sample(z, y) maps z through it (:190-196) */
-    int32_t precision;         /* iwae_precision of train / forward calls (iwae_eval_llh always evaluates in float32) */
+    int32_t precision;         /* iwae_precision of forward / train calls (iwae_eval_llh: iwae_set_eval_precision); IWAE_PREC_FP32 needs cond_dim = 0 */
     int32_t reserved;          /* 0 */
 } iwae_config;
 
@@ -177,6 +177,10 @@ int iwae_comm_destroy(iwae_handle h);
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
  * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
 int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);
+/* arithmetic of iwae_eval_llh, independent of iwae_config.precision: IWAE_PREC_FP32 by default (the reference evaluates in
+ * float32, main.py:176; 10 000 images x k = 5000 take well under a second either way), IWAE_PREC_BF16 for the fast path.
+ * The conditional models (cond_dim > 0) always evaluate on the bf16 path. */
+int iwae_set_eval_precision(iwae_handle h, int32_t precision);
 
 /* IWAE.sample(z): decoder only -> probs [n, x_dim].  1-layer: src/iwae1.py:168-178, z [n,D1].  2-layer:
  * src/iwae2.py:184-196, z = z2 [n,D2]: z1 ~ p(z1|z2) is drawn on the device (Philox), then decoded. */

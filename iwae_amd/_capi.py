@@ -60,6 +60,7 @@ SYMBOLS = {
     "iwae_grad_devptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "iwae_adam_step": (C.c_int, [_P, C.c_float, C.c_float]),
     "iwae_set_adam": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
+    "iwae_set_eval_precision": (C.c_int, [_P, C.c_int32]),
     "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "iwae_comm_unique_id": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "iwae_comm_init": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, C.c_int32]),

@@ -9,5 +9,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fn
 if [ -n "${STAMPS:-}" ]; then FLAGS="$FLAGS -DIWAE_DENSE_STAMPS"; fi
 $HIPCC $FLAGS -c kernels.hip -o kernels.o
 $HIPCC $FLAGS -c model.hip -o model.o
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libiwae_amd.so kernels.o model.o -ldl
+$HIPCC $FLAGS -c fp32_kernels.hip -o fp32_kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libiwae_amd.so kernels.o model.o fp32_kernels.o -ldl
 echo "built $(cd .. && pwd)/libiwae_amd.so"

@@ -1,0 +1,168 @@
+// float32 mode (iwae_config.precision = IWAE_PREC_FP32): the reference's arithmetic -- Keras Dense layers in float32
+// (src/iwae1.py:31-34,72-75) -- with every GEMM on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-for-bit a k-ordered
+// fmaf chain, no reduced-precision operands).  Row-major float32 activations in their natural widths, weights read straight
+// from the fp32 master parameters in Keras [in, out] order.  This mode exists for parity (scalars rel 1e-5,
+// gradients rel 1e-4 against the float64 oracle) and for the k = 5000 evaluator; the bf16 kernels in kernels.hip are the fast path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace iwae {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+
+// C[M,N] (=|+=) epi(op(A)[M,K] op(B)[K,N] + bias): 64 x 64 tile per 256-thread workgroup, K walked in steps of 16 through
+// LDS; wave (wm, wn) owns a 32 x 32 sub-tile = 2 x 2 MFMA tiles.  Element (m,k) of A is A[m*sam + k*sak], (k,n) of B is
+// B[k*sbk + n*sbn]: plain, transposed-A (weight gradient X^T G) and transposed-B (dX = G W^T) products are the same kernel;
+// the tile loads walk the unit-stride index fastest so they stay coalesced either way.
+// blockIdx.z = K split: split z covers k in [z*kchunk, (z+1)*kchunk) and writes C + z*slab_stride (fp32 slabs, summed in a
+// fixed order by reduce_slabs_f32_kernel: deterministic, no float atomics).
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
+    __shared__ float sA[64][17];
+    __shared__ float sB[16][80];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int ka = a_kfast ? (idx & 15) : (idx >> 6), ma = a_kfast ? (idx >> 4) : (idx & 63);
+            const int gm = m0 + ma, gk = k0 + ka;
+            sA[ma][ka] = (gm < a.M && gk < k_end) ? a.A[(size_t)gm * a.sam + (size_t)gk * a.sak] : 0.0f;
+            const int nb = b_nfast ? (idx & 63) : (idx >> 4), kb = b_nfast ? (idx >> 6) : (idx & 15);
+            const int gn = n0 + nb, gk2 = k0 + kb;
+            sB[kb][nb] = (gn < a.N && gk2 < k_end) ? a.B[(size_t)gk2 * a.sbk + (size_t)gn * a.sbn] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = sA[32 * wm + 16 * i + r16][4 * kk + q];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = sB[4 * kk + q][32 * wn + 16 * j + r16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * wn + 16 * j + r16;
+            if (n >= a.N) continue;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wm + 16 * i + 4 * q + r;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (a.epi == GEMM_EPI_TANH) v = tanhf(v);                       // iwae1.py:31-32,72-73
+                else if (a.epi == GEMM_EPI_EXP) v = expf(v) + 1e-6f;             // iwae1.py:34,42
+                else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n]; v *= 1.0f - y * y; }
+                float* dst = C + (size_t)m * a.ldc + n;
+                *dst = a.accumulate ? *dst + v : v;
+            }
+        }
+}
+
+// out[i] = sum over z of slabs[z*stride + i] (fixed order), i < n
+__global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slabs, size_t stride, int nsplit, size_t n, float* out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
+    out[i] = s;
+}
+
+// partial column sums of G [M][ld] over row split blockIdx.y: part[y][n] (bias gradients), summed by reduce_slabs_f32_kernel
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* G, size_t ld, int M, int N, int rows_per_split, float* part) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
+    float s = 0.0f;
+    if (n < N)
+        for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// log p(x|z) per data row from float32 logits: sum_j x_j l_j - softplus(l_j) (iwae1.py:111); one wave per row (image-major rows: b = row / k)
+__global__ __launch_bounds__(256) void bern_f32_kernel(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* l = logits + (size_t)row * ld;
+    const float* xr = x + (size_t)(row / k) * X;
+    float s = 0.0f;
+    for (int j = lane; j < X; j += 64) {
+        const float v = l[j];
+        s += xr[j] * v - (fmaxf(v, 0.0f) + log1pf(expf(-fabsf(v))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) lpxz[row] = s;
+}
+
+// in place: logits -> dl = gx[row] * (x - sigmoid(l))   (d loss / d logits)
+__global__ __launch_bounds__(256) void dl_f32_kernel(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * X) return;
+    const int row = (int)(idx / X), j = (int)(idx - (size_t)row * X);
+    float* p = logits + (size_t)row * ld + j;
+    const float v = *p;
+    *p = gx[row] * (x[(size_t)(row / k) * X + j] - 1.0f / (1.0f + expf(-v)));
+}
+
+// out[row][f] = 1 / (1 + exp(-in)): IWAE.sample's probs (iwae1.py:174)
+__global__ __launch_bounds__(256) void sigmoid_f32_kernel(float* v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = 1.0f / (1.0f + expf(-v[i]));
+}
+
+// [B*k][X] image-major rows -> the reference's [k][B][X] order (src/iwae1.py:148)
+__global__ __launch_bounds__(256) void export_mat_kernel(const float* in, int B, int k, int X, float* out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * k * X) return;
+    const int row = (int)(idx / X), j = (int)(idx - (size_t)row * X);
+    const int b = row / k, s = row - b * k;
+    out[((size_t)s * B + b) * X + j] = in[idx];
+}
+void launch_export_mat(const float* in, int B, int k, int X, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(export_mat_kernel, dim3((unsigned)(((size_t)B * k * X + 255) / 256)), dim3(256), 0, st, in, B, k, X, out);
+}
+
+void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st) {
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
+}
+void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
+}
+void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st) {
+    const int rps = (M + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, st, G, ld, M, N, rps, part);
+}
+void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st) {
+    hipLaunchKernelGGL(bern_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, ld, x, X, M, k, lpxz);
+}
+void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st) {
+    hipLaunchKernelGGL(dl_f32_kernel, dim3((unsigned)(((size_t)M * X + 255) / 256)), dim3(256), 0, st, logits, ld, x, X, M, k, gx);
+}
+void launch_sigmoid_f32(float* v, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(sigmoid_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, n);
+}
+
+}  // namespace iwae

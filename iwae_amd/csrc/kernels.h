@@ -112,7 +112,8 @@ struct SampleArgs {
     const float* head; int ldH; int Dp; int D; int head_per_row;
     int M, Mp, k, B;
     EpsSrc eps;
-    uint16_t* ZP;
+    uint16_t* ZP;                     // z as bf16 P-layout [M][Dp], or null
+    float* ZF; int ldZF;              // z as float32 rows [M][ldZF] (float32 mode), or null
     const float* prior_head;          // conditional prior: per-image head [B][ldH] (mu_p | sigma_p) scoring z, or null = N(0,1)
     const float* cond; int C;         // conditional model: y [B][C] goes into features D..D+C-1 of the z rows (decoder input concat(z, y))
     float* lp_prior; float* lq; float* lq_dreg;
@@ -145,9 +146,11 @@ struct LatentBwdArgs {
     EpsSrc eps;
     int B, Bp, k;
     float kmu, ksig;
-    uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp]
+    uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp] (or null)
+    float* DHF;                       // float32 mode: dhead as float32 [B][2Dp] (d mu at f, d pre-exp at Dp + f), or null
     const float* prior_head;          // conditional prior p(z|y) (tasks/task04.py:124-130): per-image head [B][ldH] like `head`, or null = N(0,1)
     uint16_t* DHP2;                   // its dhead, P-layout [B][2Dp] (written when prior_head != null)
+    float* DHF2;                      // float32 mode: the same as float32 [B][2Dp]
 };
 
 struct GaussBwdArgs {
@@ -158,7 +161,8 @@ struct GaussBwdArgs {
     const float* dz_in; float* dz_direct; int ldDZ;
     EpsSrc eps;
     int M, Mp, k;
-    uint16_t* DHP;
+    uint16_t* DHP;                    // dhead bf16 P-layout [M][2Dp], or null
+    float* DHF;                       // float32 mode: dhead float32 [M][2Dp], or null
 };
 
 struct LayerDesc {
@@ -204,5 +208,26 @@ void launch_export_z(const SampleArgs& a, float* zout, hipStream_t st);
 void launch_snis(const float* z, const float* wn, int B, int k, int D, float* out, hipStream_t st);
 void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hipStream_t st);
 void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st);
+
+// ---- float32 mode (fp32_kernels.hip)
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_TANH = 1, GEMM_EPI_EXP = 2, GEMM_EPI_DTANH = 3 };
+struct GemmF32Args {
+    const float* A; long sam, sak;        // element (m,k) of op(A) at A[m*sam + k*sak]
+    const float* B; long sbk, sbn;        // element (k,n) of op(B) at B[k*sbk + n*sbn]
+    float* C; long ldc;                   // C[m*ldc + n]
+    int M, N, K;
+    const float* bias;                    // [N] or null
+    int epi;                              // GEMM_EPI_*: none | tanh | exp(.)+1e-6 | times (1 - ACT^2)
+    const float* ACT; long ldact;         // GEMM_EPI_DTANH: stored tanh activation of the outputs
+    int accumulate;                       // C += instead of C =
+    int kchunk; size_t slab_stride;       // K split over blockIdx.z: split z covers kchunk k's and writes C + z*slab_stride
+};
+void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
+void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
+void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st);      // part [nsplit][N]
+void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st);
+void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st);
+void launch_sigmoid_f32(float* v, size_t n, hipStream_t st);
+void launch_export_mat(const float* in, int B, int k, int X, float* out, hipStream_t st);
 
 }  // namespace iwae

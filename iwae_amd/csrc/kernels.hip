@@ -2440,8 +2440,17 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 z8[4 * h + i] = z;
             }
         }
-        if (valid)
+        if (valid && a.ZP)
             *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * (4 * t + q)) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+        if (valid && a.ZF) {       // float32 mode: z in natural feature order, unrounded
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 32 * t + 16 * h + 4 * q + i;
+                    if (f < a.ldZF) a.ZF[(size_t)row * a.ldZF + f] = z8[4 * h + i];
+                }
+        }
     }
     lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
     lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
@@ -2711,8 +2720,14 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
         }
     }
     if (sg == 0 && b < a.B) {
-        *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
-        *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
+        if (a.DHP) {
+            *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3]));
+            *(uint2*)(a.DHP + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
+        }
+        if (a.DHF) {
+            *(float4*)(a.DHF + (size_t)b * (2 * a.Dp) + f0) = make_float4(dmu[0], dmu[1], dmu[2], dmu[3]);
+            *(float4*)(a.DHF + (size_t)b * (2 * a.Dp) + a.Dp + f0) = make_float4(dsg[0], dsg[1], dsg[2], dsg[3]);
+        }
     }
     if (!a.prior_head) return;       // block-uniform
     // same reduction for the conditional prior's head: d/dmu_p, d/dsigma_p -> pre-activation of exp (sigma_p - 1e-6)
@@ -2731,8 +2746,14 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             else { dpm[i] = 0.0f; dps[i] = 0.0f; }
         }
     }
-    *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dpm[0], dpm[1]), pack2(dpm[2], dpm[3]));
-    *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dps[0], dps[1]), pack2(dps[2], dps[3]));
+    if (a.DHP2) {
+        *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dpm[0], dpm[1]), pack2(dpm[2], dpm[3]));
+        *(uint2*)(a.DHP2 + (size_t)b * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(dps[0], dps[1]), pack2(dps[2], dps[3]));
+    }
+    if (a.DHF2) {
+        *(float4*)(a.DHF2 + (size_t)b * (2 * a.Dp) + f0) = make_float4(dpm[0], dpm[1], dpm[2], dpm[3]);
+        *(float4*)(a.DHF2 + (size_t)b * (2 * a.Dp) + a.Dp + f0) = make_float4(dps[0], dps[1], dps[2], dps[3]);
+    }
 }
 
 // per data row and 4 features, 2-layer model: everything that touches a per-row
@@ -2784,8 +2805,14 @@ __global__ void gauss_bwd_kernel(GaussBwdArgs a) {
         }
     }
     if (valid) {
-        *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dm[0], dm[1]), pack2(dm[2], dm[3]));
-        *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
+        if (a.DHP) {
+            *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(f0)) = make_uint2(pack2(dm[0], dm[1]), pack2(dm[2], dm[3]));
+            *(uint2*)(a.DHP + (size_t)row * (2 * a.Dp) + p_pos(a.Dp + f0)) = make_uint2(pack2(ds[0], ds[1]), pack2(ds[2], ds[3]));
+        }
+        if (a.DHF) {
+            *(float4*)(a.DHF + (size_t)row * (2 * a.Dp) + f0) = make_float4(dm[0], dm[1], dm[2], dm[3]);
+            *(float4*)(a.DHF + (size_t)row * (2 * a.Dp) + a.Dp + f0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+        }
         if (a.mode == 0) *(float4*)(a.dz_direct + (size_t)row * a.ldDZ + f0) = make_float4(dzd[0], dzd[1], dzd[2], dzd[3]);
     }
 }

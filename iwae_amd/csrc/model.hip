@@ -128,6 +128,12 @@ struct iwae_model {
     DevBuf condP;              // y as bf16 P-layout [Bp][32*ceil(C/32)] (the prior block's input)
     float *param = nullptr, *grad = nullptr, *mom = nullptr, *vel = nullptr;
     int64_t adam_t = 0;
+    // float32 mode (iwae_config.precision / iwae_set_eval_precision): row-major float32 activations, GEMMs on v_mfma_f32_16x16x4_f32
+    struct F32Block { DevBuf h1, h2, dhead, d2, d1, dx; };
+    struct F32State { F32Block enc1, enc2, dec2; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart; } f32;
+    int eval_precision = IWAE_PREC_FP32;      // arithmetic of iwae_eval_llh (iwae_set_eval_precision)
+    bool fwd_was_f32 = false;                 // the last forward ran in float32 mode (its backward must too)
+    const float* f32_x = nullptr;             // device x [B][X] of the last float32 forward
     // data-parallel training inside the library (iwae_comm_init): one communicator per stream that carries a collective
     ncclComm_t comm_main = nullptr, comm_side = nullptr;
     int comm_world = 1, comm_rank = 0;
@@ -869,6 +875,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     }
     HIPCHK(hipGetLastError());
     m->have_forward = true;
+    m->fwd_was_f32 = false;
     return IWAE_OK;
 }
 
@@ -882,6 +889,7 @@ float adam_alpha(iwae_model* m, float lr) {      // keras Adam: lr_t = lr * sqrt
 // fused_lr >= 0: the optimizer update runs inside the slab reduction (single-GPU train step); < 0: gradient only
 int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool split = false) {
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "backward without forward");
+    if (m->fwd_was_f32) return fail(IWAE_ERR_STATE, "the last forward ran in float32 mode");
     const bool two = m->cfg.n_layers == 2;
     const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32;
     hipStream_t st = m->stream;
@@ -1122,6 +1130,277 @@ int adam_impl(iwae_model* m, float lr, float gscale) {
     return IWAE_OK;
 }
 
+// =================================================================== float32 mode
+// The reference's own arithmetic: Keras Dense layers in float32 (src/iwae1.py:31-34,72-75).  Same step structure as the bf16
+// path with plain row-major float32 tensors and one generic MFMA GEMM (fp32_kernels.hip); the per-sample kernels that already
+// work in float32 (sampling + densities, lse_kernel, latent_bwd_kernel, gauss_*_kernel, Adam) are shared.
+int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
+             const float* bias, int epi, const float* ACT, long ldact, bool accumulate) {
+    GemmF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    a.bias = bias; a.epi = epi; a.ACT = ACT; a.ldact = ldact; a.accumulate = accumulate ? 1 : 0; a.kchunk = K; a.slab_stride = 0;
+    launch_gemm_f32(a, 1, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+// Y = epi(X W + b), W = the Keras kernel [in, out] of layer kl inside the flat float32 parameters
+int f32_fwd(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, int rows, float* Y, long ldy, int epi) {
+    return f32_gemm(m, X, ldx, 1, m->param + kl.offW, kl.Nout, 1, Y, ldy, rows, kl.Nout, kl.Kin, m->param + kl.offb, epi, nullptr, 0, false);
+}
+// DX (+)= (G W^T) * (1 - ACT^2)   (ACT = the stored tanh output of the layer below, or null)
+int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int rows, float* DX, long lddx, const float* ACT, long ldact, bool accumulate) {
+    return f32_gemm(m, G, ldg, 1, m->param + kl.offW, 1, kl.Nout, DX, lddx, rows, kl.Kin, kl.Nout, nullptr, ACT ? GEMM_EPI_DTANH : GEMM_EPI_NONE, ACT, ldact, accumulate);
+}
+// grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
+int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows) {
+    const int nsplit = std::max(1, std::min(64, rows / 1024));
+    const size_t nW = (size_t)kl.Kin * kl.Nout;
+    CHK(ensure(m->f32.slab, nsplit * nW * 4, m->stream));
+    CHK(ensure(m->f32.bpart, (size_t)nsplit * kl.Nout * 4, m->stream));
+    GemmF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.A = X; a.sam = 1; a.sak = ldx; a.B = G; a.sbk = ldg; a.sbn = 1; a.M = kl.Kin; a.N = kl.Nout; a.K = rows;
+    a.kchunk = (rows + nsplit - 1) / nsplit; a.kchunk = (a.kchunk + 15) / 16 * 16;
+    const int ns = (rows + a.kchunk - 1) / a.kchunk;
+    if (ns == 1) { a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; launch_gemm_f32(a, 1, m->stream); }
+    else {
+        a.C = ptr<float>(m->f32.slab); a.ldc = kl.Nout; a.slab_stride = nW;
+        launch_gemm_f32(a, ns, m->stream);
+        launch_reduce_slabs_f32(ptr<float>(m->f32.slab), nW, ns, nW, m->grad + kl.offW, m->stream);
+    }
+    launch_colsum_f32(G, ldg, rows, kl.Nout, ns, ptr<float>(m->f32.bpart), m->stream);
+    launch_reduce_slabs_f32(ptr<float>(m->f32.bpart), kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+// BasicBlock (iwae1.py:36-44) on R rows: X [R][ldx] -> h1, h2 [R][H], head [R][2Dp] (mu at 0.., sigma = exp(.)+1e-6 at Dp..)
+int f32_block_fwd(iwae_model* m, int base, iwae_model::F32Block& w, const float* X, long ldx, int R, float* head, int Dp, bool bwd) {
+    const KerasLayer *l1 = &m->klayers[base], *l2 = l1 + 1, *lmu = l1 + 2, *lsd = l1 + 3;
+    const int H = l1->Nout, D = lmu->Nout;
+    CHK(ensure(w.h1, (size_t)R * H * 4, m->stream));
+    CHK(ensure(w.h2, (size_t)R * H * 4, m->stream));
+    CHK(f32_fwd(m, *l1, X, ldx, R, ptr<float>(w.h1), H, GEMM_EPI_TANH));
+    CHK(f32_fwd(m, *l2, ptr<float>(w.h1), H, R, ptr<float>(w.h2), H, GEMM_EPI_TANH));
+    CHK(f32_fwd(m, *lmu, ptr<float>(w.h2), H, R, head, 2 * Dp, GEMM_EPI_NONE));
+    CHK(f32_fwd(m, *lsd, ptr<float>(w.h2), H, R, head + Dp, 2 * Dp, GEMM_EPI_EXP));
+    (void)D; (void)bwd;
+    return IWAE_OK;
+}
+// backward of a BasicBlock from dhead [R][2Dp] (d mu | d pre-exp): all four weight gradients, optionally dX [R][lddx]
+int f32_block_bwd(iwae_model* m, int base, iwae_model::F32Block& w, const float* X, long ldx, int R, int Dp, float* dX, long lddx) {
+    const KerasLayer *l1 = &m->klayers[base], *l2 = l1 + 1, *lmu = l1 + 2, *lsd = l1 + 3;
+    const int H = l1->Nout;
+    const float* dh = ptr<float>(w.dhead);
+    CHK(ensure(w.d2, (size_t)R * H * 4, m->stream));
+    CHK(ensure(w.d1, (size_t)R * H * 4, m->stream));
+    CHK(f32_dw(m, *lmu, ptr<float>(w.h2), H, dh, 2 * Dp, R));
+    CHK(f32_dw(m, *lsd, ptr<float>(w.h2), H, dh + Dp, 2 * Dp, R));
+    CHK(f32_dx(m, *lmu, dh, 2 * Dp, R, ptr<float>(w.d2), H, ptr<float>(w.h2), H, false));
+    CHK(f32_dx(m, *lsd, dh + Dp, 2 * Dp, R, ptr<float>(w.d2), H, ptr<float>(w.h2), H, true));
+    CHK(f32_dw(m, *l2, ptr<float>(w.h1), H, ptr<float>(w.d2), H, R));
+    CHK(f32_dx(m, *l2, ptr<float>(w.d2), H, R, ptr<float>(w.d1), H, ptr<float>(w.h1), H, false));
+    CHK(f32_dw(m, *l1, X, ldx, ptr<float>(w.d1), H, R));
+    if (dX) CHK(f32_dx(m, *l1, ptr<float>(w.d1), H, R, dX, lddx, nullptr, 0, false));
+    return IWAE_OK;
+}
+
+int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd, const iwae_tensors* want) {
+    const bool from_ds = m->ds_start >= 0;
+    if ((!x && !from_ds) || B <= 0 || k <= 0) return fail(IWAE_ERR_ARG, "forward: need x, B > 0, k > 0");
+    if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
+    if (m->C > 0) return fail(IWAE_ERR_ARG, "float32 mode covers the unconditional 1- and 2-layer models");
+    const bool two = m->cfg.n_layers == 2;
+    m->B = B; m->k = k; m->M = B * k; m->beta = beta;
+    m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
+    m->time_this = false;
+    const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X;
+    hipStream_t st = m->stream;
+    CHK(join_side(m));
+    m->user_eps = eps != nullptr;
+    m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
+    if (!eps) {       // the step's draws, kept for the backward pass and the 2-layer densities (same generator as the bf16 path)
+        const int np = (m->epsc_par + 1) % 3;
+        if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+        CHK(draw_eps(m, np, m->noise_step, M, st));
+        m->epsc_par = np;
+        for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
+    } else {
+        CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
+    }
+    const float* xd = x;
+    if (from_ds) {      // main.py:117-120 on the device: gather + binarise, keeping the float32 copy of the batch
+        CHK(ensure(m->xP, (size_t)Bp * m->Xinp * 2, st));
+        CHK(ensure(m->xin, (size_t)B * X * 4, st));
+        launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, m->Xinp, Bp, m->cfg.seed,
+                               m->ds_epoch, ptr<uint16_t>(m->xP), ptr<float>(m->xin), st);
+        m->ds_start = -1;
+        xd = ptr<float>(m->xin);
+    } else if (!is_device_ptr(x, m->cfg.device)) { CHK(copy_in(m, m->xin, x, (size_t)B * X * 4)); xd = ptr<float>(m->xin); }
+    m->f32_x = xd;
+    // ---- encoder on the images
+    const int b_enc1 = m->enc1[0].sub[0];
+    CHK(ensure(m->wenc1.head, (size_t)Bp * 2 * m->Dp[0] * 4, st));
+    CHK(f32_block_fwd(m, b_enc1, m->f32.enc1, xd, X, B, ptr<float>(m->wenc1.head), m->Dp[0], bwd));
+    for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
+    float* lpxz = ptr<float>(m->rows[0]);
+    float* t1 = ptr<float>(m->rows[1]);
+    float* t2 = ptr<float>(m->rows[2]);
+    float* t3 = ptr<float>(m->rows[3]);
+    float* t4 = ptr<float>(m->rows[4]);
+    float* lqd = ptr<float>(m->rows[5]);
+    // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
+    CHK(ensure(m->f32.z[0], (size_t)Mp * m->D[0] * 4, st));
+    {
+        SampleArgs s;
+        memset(&s, 0, sizeof(s));
+        s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
+        s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
+        s.ZP = nullptr; s.ZF = ptr<float>(m->f32.z[0]); s.ldZF = m->D[0];
+        s.lp_prior = two ? nullptr : t1;
+        s.lq = two ? t3 : t2;
+        const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);
+        s.lq_dreg = want_dreg ? lqd : nullptr;
+        launch_sample(s, st);
+    }
+    if (two) {       // q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
+        const int b_enc2 = m->enc2[0].sub[0], b_dec2 = m->dec2[0].sub[0];
+        CHK(ensure(m->wenc2.head, (size_t)Mp * 2 * m->Dp[1] * 4, st));
+        CHK(f32_block_fwd(m, b_enc2, m->f32.enc2, ptr<float>(m->f32.z[0]), m->D[0], M, ptr<float>(m->wenc2.head), m->Dp[1], bwd));
+        CHK(ensure(m->f32.z[1], (size_t)Mp * m->D[1] * 4, st));
+        SampleArgs s;
+        memset(&s, 0, sizeof(s));
+        s.head = ptr<float>(m->wenc2.head); s.ldH = 2 * m->Dp[1]; s.Dp = m->Dp[1]; s.D = m->D[1]; s.head_per_row = 1;
+        s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 1);
+        s.ZP = nullptr; s.ZF = ptr<float>(m->f32.z[1]); s.ldZF = m->D[1];
+        s.lp_prior = t2; s.lq = t4; s.lq_dreg = nullptr;
+        launch_sample(s, st);
+        CHK(ensure(m->wdec2.head, (size_t)Mp * 2 * m->Dp[0] * 4, st));
+        CHK(f32_block_fwd(m, b_dec2, m->f32.dec2, ptr<float>(m->f32.z[1]), m->D[1], M, ptr<float>(m->wdec2.head), m->Dp[0], bwd));
+        GaussLpArgs g;
+        memset(&g, 0, sizeof(g));
+        g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * m->Dp[0]; g.Dzp = m->Dp[0];
+        g.phead = ptr<float>(m->wdec2.head); g.ldPH = 2 * m->Dp[0]; g.Dpp = m->Dp[0];
+        g.D = m->D[0]; g.M = M; g.k = k; g.eps = eps_src(m, 0); g.out = t1;
+        launch_gauss_lp(g, st);
+    }
+    // ---- decoder + Bernoulli log-likelihood (iwae1.py:81-83,111)
+    const int b_dec1 = m->dec1[0].sub[0];
+    const KerasLayer *d1 = &m->klayers[b_dec1], *d2 = d1 + 1, *d3 = d1 + 2;
+    const int H = d1->Nout;
+    CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
+    CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
+    CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
+    CHK(f32_fwd(m, *d1, ptr<float>(m->f32.z[0]), m->D[0], M, ptr<float>(m->f32.g1), H, GEMM_EPI_TANH));
+    CHK(f32_fwd(m, *d2, ptr<float>(m->f32.g1), H, M, ptr<float>(m->f32.g2), H, GEMM_EPI_TANH));
+    CHK(f32_fwd(m, *d3, ptr<float>(m->f32.g2), H, M, ptr<float>(m->f32.logits), X, GEMM_EPI_NONE));
+    launch_bern_f32(ptr<float>(m->f32.logits), X, xd, X, M, k, lpxz, st);
+    if (want && want->logits) {      // reference [k,B,X] order
+        CHK(ensure(m->scratch, (size_t)M * X * 4, st));
+        launch_export_mat(ptr<float>(m->f32.logits), B, k, X, ptr<float>(m->scratch), st);
+        CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
+    }
+    // ---- log_w, log-mean-exp over k, objectives (iwae1.py:113-139): the shared kernel
+    CHK(ensure(m->logw, (size_t)Mp * 4, st));
+    CHK(ensure(m->wn, (size_t)Mp * 4, st));
+    CHK(ensure(m->gx, (size_t)Mp * 4, st));
+    CHK(ensure(m->cf, (size_t)Mp * 16, st));
+    CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
+    {
+        LseArgs a;
+        memset(&a, 0, sizeof(a));
+        if (!two) {
+            a.term[0] = lpxz; a.coef[0] = 1.f; a.term[1] = t1; a.coef[1] = beta; a.term[2] = t2; a.coef[2] = -beta;
+            a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0]; a.cz_on = 1.f;
+        } else {
+            a.term[0] = lpxz; a.coef[0] = 1.f; a.term[1] = t1; a.coef[1] = 1.f; a.term[2] = t2; a.coef[2] = 1.f;
+            a.term[3] = t3; a.coef[3] = -1.f; a.term[4] = t4; a.coef[4] = -1.f; a.head = nullptr; a.cz_on = 0.f;
+        }
+        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
+        a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
+        a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
+        a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
+        a.n_px_part = 1; a.px_stride = 0; a.term0_out = lpxz;
+        launch_lse(a, st);
+        launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
+    }
+    HIPCHK(hipGetLastError());
+    m->have_forward = true;
+    m->fwd_was_f32 = true;
+    m->px_parts = 1;
+    return IWAE_OK;
+}
+
+// closed-form backward in float32: leaves the flat gradient in m->grad
+int backward_f32(iwae_model* m, int objective) {
+    if (!m->have_forward || !m->fwd_was_f32) return fail(IWAE_ERR_STATE, "backward without a float32 forward");
+    const bool two = m->cfg.n_layers == 2;
+    const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, X = m->X;
+    hipStream_t st = m->stream;
+    const int b_dec1 = m->dec1[0].sub[0];
+    const KerasLayer *d1 = &m->klayers[b_dec1], *d2 = d1 + 1, *d3 = d1 + 2;
+    const int H = d1->Nout, D0 = m->D[0], Dp0 = m->Dp[0];
+    float* dl = ptr<float>(m->f32.logits);
+    launch_dl_f32(dl, X, m->f32_x, X, M, k, ptr<float>(m->gx), st);        // dl = g_r (x - sigmoid(l)), in place
+    CHK(ensure(m->f32.d2, (size_t)M * H * 4, st));
+    CHK(ensure(m->f32.d1, (size_t)M * H * 4, st));
+    CHK(ensure(m->wdec1.dz, (size_t)Mp * Dp0 * 4, st));
+    CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M));
+    CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false));
+    CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M));
+    CHK(f32_dx(m, *d2, ptr<float>(m->f32.d2), H, M, ptr<float>(m->f32.d1), H, ptr<float>(m->f32.g1), H, false));
+    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0, ptr<float>(m->f32.d1), H, M));
+    CHK(f32_dx(m, *d1, ptr<float>(m->f32.d1), H, M, ptr<float>(m->wdec1.dz), Dp0, nullptr, 0, false));
+    const float *dz1_b = nullptr, *dz1_c = nullptr;
+    if (two) {
+        const int b_enc2 = m->enc2[0].sub[0], b_dec2 = m->dec2[0].sub[0];
+        const int Dp1 = m->Dp[1];
+        CHK(ensure(m->dzdir, (size_t)Mp * Dp0 * 4, st));
+        CHK(ensure(m->f32.dec2.dhead, (size_t)Mp * 2 * Dp0 * 4, st));
+        CHK(ensure(m->f32.dec2.dx, (size_t)Mp * Dp1 * 4, st));
+        CHK(ensure(m->f32.enc2.dhead, (size_t)Mp * 2 * Dp1 * 4, st));
+        CHK(ensure(m->f32.enc2.dx, (size_t)Mp * Dp0 * 4, st));
+        HIPCHK(hipMemsetAsync(m->f32.dec2.dhead.p, 0, (size_t)Mp * 2 * Dp0 * 4, st));      // (pad columns are read by the weight-gradient GEMMs' strided views: keep them zero)
+        HIPCHK(hipMemsetAsync(m->f32.enc2.dhead.p, 0, (size_t)Mp * 2 * Dp1 * 4, st));
+        GaussBwdArgs g;
+        memset(&g, 0, sizeof(g));
+        g.mode = 0; g.G = ptr<float>(m->gx);
+        g.head = ptr<float>(m->wdec2.head); g.ldH = 2 * Dp0; g.D = D0; g.Dp = Dp0;
+        g.zhead = ptr<float>(m->wenc1.head); g.ldZH = 2 * Dp0; g.Dzp = Dp0;
+        g.dz_direct = ptr<float>(m->dzdir); g.ldDZ = Dp0;
+        g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
+        g.DHP = nullptr; g.DHF = ptr<float>(m->f32.dec2.dhead);
+        launch_gauss_bwd(g, st);
+        CHK(f32_block_bwd(m, b_dec2, m->f32.dec2, ptr<float>(m->f32.z[1]), m->D[1], M, Dp0, ptr<float>(m->f32.dec2.dx), Dp1));
+        memset(&g, 0, sizeof(g));
+        g.mode = 1; g.G = ptr<float>(m->gx);
+        g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * Dp1; g.D = m->D[1]; g.Dp = Dp1;
+        g.dz_in = ptr<float>(m->f32.dec2.dx); g.ldDZ = Dp1;
+        g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
+        g.DHP = nullptr; g.DHF = ptr<float>(m->f32.enc2.dhead);
+        launch_gauss_bwd(g, st);
+        CHK(f32_block_bwd(m, b_enc2, m->f32.enc2, ptr<float>(m->f32.z[0]), D0, M, Dp1, ptr<float>(m->f32.enc2.dx), Dp0));
+        dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->f32.enc2.dx);
+    }
+    {
+        CHK(ensure(m->f32.enc1.dhead, (size_t)m->Bp * 2 * Dp0 * 4, st));
+        HIPCHK(hipMemsetAsync(m->f32.enc1.dhead.p, 0, (size_t)m->Bp * 2 * Dp0 * 4, st));
+        LatentBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.dz = ptr<float>(m->wdec1.dz); a.dz2 = dz1_b; a.dz3 = dz1_c; a.ldDZ = Dp0;
+        a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * Dp0; a.D = D0; a.Dp = Dp0;
+        a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
+        a.B = B; a.Bp = m->Bp; a.k = k;
+        a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
+        a.DHP = nullptr; a.DHF = ptr<float>(m->f32.enc1.dhead);
+        launch_latent_bwd(a, st);
+    }
+    CHK(f32_block_bwd(m, m->enc1[0].sub[0], m->f32.enc1, m->f32_x, X, B, Dp0, nullptr, 0));
+    HIPCHK(hipGetLastError());
+    m->split_offset = m->nparam;       // (data-parallel step: one all-reduce of the whole gradient)
+    return IWAE_OK;
+}
+
 // Data-parallel step, second half (the gradient of this rank's shard is in m->grad; backward_impl(split) left the decoder's
 // segment on the side stream, unjoined): all-reduce + Adam(grad_scale 1/N) of the decoder's layers on the SIDE stream -- they run
 // beside the encoder's backward pass and the next encoder forward, as the single-GPU step's deferred update does -- and of the
@@ -1164,6 +1443,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
                                       std::to_string(sizeof(iwae_config)) + " bytes (binding built against another include/iwae_amd.h?)");
     if (cfg->reserved != 0) return fail(IWAE_ERR_ARG, "iwae_config.reserved must be 0");
     if (cfg->precision != IWAE_PREC_BF16 && cfg->precision != IWAE_PREC_FP32) return fail(IWAE_ERR_ARG, "precision must be IWAE_PREC_BF16 or IWAE_PREC_FP32");
+    if (cfg->precision == IWAE_PREC_FP32 && cfg->cond_dim > 0) return fail(IWAE_ERR_ARG, "float32 mode covers the unconditional 1- and 2-layer models (cond_dim = 0)");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(IWAE_ERR_ARG, "need world_size >= 1 and 0 <= rank < world_size");
     if (cfg->n_layers != 1 && cfg->n_layers != 2) return fail(IWAE_ERR_ARG, "n_layers must be 1 or 2 (main.py:17)");
     for (int i = 0; i < cfg->n_layers; ++i) {
@@ -1300,6 +1580,12 @@ void iwae_destroy(iwae_handle m) {
         DevBuf* bb[] = {&w->g1P, &w->g2P, &w->dlP, &w->d2P, &w->d1P, &w->dz};
         for (DevBuf* b : bb) free_buf(*b);
     }
+    {
+        iwae_model::F32Block* fb[] = {&m->f32.enc1, &m->f32.enc2, &m->f32.dec2};
+        for (auto* w : fb) { DevBuf* bb[] = {&w->h1, &w->h2, &w->dhead, &w->d2, &w->d1, &w->dx}; for (DevBuf* b : bb) free_buf(*b); }
+        DevBuf* bb[] = {&m->f32.z[0], &m->f32.z[1], &m->f32.g1, &m->f32.g2, &m->f32.logits, &m->f32.d2, &m->f32.d1, &m->f32.slab, &m->f32.bpart};
+        for (DevBuf* b : bb) free_buf(*b);
+    }
     if (m->param) (void)hipFree(m->param);
     if (m->grad) (void)hipFree(m->grad);
     if (m->mom) (void)hipFree(m->mom);
@@ -1420,7 +1706,8 @@ int iwae_forward(iwae_handle m, const float* x, int32_t B, int32_t k, float beta
                  const iwae_tensors* want) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(m->cfg.device));
-    CHK(forward_impl(m, x, B, k, beta, eps, OBJ_IWAE_ELBO, false, want));
+    if (m->cfg.precision == IWAE_PREC_FP32) CHK(forward_f32(m, x, B, k, beta, eps, OBJ_IWAE_ELBO, false, want));
+    else CHK(forward_impl(m, x, B, k, beta, eps, OBJ_IWAE_ELBO, false, want));
     CHK(fetch_outputs(m, scalars, want));
     m->noise_step += 1;
     return IWAE_OK;
@@ -1431,8 +1718,13 @@ int iwae_forward_backward(iwae_handle m, const float* x, int32_t B, int32_t k, f
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(check_objective(m, objective));
-    CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
-    CHK(backward_impl(m, objective));
+    if (m->cfg.precision == IWAE_PREC_FP32) {
+        CHK(forward_f32(m, x, B, k, beta, eps, objective, true, want));
+        CHK(backward_f32(m, objective));
+    } else {
+        CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
+        CHK(backward_impl(m, objective));
+    }
     CHK(fetch_outputs(m, scalars, want));
     m->noise_step += 1;
     return IWAE_OK;
@@ -1443,8 +1735,13 @@ int iwae_forward_backward_split(iwae_handle m, const float* x, int32_t B, int32_
     if (!m || !side_stream || !side_offset) return fail(IWAE_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(check_objective(m, objective));
-    CHK(forward_impl(m, x, B, k, beta, eps, objective, true, nullptr));
-    CHK(backward_impl(m, objective, -1.0f, true));
+    if (m->cfg.precision == IWAE_PREC_FP32) {       // float32 mode: nothing is left on the side stream (*side_offset = n)
+        CHK(forward_f32(m, x, B, k, beta, eps, objective, true, nullptr));
+        CHK(backward_f32(m, objective));
+    } else {
+        CHK(forward_impl(m, x, B, k, beta, eps, objective, true, nullptr));
+        CHK(backward_impl(m, objective, -1.0f, true));
+    }
     *side_stream = (void*)m->side;
     *side_offset = m->split_offset;
     m->noise_step += 1;
@@ -1466,6 +1763,13 @@ int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
     return adam_impl(m, lr, grad_scale);
 }
 
+int iwae_set_eval_precision(iwae_handle m, int32_t precision) {
+    if (!m) return fail(IWAE_ERR_ARG, "null handle");
+    if (precision != IWAE_PREC_BF16 && precision != IWAE_PREC_FP32) return fail(IWAE_ERR_ARG, "precision must be IWAE_PREC_BF16 or IWAE_PREC_FP32");
+    m->eval_precision = precision;
+    return IWAE_OK;
+}
+
 int iwae_set_adam(iwae_handle m, float beta1, float beta2, float epsilon) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     if (!(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(epsilon > 0.f)) return fail(IWAE_ERR_ARG, "set_adam: need 0 <= beta < 1, epsilon > 0");
@@ -1478,6 +1782,16 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(m->cfg.device));
     CHK(check_objective(m, objective));
+    if (m->cfg.precision == IWAE_PREC_FP32) {   // float32 mode: forward, closed-form backward, [exchange,] Adam -- all in float32
+        CHK(forward_f32(m, x, B, k, beta, eps, objective, true, want));
+        CHK(backward_f32(m, objective));
+        if (want) CHK(fetch_outputs(m, nullptr, want));
+        if (m->comm_main) CHK(dp_finish(m, lr));
+        else CHK(adam_impl(m, lr, 1.0f));
+        CHK(fetch_outputs(m, scalars, nullptr));
+        m->noise_step += 1;
+        return IWAE_OK;
+    }
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
     if (m->comm_main) {                         // data-parallel step: exchange between gradient and update (iwae_comm_init)
         CHK(backward_impl(m, objective, -1.0f, true));
@@ -1564,7 +1878,9 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
         const int nb = std::min(chunk, N - i0);
         m->batch_offset = saved_off + (uint32_t)i0;
         m->cond_row0 = i0;
-        const int rc_fwd = forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
+        const bool f32 = m->eval_precision == IWAE_PREC_FP32 && m->C == 0;      // (the conditional models evaluate on the bf16 path)
+        const int rc_fwd = f32 ? forward_f32(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
+                               : forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
         m->cond_row0 = 0;
         if (rc_fwd != IWAE_OK) { m->batch_offset = saved_off; return rc_fwd; }
         HIPCHK(hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));

@@ -197,6 +197,10 @@ class NativeModel:
         """keras.optimizers.Adam hyper-parameters of the device optimizer (default: the reference's, main.py:93)."""
         check(self.lib.iwae_set_adam(self.h, float(beta_1), float(beta_2), float(epsilon)))
 
+    def set_eval_precision(self, precision):
+        """Arithmetic of eval_llh: "fp32" (default, the reference's) or "bf16" (the fast path)."""
+        check(self.lib.iwae_set_eval_precision(self.h, PRECISIONS[precision]))
+
     def adam_step(self, lr, grad_scale=1.0):
         check(self.lib.iwae_adam_step(self.h, float(lr), float(grad_scale)))
 

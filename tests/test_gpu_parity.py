@@ -648,6 +648,143 @@ def test_eval_llh_chunking_and_definition(big):
     assert np.isfinite(l5000) and l5000 > l50 - 0.5
 
 
+# ---------------------------------------------------------------- float32 mode (iwae_config.precision = IWAE_PREC_FP32)
+# "fp32 kernels rel 1e-5 on scalars / 1e-4 on grads vs fp64 oracle".  The reference computes in float32
+# (Keras Dense defaults, src/iwae1.py:31-34,72-75); every GEMM of this mode is an exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
+F32_SCALAR_REL, F32_GRAD_REL, F32_ROW_ATOL = 1e-5, 1e-4, 2e-3
+
+CASES_F32 = [  # (layers, B, k, objective, beta, n_hidden, n_latent, x_dim)
+    (1, 20, 1, "vae_elbo", 1.0, 200, 100, 784),          # BASELINE configs[0]
+    (1, 8, 50, "iwae_elbo", 1.0, 200, 100, 784),
+    (1, 5, 7, "vae_elbo_kl", 0.7, 200, 100, 784),
+    (1, 6, 5, "iwae_eq14", 1.0, 200, 100, 784),
+    (1, 6, 5, "dreg", 1.0, 200, 100, 784),               # tasks/task02.py
+    (1, 5, 3, "iwae_elbo", 0.7, 16, 4, 48),              # the tiny fixture's dims
+    (1, 3, 130, "iwae_elbo", 1.0, 64, 2, 784),           # 2-D latent (tasks/task01.py), k > 64
+    (1, 170, 50, "iwae_elbo", 1.0, 200, 100, 784),       # 8 500 rows: row-split weight gradients
+    (2, 4, 3, "iwae_elbo", 1.0, [200, 100], [100, 50], 784),
+    (2, 6, 50, "vae_elbo", 1.0, [200, 100], [100, 50], 784),
+    (2, 3, 5, "iwae_eq14", 1.0, [16, 8], [4, 2], 48),
+]
+
+
+@pytest.mark.parametrize("layers,B,k,obj,beta,nh,nl,xd", CASES_F32)
+def test_float32_mode_matches_exact_oracle(gpu, layers, B, k, obj, beta, nh, nl, xd):
+    from iwae_amd.native import NativeModel
+    x, P, eps = MG.inputs(layers, nh, nl, xd, B, k, 300 + B + k)
+    if layers == 1:
+        res, g = O.loss_grads_1layer(P, x, eps, beta, obj)
+        rows = (("lpxz", "lpxz"), ("lpz", "lpz"), ("lqzx", "lqzx"))
+        keys = ("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "vae_elbo_kl", "iwae_elbo", "iwae_eq14")
+    else:
+        res, g = O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, obj)
+        rows = (("lpxz", "lpxz1"), ("lpz", "lpz1z2"), ("lpz2", "lpz2"), ("lqzx", "lqz1x"), ("lqzx2", "lqz2z1"))
+        keys = ("vae_elbo", "iwae_elbo", "iwae_eq14")
+    m = NativeModel(layers, nh, nl, x_dim=xd, seed=123, precision="fp32")
+    m.set_params(O.flatten_params(P))
+    r = m.forward_backward(x, k, beta, obj, eps=eps, want=tuple(a for a, _ in rows) + ("al", "logits", "z"))
+    for a, b in rows:
+        assert np.max(np.abs(r[a] - res[b])) < F32_ROW_ATOL, (a, float(np.max(np.abs(r[a] - res[b]))))
+    assert np.max(np.abs(r["logits"] - res["logits"])) < 2e-4
+    np.testing.assert_allclose(r["z"], res["z"] if layers == 1 else res["z1"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(r["al"], res["al"], atol=2e-4)
+    for key in keys:
+        assert abs(r[key] - res[key]) <= F32_SCALAR_REL * abs(res[key]) + 2e-4, (key, r[key], res[key])
+    if obj == "dreg":
+        assert abs(r["inference_loss"] - res["inference_loss"]) <= 1e-4 * abs(res["inference_loss"]) + 1e-4
+    flat = m.get_grads()
+    errs = _grad_rel_errors(flat, g)
+    assert max(errs) < F32_GRAD_REL, errs
+    # the forward-only call and the fused train step agree with the two-call path; Keras Adam from the device gradient
+    r0 = m.forward(x, k, beta, eps=eps)
+    for key in keys:
+        assert abs(r0[key] - r[key]) <= 1e-6 * abs(r[key]) + 1e-5
+    r2 = m.train_step(x, k, beta, 1e-3, obj, eps=eps)
+    np.testing.assert_array_equal(m.get_grads(), flat)
+    ref, _, _ = O.adam_update(O.flatten_params(P), flat.astype(np.float64), 0.0, 0.0, 1, 1e-3)
+    assert np.max(np.abs(m.get_params() - ref)) < 2e-6
+    m.close()
+
+
+def test_float32_mode_against_golden_fixtures(gpu):
+    """The tiny fixtures' exact (float64) expectations, element by element, at SURVEY 8(c)'s float32 tolerances."""
+    from iwae_amd.native import NativeModel
+    for name in ("tiny_1layer", "tiny_2layer", "full_1layer_B20_k1"):
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        nl = int(g["n_layers"])
+        nh = g["n_hidden"].tolist() if nl == 2 else int(g["n_hidden"])
+        nlat = g["n_latent"].tolist() if nl == 2 else int(g["n_latent"])
+        B, k, beta, xd = int(g["B"]), int(g["k"]), float(g["beta"]), int(g["x_dim"])
+        x, P, eps = MG.inputs(nl, nh, nlat, xd, B, k, int(g["seed"]))
+        m = NativeModel(nl, nh, nlat, x_dim=xd, seed=123, precision="fp32")
+        for obj in [str(o) for o in g["objectives"]]:
+            m.set_params(O.flatten_params(P))
+            r = m.forward_backward(x, k, beta, obj, eps=eps)
+            pre = "exact/%s/" % obj
+            for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+                if pre + key in g:
+                    assert abs(r[key] - float(g[pre + key])) <= F32_SCALAR_REL * abs(float(g[pre + key])) + 2e-4, (name, obj, key)
+            flat = m.get_grads().astype(np.float64)
+            want = g[pre + "grad_probe"]
+            got = flat[g["grad_probe_idx"]]
+            assert np.linalg.norm(got - want) <= F32_GRAD_REL * np.linalg.norm(want) + 1e-9, (name, obj)
+            if pre + "grad_flat" in g:
+                full = g[pre + "grad_flat"]
+                assert np.linalg.norm(flat - full) <= F32_GRAD_REL * np.linalg.norm(full), (name, obj)
+        m.close()
+
+
+def test_float32_mode_with_device_noise_and_dataset_pipeline(gpu):
+    """float32 mode on the device's own Philox noise (oracle fed the NumPy restatement of the same draws) and through the
+    resident-dataset input path; 15 fused train steps track the float64 oracle trajectory."""
+    from iwae_amd.native import NativeModel
+    B, k, step = 40, 10, 3
+    x = O.synthetic_binarized(B, 23)
+    P = O.init_params(1, 200, 100, 29, x_mean=O.synthetic_pixel_means())
+    eps = philox_np.device_eps(123, step, B, k, 100)
+    res, g = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo")
+    m = NativeModel(1, 200, 100, seed=123, precision="fp32")
+    m.set_params(O.flatten_params(P))
+    m.set_step(step, 0)
+    r = m.forward_backward(x, k, 1.0, "iwae_elbo", want=("lpxz", "lqzx"))
+    assert abs(r["iwae_elbo"] - res["iwae_elbo"]) < 2e-2        # float32 Box-Muller with fast sin / cos / log: eps differs by <= 2e-5
+    assert max(_grad_rel_errors(m.get_grads(), g)) < 2e-3
+    # trajectory with explicit noise
+    flat = O.flatten_params(P)
+    mo = vo = 0.0
+    rng = np.random.default_rng(5)
+    for t in range(1, 16):
+        e = rng.standard_normal((k, B, 100)).astype(np.float32)
+        rr = m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", eps=e)
+        Pt = O.unflatten_params(flat, 1, 200, 100)
+        rt, gt = O.loss_grads_1layer(Pt, x, e, 1.0, "iwae_elbo")
+        flat, mo, vo = O.adam_update(flat, O.flatten_grads(gt), mo, vo, t, 1e-3)
+        assert abs(rr["iwae_elbo"] - rt["iwae_elbo"]) < 5e-3
+    assert np.max(np.abs(m.get_params() - flat)) < 2e-5
+    # resident dataset path == host batch path
+    rng = np.random.default_rng(3)
+    gray = (rng.random((200, 784)) * 256).astype(np.uint8)
+    m.dataset_upload(gray)
+    m.dataset_begin_epoch(2, rng.permutation(200).astype(np.int32))
+    xb = m.dataset_get_batch(11, 64)
+    p0 = m.get_params().copy(); mo_, ve_, ts_ = m.get_adam_state()
+    m.set_step(9, 0)
+    a = m.train_step_dataset(11, 64, 5, 1.0, 1e-3, "iwae_elbo")
+    pa = m.get_params().copy()
+    m.set_params(p0); m.set_adam_state(mo_, ve_, ts_)
+    m.set_step(9, 0)
+    b = m.train_step(xb, 5, 1.0, 1e-3, "iwae_elbo")
+    assert a["iwae_elbo"] == b["iwae_elbo"]
+    np.testing.assert_array_equal(pa, m.get_params())
+    m.close()
+
+
+def test_float32_mode_rejects_conditional_models(gpu):
+    from iwae_amd.native import NativeModel
+    with pytest.raises(ValueError):
+        NativeModel(1, 200, 100, cond_dim=10, precision="fp32")
+
+
 def test_full_size_dreg_invariants(big):
     """BASELINE configs[3] at its full size (B = 1024, k = 50, DReG step of tasks/task02.py:87-101) through size-independent
     properties: the decoder is trained on -iwae_elbo (:95-96), so its gradient must equal the iwae_elbo step's decoder gradient
@@ -779,16 +916,23 @@ def test_trained_model_k5000_llh_within_north_star_tolerance(gpu):
     net = model._net
     n = 16
     net.set_step(999, 0)
-    llh_dev, per = net.eval_llh(Xt[:n], 5000, chunk=n, per_image=True)
+    llh_dev, per = net.eval_llh(Xt[:n], 5000, chunk=n, per_image=True)        # default arithmetic of the evaluator: float32
+    net.set_eval_precision("bf16")
+    net.set_step(999, 0)
+    _, per_bf = net.eval_llh(Xt[:n], 5000, chunk=n, per_image=True)            # the fast path (bf16 GEMM operands)
+    net.set_eval_precision("fp32")
     P = O.unflatten_params(net.get_params().astype(np.float64), 1, 200, 100)
     per_o = np.array([float(O.forward_1layer(P, Xt[i:i + 1], philox_np.device_eps(123, 999, 1, 5000, 100, batch_offset=i))["iwae_elbo"])
                       for i in range(n)])
     d_mean, d_max = abs(per.mean() - per_o.mean()), np.max(np.abs(per - per_o))
     print("k=5000 LLH: device %.4f, exact fp64 oracle %.4f, |mean diff| %.4f, max per-image |diff| %.4f (trained %.2f -> %.2f)"
           % (per.mean(), per_o.mean(), d_mean, d_max, first, last))
+    d_bf_mean, d_bf_max = abs(per_bf.mean() - per_o.mean()), np.max(np.abs(per_bf - per_o))
+    print("          bf16 evaluator: |mean diff| %.4f, max per-image |diff| %.4f" % (d_bf_mean, d_bf_max))
     assert abs(llh_dev - per.mean()) < 1e-3
-    assert d_mean <= 0.1, d_mean           # north_star: +-0.1 nat
-    assert d_max <= 0.1, d_max
+    assert d_mean <= 0.1 and d_max <= 0.1, (d_mean, d_max)                 # north_star: +-0.1 nat
+    assert d_mean <= 2e-3 and d_max <= 5e-3, (d_mean, d_max)               # ... and float32 arithmetic is two orders inside it
+    assert d_bf_mean <= 0.1 and d_bf_max <= 0.1, (d_bf_mean, d_bf_max)     # the bf16 evaluator also stays inside the budget
 
 
 def test_training_reduces_loss_and_matches_oracle_trajectory(gpu):
