@@ -254,14 +254,21 @@ def run():
     llh_eval = None
     if world == 1 and not args.no_llh_eval and cfg["layers"] == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
         n_eval = 1000
-        net.eval_llh(x_np[:32], 5000)
-        net.sync()
-        t1 = time.perf_counter()
-        llh = net.eval_llh(np.tile(x_np, (n_eval // x_np.shape[0] + 1, 1))[:n_eval], 5000)
-        dt_eval = time.perf_counter() - t1
-        llh_eval = {"k": 5000, "images": n_eval, "images_per_s": round(n_eval / dt_eval, 1), "llh": round(float(llh), 3),
-                    "gemm_tflops": round(n_eval * 2168473600.0 / dt_eval / 1e12, 1),
-                    "note": "forward-only evaluator on synthetic images with the just-trained weights; 10 000 images take %.2f s" % (dt_eval * 10000 / n_eval)}
+        xe = np.tile(x_np, (n_eval // x_np.shape[0] + 1, 1))[:n_eval]
+        llh_eval = {"k": 5000, "images": n_eval}
+        for prec in ("fp32", "bf16"):      # the evaluator's default arithmetic (float32, as the reference's) and the fast path
+            net.set_eval_precision(prec)
+            net.set_step(1 << 20, 0)
+            net.eval_llh(xe[:32], 5000)
+            net.sync()
+            net.set_step(1 << 20, 0)
+            t1 = time.perf_counter()
+            llh = net.eval_llh(xe, 5000)
+            dt_eval = time.perf_counter() - t1
+            llh_eval[prec] = {"images_per_s": round(n_eval / dt_eval, 1), "llh": round(float(llh), 4),
+                              "gemm_tflops": round(n_eval * 2168473600.0 / dt_eval / 1e12, 1), "s_per_10000_images": round(dt_eval * 10000 / n_eval, 3)}
+        net.set_eval_precision("fp32")
+        llh_eval["note"] = "forward-only evaluator on synthetic images with the just-trained weights, same noise in both arithmetics"
 
     if rank == 0:
         ms = dt * 1e3 / args.steps

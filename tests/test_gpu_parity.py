@@ -631,21 +631,24 @@ def test_eval_llh_chunking_and_definition(big):
     """main.py:170-184: mean over images of iwae_elbo(k, B=1).  Chunking must not change the estimate
     (noise is keyed by the global image index) and it must equal per-image forward calls."""
     m, x = big
-    m.set_step(21, 0)
-    a, pa = m.eval_llh(x[:48], k=500, chunk=48, per_image=True)
-    m.set_step(21, 0)
-    b, pb = m.eval_llh(x[:48], k=500, chunk=7, per_image=True)
-    np.testing.assert_allclose(pa, pb, atol=2e-3)
-    assert abs(a - b) < 1e-3
-    m.set_step(21, 5)
-    single = m.forward(x[5:6], 500)["iwae_elbo"]
-    assert abs(single - pa[5]) < 2e-3
+    for prec in ("fp32", "bf16"):          # the evaluator's default arithmetic (float32) and the fast path
+        m.set_eval_precision(prec)
+        m.set_step(21, 0)
+        a, pa = m.eval_llh(x[:48], k=500, chunk=48, per_image=True)
+        m.set_step(21, 0)
+        b, pb = m.eval_llh(x[:48], k=500, chunk=7, per_image=True)
+        np.testing.assert_allclose(pa, pb, atol=2e-3)
+        assert abs(a - b) < 1e-3
+        m.set_step(21, 5)
+        single = m.forward(x[5:6], 500)["iwae_elbo"]          # this handle's forward is the bf16 path
+        assert abs(single - pa[5]) < (2e-3 if prec == "bf16" else EXACT_SCALAR_ATOL)
     # k = 5000 (the reference's L) on a few images: runs, finite, and tighter than k = 50 on average
     m.set_step(22, 0)
     l5000 = m.eval_llh(x[:8], k=5000)
     m.set_step(22, 0)
     l50 = m.eval_llh(x[:8], k=50)
     assert np.isfinite(l5000) and l5000 > l50 - 0.5
+    m.set_eval_precision("fp32")
 
 
 # ---------------------------------------------------------------- float32 mode (iwae_config.precision = IWAE_PREC_FP32)
