@@ -186,6 +186,7 @@ void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st);
 void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st);      // shape: see wgradp_strip
 int wgradp_strip(int shape);          // j-tiles (16 out-features each) per block of a shape: 8 -> 8, 16 / 7 -> 16
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
+void launch_wgradws_group(const WgradPGroup& g, hipStream_t st);     // shape-7 (specialised waves) gradients, non-row-weighted, in one launch
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);

@@ -2119,15 +2119,14 @@ __device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n in {0, 8, 12
     }
 }
 template <bool SC>
-__global__ __launch_bounds__(768, 3) void wgradws_kernel(WgradPArgs a) {
+__device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz, const int gx, const int nz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int AI = 7, BJ = 4, IGC = 2, NCW = 8, NLW = 4, STRIP = 16;
     constexpr int XT_BYTES = WG_SR * 512, GROW = 512, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
     constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, PPL = (XP + GP) / NLW, XPL = XP / NLW, GPL = GP / NLW;     // pieces per loader: 8 = 4 X + 4 G
     typedef __attribute__((ext_vector_type(4))) short v4s;
-    int bx = blockIdx.x, bz = blockIdx.z;
     {   // XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
-        const int gx = gridDim.x, nb = gx * (int)gridDim.z;
+        const int nb = gx * nz;
         if ((nb & 7) == 0) {
             const int L = bx + gx * bz;
             const int V = (L & 7) * (nb >> 3) + (L >> 3);
@@ -2290,6 +2289,19 @@ __global__ __launch_bounds__(768, 3) void wgradws_kernel(WgradPArgs a) {
             if (ig == 0 && q == 0) a.slabB[(size_t)bz * a.JT * 16 + jt * 16 + l16] = accb[u][0];
         }
     }
+}
+
+template <bool SC>
+__global__ __launch_bounds__(768, 3) void wgradws_kernel(WgradPArgs a) {
+    wgradws_body<SC>(a, blockIdx.x, blockIdx.z, gridDim.x, gridDim.z);
+}
+// two (or three) of them in one launch: blockIdx.z runs over the concatenated row splits (the decoder's two hidden layers need the
+// same inputs at the same time -- one launch instead of two queued behind each other on a side stream)
+__global__ __launch_bounds__(768, 3) void wgradws_group_kernel(WgradPGroup g) {
+    int l = 0;
+    while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
+    if ((int)blockIdx.x >= g.gx[l]) return;          // (uniform per workgroup: no barrier is skipped by part of a workgroup)
+    wgradws_body<false>(g.a[l], blockIdx.x, blockIdx.z - g.zbeg[l], g.gx[l], g.zbeg[l + 1] - g.zbeg[l]);
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
@@ -3123,6 +3135,11 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
         }
     }
 }
+void launch_wgradws_group(const WgradPGroup& g, hipStream_t st) {
+    int mx = 0;
+    for (int l = 0; l < g.n; ++l) mx = std::max(mx, g.gx[l]);
+    LAUNCH_EV(wgradws_group_kernel, dim3(mx, 1, g.zbeg[g.n]), dim3(768), WG_NST * (WG_SR * 512 + WG_SR * 512), st, g);
+}
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
     int mx = 0, my = 0;
     for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
@@ -3135,8 +3152,8 @@ void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st) {
     const size_t sc = a.rowscale ? 1024 : 0;
     if (shape == 7) {        // specialised waves: 8 compute + 4 loader (needs IT <= 14, one i-block)
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512);
-        if (a.rowscale) hipLaunchKernelGGL((wgradws_kernel<true>), grid, dim3(768), lds, st, a);
-        else hipLaunchKernelGGL((wgradws_kernel<false>), grid, dim3(768), lds, st, a);
+        if (a.rowscale) LAUNCH_EV((wgradws_kernel<true>), grid, dim3(768), lds, st, a);
+        else LAUNCH_EV((wgradws_kernel<false>), grid, dim3(768), lds, st, a);
     } else if (shape == 16) {
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
         if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);

@@ -188,6 +188,8 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
+    hipStream_t tail = nullptr;        // this step's side stream that finishes last (carries the decoder's reduction / exchange / update)
+    bool allow_wg_group = true;        // IWAE_NO_WG_GROUP=1: the hidden layers' gradients as two launches (A/B measurements)
     hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
     hipEvent_t ev_s2 = nullptr;
     bool use_side2 = true;
@@ -378,6 +380,7 @@ int build_descs(iwae_model* m) {
     HIPCHK(hipMemcpyAsync(m->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // a deferred decoder update may still be reading the old table
+    if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
     m->descs_dirty = false;
     return IWAE_OK;
 }
@@ -955,20 +958,39 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // Forked early, the side stream is busy with the output layer's gradient until after that: ONE wait then covers everything,
     // and out_bwd carries no event at all -- one bubble less on the main stream, one wait less on the side stream.
     // The hidden layers' weight gradients need dpre2 / dpre1 (ev_fork2), not the output layer's gradient: forked early, that one
-    // keeps `side` busy well past the end of the dX chain, so they go to a second side stream and run beside it; `side` picks
-    // them up again (ev_s2) in front of whatever follows on it (the decoder's slab reduction / the join).
+    // keeps `side` busy well past the end of the dX chain, so they go to a second side stream and run beside it -- as ONE grouped
+    // launch where both take the specialised-wave shape.  They finish last, so that stream (`tail`) also carries what follows the
+    // weight gradients (the decoder's slab reduction [+ exchange] + Adam): it picks up `side` (ev_s2, recorded behind the output
+    // layer's gradient, long complete by then) instead of `side` picking up the later of the two.
     hipStream_t ws = m->side;
+    m->tail = m->side;
     if (m->early_wout && m->use_side2) {
+        HIPCHK(hipEventRecord(m->ev_s2, m->side));
         HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
         ws = m->side2;
+        m->tail = m->side2;
     } else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    { ScopedTimer tm(m, T_WGRAD_HID, ws); CHK(wgradp(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, ws)); }
-    if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-    { ScopedTimer tm(m, T_WGRAD_LAT, ws); CHK(wgradp(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, ws)); }
-    if (ws == m->side2) {
-        HIPCHK(hipEventRecord(m->ev_s2, m->side2));
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_s2, 0));
+    {
+        WgradPArgs ah, al;
+        int nsh = 1, nsl = 1, shh = 8, shl = 8;
+        CHK(wgradp_plan(m, m->dec1[1], ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d2P), M, ah, nsh, shh));
+        CHK(wgradp_plan(m, m->dec1[0], ptr<uint16_t>(m->zP[0]), ptr<uint16_t>(w.d1P), M, al, nsl, shl));
+        if (shh == 7 && shl == 7 && m->allow_wg_group && (m->early_wout || fused_dx)) {      // (both inputs ready: one launch)
+            WgradPGroup g;
+            memset(&g, 0, sizeof(g));
+            g.n = 2; g.a[0] = ah; g.a[1] = al;
+            g.gx[0] = (m->dec1[1].JT + 15) / 16; g.gx[1] = (m->dec1[0].JT + 15) / 16; g.gy[0] = g.gy[1] = 1;
+            g.zbeg[0] = 0; g.zbeg[1] = nsh; g.zbeg[2] = nsh + nsl;
+            ScopedTimer tm(m, T_WGRAD_HID, ws);
+            launch_wgradws_group(g, ws);
+        } else {
+            { ScopedTimer tm(m, T_WGRAD_HID, ws); launch_wgradp(ah, nsh, shh, ws); }
+            if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+            { ScopedTimer tm(m, T_WGRAD_LAT, ws); launch_wgradp(al, nsl, shl, ws); }
+        }
+        HIPCHK(hipGetLastError());
     }
+    if (ws == m->side2) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -1024,11 +1046,11 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     if (early) {
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
-                            m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->side);
+                            m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
-        HIPCHK(hipEventRecord(m->ev_join, m->side));
+        HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
     {
@@ -1044,7 +1066,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         // the encoder's backward pass / update and the next step's encoder forward.
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
-                            m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side);
+                            m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
     }
     HIPCHK(hipGetLastError());
@@ -1412,10 +1434,10 @@ int dp_finish(iwae_model* m, float lr) {
     const size_t n = m->nparam, off = m->split_offset;
     if (off < n && m->dec_pending) {
         const int b0 = m->descs[m->dec1[0].sub[0]].block_begin;
-        NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->side));
+        NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail));
         set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
-                    m->side, b0);
+                    m->tail, b0);
         NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
         launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
     } else {
@@ -1510,6 +1532,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         HIPCHK(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
         HIPCHK(hipEventCreateWithFlags(&m->ev_s2, hipEventDisableTiming));
         m->use_side2 = getenv("IWAE_NO_SIDE2") == nullptr;
+        m->allow_wg_group = getenv("IWAE_NO_WG_GROUP") == nullptr;
+        m->tail = m->side;
     }
     HIPCHK(hipEventCreateWithFlags(&m->ev_lse, hipEventDisableTiming));
     m->allow_early_wout = getenv("IWAE_NO_EARLY_WOUT") == nullptr;
@@ -1742,7 +1766,7 @@ int iwae_forward_backward_split(iwae_handle m, const float* x, int32_t B, int32_
         CHK(forward_impl(m, x, B, k, beta, eps, objective, true, nullptr));
         CHK(backward_impl(m, objective, -1.0f, true));
     }
-    *side_stream = (void*)m->side;
+    *side_stream = (void*)m->tail;
     *side_offset = m->split_offset;
     m->noise_step += 1;
     return IWAE_OK;
