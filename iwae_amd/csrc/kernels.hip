@@ -3156,12 +3156,12 @@ void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st) {
         else LAUNCH_EV((wgradws_kernel<false>), grid, dim3(768), lds, st, a);
     } else if (shape == 16) {
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
-        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<16, 4, 4, 4, false>), grid, dim3(1024), lds, st, a);
+        if (a.rowscale) LAUNCH_EV((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);
+        else LAUNCH_EV((wgradp_kernel<16, 4, 4, 4, false>), grid, dim3(1024), lds, st, a);
     } else {
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 256 + sc);
-        if (a.rowscale) hipLaunchKernelGGL((wgradp_kernel<8, 4, 4, 4, true>), grid, dim3(512), lds, st, a);
-        else hipLaunchKernelGGL((wgradp_kernel<8, 4, 4, 4, false>), grid, dim3(512), lds, st, a);
+        if (a.rowscale) LAUNCH_EV((wgradp_kernel<8, 4, 4, 4, true>), grid, dim3(512), lds, st, a);
+        else LAUNCH_EV((wgradp_kernel<8, 4, 4, 4, false>), grid, dim3(512), lds, st, a);
     }
 }
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st) {
