@@ -188,8 +188,18 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
+    // hipGraph replay of the small-batch train step (the reference's default regime, B = 20: ~20 dependent launches of a few
+    // microseconds each): the step is captured ONCE per (shape, objective, input) in serial form -- every kernel on the main stream,
+    // no events -- and replayed; step counter, batch offset, Adam step size and dataset offset travel through d_dyn (StepDyn).
+    struct GraphEntry { int B, k, objective; float beta; const void* x; int from_ds; uint64_t gen; int seen; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    StepDyn* d_dyn = nullptr;
+    bool serial = false;               // this call runs in serial form (capture / its warm-up step)
+    bool allow_graph = true;           // IWAE_NO_GRAPH=1: never capture (A/B measurements, tests)
+    int graph_max_rows = 4096;         // capture only below this many data rows (IWAE_GRAPH_ROWS): beyond it the step is not launch-bound
     hipStream_t tail = nullptr;        // this step's side stream that finishes last (carries the decoder's reduction / exchange / update)
-    bool allow_wg_group = true;        // IWAE_NO_WG_GROUP=1: the hidden layers' gradients as two launches (A/B measurements)
+    bool allow_wg_group = false;       // IWAE_WG_GROUP=1: the hidden layers' gradients as ONE grouped launch (measured: 0.2450 vs 0.2384 ms/step as two launches --
+                                       // both at once take more of the machine from the output layer's gradient, which is what the step waits for)
     hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
     hipEvent_t ev_s2 = nullptr;
     bool use_side2 = true;
@@ -226,8 +236,10 @@ struct iwae_model {
 
 namespace {
 
+static thread_local uint64_t g_alloc_gen = 0;      // bumped whenever a work buffer moves: captured graphs hold the old addresses
 int ensure(DevBuf& b, size_t bytes, hipStream_t st) {
     if (bytes <= b.cap) return IWAE_OK;
+    g_alloc_gen += 1;
     if (b.p) {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipFree(b.p));
@@ -422,6 +434,7 @@ EpsSrc eps_src(iwae_model* m, int layer) {
     e.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k;
     e.step = m->noise_step;
     e.stream = (uint32_t)layer;
+    if (m->serial) { e.dyn = m->d_dyn; e.dyn_k = m->k; }
     return e;
 }
 
@@ -637,7 +650,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
-    m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
+    m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0 && !m->serial;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32, Xinp = m->Xinp;
     hipStream_t st = m->stream;
@@ -655,7 +668,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         const int np = (m->epsc_par + 1) % 3;
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
         iwae_model::EpsTag& tg = m->eps_tag[np];
-        if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
+        if (m->serial) {            // captured step: the draws are always made in the graph, from the replay's own counters
+            CHK(draw_eps(m, np, m->noise_step, M, st));
+            m->eps_tag[np].valid = false;
+        } else if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
             CHK(join_side(m));          // a speculative draw into this slot may still be on the side stream
             if (m->side) HIPCHK(hipStreamSynchronize(m->side));
             CHK(draw_eps(m, np, m->noise_step, M, st));
@@ -669,7 +685,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xinp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st, m->serial ? m->d_dyn : nullptr);
         m->ds_start = -1;
     } else {
         const float* xd = x;
@@ -713,7 +729,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // side stream, which is idle until the backward pass forks -- behind the weight gradients it sat on the step's critical
     // tail (the side stream's chain decides when the next decoder forward may start).  Third ring slot: the previous step's
     // draws may still be read by its backward pass, this step's are in use.
-    if (bwd && keep_eps && m->side) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
+    if (bwd && keep_eps && m->side && !m->serial) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
     bool fuse_z = false;
     SampleArgs zin;
     memset(&zin, 0, sizeof(zin));
@@ -870,7 +886,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights lse_kernel leaves -- not
         // out_bwd -- so the side stream forks here (ev_lse on this kernel's dispatch packet), one kernel earlier, and the
         // gradient runs beside out_bwd (both read s)
-        m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two;
+        m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two && !m->serial;
         if (m->early_wout) set_launch_stop_event(m->ev_lse);
         launch_lse(a, st);
         // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
@@ -934,27 +950,29 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 d.imgB2 = m->dec1[1].imgB; d.G1 = ptr<uint16_t>(w.g1P); d.D1P = ptr<uint16_t>(w.d1P);
                 d.imgB1 = m->dec1[0].imgB; d.MG1 = m->dec1[0].MG_B; d.DZ = ptr<float>(w.dz); d.ldDZ = m->dec1[0].Kp32;
                 ScopedTimer tm(m, T_DEC_BWD);
-                set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
+                if (!m->serial) set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
                 launch_dec_bwd(d, st);
             } else {
             // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
-            { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
+            { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout && !m->serial) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
             }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
+    hipStream_t sd = m->serial ? st : m->side;       // serial form (graph capture): everything on the main stream, no events
+    if (m->serial) {}
+    else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
-        ScopedTimer tm(m, T_WGRAD_OUT, m->side);
+        ScopedTimer tm(m, T_WGRAD_OUT, sd);
         if (m->early_wout && m->use_side2) set_launch_stop_event(m->ev_s2);
-        CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, m->side, m->s_mode ? ptr<float>(m->gx) : nullptr));
+        CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->gx) : nullptr));
     }
     if (!fused_dx) {
         { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
-        { ScopedTimer tm(m, T_DX_LAT); set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
+        { ScopedTimer tm(m, T_DX_LAT); if (!m->serial) set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
     }
     // ONE event (ev_fork2) behind the whole dX chain -- the last of its kernels carries it on its dispatch packet (every separate
     // record costs the main stream a ~6 us bubble): the hidden layers' weight gradients need dpre2 and dpre1, and the deferred
@@ -966,9 +984,10 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // launch where both take the specialised-wave shape.  They finish last, so that stream (`tail`) also carries what follows the
     // weight gradients (the decoder's slab reduction [+ exchange] + Adam): it picks up `side` (ev_s2, recorded behind the output
     // layer's gradient, long complete by then) instead of `side` picking up the later of the two.
-    hipStream_t ws = m->side;
-    m->tail = m->side;
-    if (m->early_wout && m->use_side2) {
+    hipStream_t ws = sd;
+    m->tail = sd;
+    if (m->serial) {}
+    else if (m->early_wout && m->use_side2) {
         HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
         ws = m->side2;
         m->tail = m->side2;
@@ -988,16 +1007,16 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             launch_wgradws_group(g, ws);
         } else {
             { ScopedTimer tm(m, T_WGRAD_HID, ws); launch_wgradp(ah, nsh, shh, ws); }
-            if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+            if (!m->early_wout && !fused_dx && !m->serial) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
             { ScopedTimer tm(m, T_WGRAD_LAT, ws); launch_wgradp(al, nsl, shl, ws); }
         }
         HIPCHK(hipGetLastError());
     }
-    if (ws == m->side2) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
+    if (ws == m->side2 && !m->serial) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
-    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two;      // (2-layer: the main stream needs the side-stream block gradients anyway)
+    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two && !m->serial;      // (2-layer: the main stream needs the side-stream block gradients anyway)
 
     const float* dz1 = ptr<float>(w.dz);
     const float *dz1_b = nullptr, *dz1_c = nullptr;
@@ -1013,7 +1032,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wdec2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true, true));
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true, !m->serial));
         memset(&g, 0, sizeof(g));
         g.mode = 1; g.G = ptr<float>(m->gx);
         g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
@@ -1021,7 +1040,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wenc2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, true));
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, !m->serial));
         dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
     }
     {
@@ -1044,7 +1063,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
     // Without split (iwae_forward_backward: gradient only, e.g. the one-message data-parallel step) the same early decoder
     // reduction runs on the side stream and the main stream joins it behind its own, shorter, encoder reduction.
-    const bool early = !fuse && m->early_first > 0 && !two;
+    const bool early = !fuse && m->early_first > 0 && !two && !m->serial;
     m->split_offset = m->nparam;
     if (early) {
         set_launch_stop_event(m->ev_dec);
@@ -1052,14 +1071,15 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                             m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
-    } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
+    } else if (!defer && !m->serial) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
     }
     {
         ScopedTimer tm_red(m, T_REDUCE);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st,
+                            (m->serial && fuse) ? m->d_dyn : nullptr);
     }
     if (early && !split) CHK(join_side(m));
     if (defer) {
@@ -1426,6 +1446,79 @@ int backward_f32(iwae_model* m, int objective) {
     return IWAE_OK;
 }
 
+// Small-batch train step through a captured hipGraph (see iwae_model::GraphEntry).  *handled = false: not eligible, the caller
+// runs the ordinary step.  First sight of a key: one eager step in serial form (sizes every buffer); second: capture + first
+// replay; from then on: a one-thread kernel writes this step's counters into d_dyn, then hipGraphLaunch.
+int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, float lr, int objective, bool* handled) {
+    *handled = false;
+    const bool from_ds = m->ds_start >= 0;
+    if (!m->allow_graph || m->cfg.precision != IWAE_PREC_BF16 || m->comm_main || m->C > 0 || (int64_t)B * k >= m->graph_max_rows) return IWAE_OK;
+    if (!from_ds && (!x || !is_device_ptr(x, m->cfg.device))) return IWAE_OK;        // a host batch is staged by a pageable copy: not capturable
+    if (m->timing > 0 && (m->timing_calls % m->timing) == 0) return IWAE_OK;          // a sampled step of iwae_enable_timing runs eagerly, with its events
+    CHK(join_side(m));
+    iwae_model::GraphEntry* ge = nullptr;
+    for (auto& g : m->graphs)
+        if (g.B == B && g.k == k && g.objective == objective && g.beta == beta && g.x == (from_ds ? nullptr : (const void*)x) && g.from_ds == (int)from_ds) ge = &g;
+    if (!ge) {
+        if (m->graphs.size() >= 16) { for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); m->graphs.clear(); }
+        m->graphs.push_back({B, k, objective, beta, from_ds ? nullptr : (const void*)x, (int)from_ds, 0, 0, nullptr});
+        ge = &m->graphs.back();
+    }
+    const float alpha = adam_alpha(m, lr);          // advances the Adam step count: exactly once per train step, whichever branch runs it
+    const int ds_start = m->ds_start;
+    launch_set_dyn(m->d_dyn, m->noise_step, m->batch_offset, alpha, ds_start, m->stream);
+    HIPCHK(hipGetLastError());
+    if (ge->exec && ge->gen == g_alloc_gen && !m->descs_dirty) {
+        HIPCHK(hipGraphLaunch(ge->exec, m->stream));
+        m->timing_calls += 1;
+        m->ds_start = -1;
+        m->B = B; m->k = k; m->M = B * k; m->beta = beta; m->have_forward = false;
+        *handled = true;
+        return IWAE_OK;
+    }
+    if (ge->exec) { (void)hipGraphExecDestroy(ge->exec); ge->exec = nullptr; ge->seen = 0; }        // buffers moved since the capture
+    m->adam_t -= 1;                                  // (the serial step below computes alpha itself through backward_impl)
+    m->serial = true;
+    int rc = IWAE_OK;
+    if (ge->seen == 0) {                             // warm-up: the same serial step, eagerly -- allocates and plans everything the capture will reference
+        rc = forward_impl(m, x, B, k, beta, nullptr, objective, true, nullptr);
+        if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
+        m->serial = false;
+        if (rc != IWAE_OK) return rc;
+        ge->seen = 1;
+        *handled = true;
+        return IWAE_OK;
+    }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { m->serial = false; (void)hipGetLastError(); m->allow_graph = false; return IWAE_OK; }      // capture unavailable: eager from now on
+    const uint64_t gen0 = g_alloc_gen;
+    m->ds_start = ds_start;
+    rc = forward_impl(m, x, B, k, beta, nullptr, objective, true, nullptr);
+    if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
+    m->serial = false;
+    e = hipStreamEndCapture(m->stream, &graph);
+    if (rc != IWAE_OK || e != hipSuccess || !graph || gen0 != g_alloc_gen || m->descs_dirty) {
+        // something moved or could not be captured: drop the capture and run this step eagerly (nothing has executed yet)
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        m->adam_t -= 1;
+        ge->seen = 0;
+        m->ds_start = ds_start;
+        if (rc != IWAE_OK) return rc;
+        if (e != hipSuccess) m->allow_graph = false;
+        return IWAE_OK;                              // *handled = false
+    }
+    e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { ge->exec = nullptr; (void)hipGetLastError(); m->adam_t -= 1; m->ds_start = ds_start; m->allow_graph = false; return IWAE_OK; }
+    ge->gen = g_alloc_gen;
+    HIPCHK(hipGraphLaunch(ge->exec, m->stream));     // the capture recorded the step; this runs it (d_dyn already holds its counters)
+    m->have_forward = false;
+    *handled = true;
+    return IWAE_OK;
+}
+
 // Data-parallel step, second half (the gradient of this rank's shard is in m->grad; backward_impl(split) left the decoder's
 // segment on the side stream, unjoined): all-reduce + Adam(grad_scale 1/N) of the decoder's layers on the SIDE stream -- they run
 // beside the encoder's backward pass and the next encoder forward, as the single-GPU step's deferred update does -- and of the
@@ -1539,7 +1632,9 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         HIPCHK(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
         HIPCHK(hipEventCreateWithFlags(&m->ev_s2, hipEventDisableTiming));
         m->use_side2 = getenv("IWAE_NO_SIDE2") == nullptr;
-        m->allow_wg_group = getenv("IWAE_NO_WG_GROUP") == nullptr;
+        m->allow_wg_group = getenv("IWAE_WG_GROUP") != nullptr;
+        m->allow_graph = getenv("IWAE_NO_GRAPH") == nullptr;
+        if (const char* e = getenv("IWAE_GRAPH_ROWS")) m->graph_max_rows = atoi(e);
         m->tail = m->side;
     }
     HIPCHK(hipEventCreateWithFlags(&m->ev_lse, hipEventDisableTiming));
@@ -1571,6 +1666,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipMemset(m->vel, 0, nb));
     HIPCHK(hipMalloc((void**)&m->d_zero, 1024));
     HIPCHK(hipMemset(m->d_zero, 0, 1024));
+    HIPCHK(hipMalloc((void**)&m->d_dyn, sizeof(StepDyn)));
+    HIPCHK(hipMemset(m->d_dyn, 0, sizeof(StepDyn)));
     HIPCHK(hipMalloc((void**)&m->d_scalars, SC_COUNT * 4));
     HIPCHK(hipMemset(m->d_scalars, 0, SC_COUNT * 4));
     HIPCHK(hipHostMalloc((void**)&m->h_scalars, SC_COUNT * 4));
@@ -1623,6 +1720,8 @@ void iwae_destroy(iwae_handle m) {
     if (m->vel) (void)hipFree(m->vel);
     if (m->d_descs) (void)hipFree(m->d_descs);
     if (m->d_zero) (void)hipFree(m->d_zero);
+    for (auto& ge : m->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+    if (m->d_dyn) (void)hipFree(m->d_dyn);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);
     for (int i = 0; i < T_COUNT; ++i) {
@@ -1822,6 +1921,15 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
         CHK(fetch_outputs(m, scalars, nullptr));
         m->noise_step += 1;
         return IWAE_OK;
+    }
+    if (!eps && !want) {                        // small batches: the captured step (hipGraph replay), where eligible
+        bool handled = false;
+        CHK(train_step_graph(m, x, B, k, beta, lr, objective, &handled));
+        if (handled) {
+            CHK(fetch_outputs(m, scalars, nullptr));
+            m->noise_step += 1;
+            return IWAE_OK;
+        }
     }
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
     if (m->comm_main) {                         // data-parallel step: exchange between gradient and update (iwae_comm_init)

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 EMU_ROW_ATOL, EMU_SCALAR_ATOL, EMU_GRAD_REL = 0.03, 0.02, 1e-2
+O_ID = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "dreg": 4}
 EXACT_SCALAR_ATOL, EXACT_GRAD_REL = 0.15, 3e-2
 
 
@@ -434,6 +435,52 @@ def test_conditional_prior_model_matches_oracle(gpu, B, k, obj, beta):
     ref = O.sigmoid(dec.fwd(O.bf16_round(np.concatenate([mu_p + sig_p * z, yz], axis=-1))))
     assert np.max(np.abs(m.decode(z) - ref)) < 2e-2
     m.close()
+
+
+@pytest.mark.parametrize("layers,B,k,obj", [(1, 20, 1, "vae_elbo"), (1, 20, 5, "iwae_elbo"), (1, 32, 50, "dreg"), (2, 20, 5, "iwae_elbo")])
+def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, monkeypatch, layers, B, k, obj):
+    """BASELINE configs[0] regime (the reference's default B = 20, main.py:19-20): below 4 096 data rows iwae_train_step captures
+    the step once (serial form: one stream, no events) and replays the hipGraph, with the step counter, batch offset, Adam step
+    size and dataset offset read from a device block.  30 steps through the resident-dataset path and through a device-resident
+    batch must land on bit-identical parameters, Adam state and ELBO values as the eager step (IWAE_NO_GRAPH=1), including across a
+    change of batch shape (a second capture) and back."""
+    import torch
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    rng = np.random.default_rng(7)
+    gray = (rng.random((400, 784)) * 256).astype(np.uint8)
+    order = rng.permutation(400).astype(np.int32)
+    P = O.init_params(layers, nh, nl, 5, x_mean=O.synthetic_pixel_means())
+    xdev = torch.tensor(O.synthetic_binarized(B, 3), device="cuda")
+    outs = []
+    for graph in (False, True):
+        if not graph:
+            monkeypatch.setenv("IWAE_NO_GRAPH", "1")
+        m = _model(layers, nh, nl)
+        monkeypatch.delenv("IWAE_NO_GRAPH", raising=False)
+        m.set_params(O.flatten_params(P))
+        m.dataset_upload(gray)
+        m.dataset_begin_epoch(3, order)
+        elbos = []
+        for t in range(30):
+            if t == 17:                       # another shape in between: its own capture, then back to the first one
+                for _ in range(3):
+                    m.train_step_dataset(0, B // 2, k, 1.0, 1e-3, obj, scalars=False)
+            lr = 1e-3 if t < 20 else 5e-4     # the learning-rate schedule changes the step size inside a captured step (main.py:128-133)
+            if t % 2 == 0:
+                r = m.train_step_dataset((t * B) % (400 - B), B, k, 1.0, lr, obj, scalars=(t % 6 == 0))
+            else:
+                m.set_step(100 + t, 7 * t)
+                m.train_step_devptr(xdev.data_ptr(), B, k, 1.0, lr, O_ID[obj])
+                r = {}
+            if "iwae_elbo" in r:
+                elbos.append(r["iwae_elbo"])
+        outs.append((m.get_params().copy(), m.get_adam_state(), np.array(elbos)))
+        m.close()
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1][0], outs[1][1][0])
+    np.testing.assert_array_equal(outs[0][1][1], outs[1][1][1])
+    assert outs[0][1][2] == outs[1][1][2] == 33
 
 
 def test_changing_batch_shapes_do_not_leak_state(gpu):
