@@ -669,6 +669,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
         iwae_model::EpsTag& tg = m->eps_tag[np];
         if (m->serial) {            // captured step: the draws are always made in the graph, from the replay's own counters
+            for (int p3 = 0; p3 < 3; ++p3)       // (every ring slot sized by the warm-up step: no allocation may happen inside a capture)
+                for (int l = 0; l < m->cfg.n_layers; ++l) CHK(ensure(m->epsc[p3][l], (size_t)Mp * m->Dp[l] * 4, st));
             CHK(draw_eps(m, np, m->noise_step, M, st));
             m->eps_tag[np].valid = false;
         } else if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
@@ -1464,6 +1466,7 @@ int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, fl
         m->graphs.push_back({B, k, objective, beta, from_ds ? nullptr : (const void*)x, (int)from_ds, 0, 0, nullptr});
         ge = &m->graphs.back();
     }
+    if (ge->seen < 0) return IWAE_OK;               // a shape whose capture failed once: eager
     const float alpha = adam_alpha(m, lr);          // advances the Adam step count: exactly once per train step, whichever branch runs it
     const int ds_start = m->ds_start;
     launch_set_dyn(m->d_dyn, m->noise_step, m->batch_offset, alpha, ds_start, m->stream);
@@ -1502,11 +1505,9 @@ int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, fl
         // something moved or could not be captured: drop the capture and run this step eagerly (nothing has executed yet)
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        m->adam_t -= 1;
-        ge->seen = 0;
+        if (rc == IWAE_OK) m->adam_t -= 1;           // (backward_impl advanced the step count; the eager step will do it again)
+        ge->seen = (rc != IWAE_OK || e != hipSuccess) ? -1 : 0;      // -1: this shape is never captured again (the eager step reports a real error)
         m->ds_start = ds_start;
-        if (rc != IWAE_OK) return rc;
-        if (e != hipSuccess) m->allow_graph = false;
         return IWAE_OK;                              // *handled = false
     }
     e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
