@@ -191,11 +191,15 @@ struct iwae_model {
     // hipGraph replay of the small-batch train step (the reference's default regime, B = 20: ~20 dependent launches of a few
     // microseconds each): the step is captured ONCE per (shape, objective, input) in serial form -- every kernel on the main stream,
     // no events -- and replayed; step counter, batch offset, Adam step size and dataset offset travel through d_dyn (StepDyn).
-    struct GraphEntry { int B, k, objective; float beta; const void* x; int from_ds; uint64_t gen; int seen; hipGraphExec_t exec; };
+    struct GraphEntry { int B, k, objective; float beta; const void* x; int from_ds; uint64_t gen; int seen; hipGraphExec_t exec; LayerDesc* d_descs; };
+    bool capturing = false;            // inside hipStreamBeginCapture: the (synchronous) rebuild of the shared layer table is skipped
+    LayerDesc* cur_descs = nullptr;    // the layer table the slab reductions of THIS call read (a captured step owns a copy: its row splits are part of the capture)
     std::vector<GraphEntry> graphs;
     StepDyn* d_dyn = nullptr;
     bool serial = false;               // this call runs in serial form (capture / its warm-up step)
-    bool allow_graph = true;           // IWAE_NO_GRAPH=1: never capture (A/B measurements, tests)
+    bool allow_graph = false;          // IWAE_GRAPH=1 switches the captured step on.  Measured at B = 20, k = 1 (bench.py --config c0): replay 0.163 ms/step, eager 0.142 --
+                                       // the eager step overlaps its weight gradients on the side streams and is not host-bound, the serial capture gives that up
+                                       // and pays the graph launch; kept as an option (bit-identical to the eager step: test_graph_replayed_...)
     int graph_max_rows = 4096;         // capture only below this many data rows (IWAE_GRAPH_ROWS): beyond it the step is not launch-bound
     hipStream_t tail = nullptr;        // this step's side stream that finishes last (carries the decoder's reduction / exchange / update)
     bool allow_wg_group = false;       // IWAE_WG_GROUP=1: the hidden layers' gradients as ONE grouped launch (measured: 0.2450 vs 0.2384 ms/step as two launches --
@@ -1017,7 +1021,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     if (ws == m->side2 && !m->serial) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
-    if (m->descs_dirty) CHK(build_descs(m));
+    if (m->descs_dirty && !m->capturing) CHK(build_descs(m));
     const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two && !m->serial;      // (2-layer: the main stream needs the side-stream block gradients anyway)
 
     const float* dz1 = ptr<float>(w.dz);
@@ -1059,7 +1063,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
-    if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
+    if (m->descs_dirty && !m->capturing) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
     // split (data-parallel step, iwae_forward_backward_split): the decoder's layers are summed into the flat gradient on the
     // side stream, right behind their weight gradients, and NOT joined here -- the caller's all-reduce of that segment is
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
@@ -1069,7 +1073,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     m->split_offset = m->nparam;
     if (early) {
         set_launch_stop_event(m->ev_dec);
-        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
@@ -1079,7 +1083,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     {
         ScopedTimer tm_red(m, T_REDUCE);
-        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                             alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st,
                             (m->serial && fuse) ? m->d_dyn : nullptr);
     }
@@ -1090,7 +1094,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         // the trajectory test caught a stale-image race), joined by the next user of the decoder (join_side): it runs beside
         // the encoder's backward pass / update and the next step's encoder forward.
         set_launch_stop_event(m->ev_dec);
-        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
     }
@@ -1462,16 +1466,21 @@ int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, fl
     for (auto& g : m->graphs)
         if (g.B == B && g.k == k && g.objective == objective && g.beta == beta && g.x == (from_ds ? nullptr : (const void*)x) && g.from_ds == (int)from_ds) ge = &g;
     if (!ge) {
-        if (m->graphs.size() >= 16) { for (auto& g : m->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); m->graphs.clear(); }
-        m->graphs.push_back({B, k, objective, beta, from_ds ? nullptr : (const void*)x, (int)from_ds, 0, 0, nullptr});
+        if (m->graphs.size() >= 16) {
+            HIPCHK(hipStreamSynchronize(m->stream));
+            for (auto& g : m->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.d_descs) (void)hipFree(g.d_descs); }
+            m->graphs.clear();
+        }
+        m->graphs.push_back({B, k, objective, beta, from_ds ? nullptr : (const void*)x, (int)from_ds, 0, 0, nullptr, nullptr});
         ge = &m->graphs.back();
+        HIPCHK(hipMalloc((void**)&ge->d_descs, sizeof(LayerDesc) * m->klayers.size()));
     }
     if (ge->seen < 0) return IWAE_OK;               // a shape whose capture failed once: eager
     const float alpha = adam_alpha(m, lr);          // advances the Adam step count: exactly once per train step, whichever branch runs it
     const int ds_start = m->ds_start;
     launch_set_dyn(m->d_dyn, m->noise_step, m->batch_offset, alpha, ds_start, m->stream);
     HIPCHK(hipGetLastError());
-    if (ge->exec && ge->gen == g_alloc_gen && !m->descs_dirty) {
+    if (ge->exec && ge->gen == g_alloc_gen) {
         HIPCHK(hipGraphLaunch(ge->exec, m->stream));
         m->timing_calls += 1;
         m->ds_start = -1;
@@ -1488,6 +1497,8 @@ int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, fl
         if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
         m->serial = false;
         if (rc != IWAE_OK) return rc;
+        // this shape's layer table (row splits, slab addresses) as the step just planned it: the capture's slab reductions read this copy
+        HIPCHK(hipMemcpy(ge->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice));
         ge->seen = 1;
         *handled = true;
         return IWAE_OK;
@@ -1497,11 +1508,15 @@ int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, fl
     if (e != hipSuccess) { m->serial = false; (void)hipGetLastError(); m->allow_graph = false; return IWAE_OK; }      // capture unavailable: eager from now on
     const uint64_t gen0 = g_alloc_gen;
     m->ds_start = ds_start;
+    m->cur_descs = ge->d_descs;
+    m->capturing = true;
     rc = forward_impl(m, x, B, k, beta, nullptr, objective, true, nullptr);
     if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
     m->serial = false;
+    m->cur_descs = nullptr;
+    m->capturing = false;
     e = hipStreamEndCapture(m->stream, &graph);
-    if (rc != IWAE_OK || e != hipSuccess || !graph || gen0 != g_alloc_gen || m->descs_dirty) {
+    if (rc != IWAE_OK || e != hipSuccess || !graph || gen0 != g_alloc_gen) {
         // something moved or could not be captured: drop the capture and run this step eagerly (nothing has executed yet)
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
@@ -1634,7 +1649,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         HIPCHK(hipEventCreateWithFlags(&m->ev_s2, hipEventDisableTiming));
         m->use_side2 = getenv("IWAE_NO_SIDE2") == nullptr;
         m->allow_wg_group = getenv("IWAE_WG_GROUP") != nullptr;
-        m->allow_graph = getenv("IWAE_NO_GRAPH") == nullptr;
+        m->allow_graph = getenv("IWAE_GRAPH") != nullptr && getenv("IWAE_NO_GRAPH") == nullptr;
         if (const char* e = getenv("IWAE_GRAPH_ROWS")) m->graph_max_rows = atoi(e);
         m->tail = m->side;
     }
@@ -1721,7 +1736,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->vel) (void)hipFree(m->vel);
     if (m->d_descs) (void)hipFree(m->d_descs);
     if (m->d_zero) (void)hipFree(m->d_zero);
-    for (auto& ge : m->graphs) if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+    for (auto& ge : m->graphs) { if (ge.exec) (void)hipGraphExecDestroy(ge.exec); if (ge.d_descs) (void)hipFree(ge.d_descs); }
     if (m->d_dyn) (void)hipFree(m->d_dyn);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);

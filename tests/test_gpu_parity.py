@@ -440,9 +440,9 @@ def test_conditional_prior_model_matches_oracle(gpu, B, k, obj, beta):
 @pytest.mark.parametrize("layers,B,k,obj", [(1, 20, 1, "vae_elbo"), (1, 20, 5, "iwae_elbo"), (1, 32, 50, "dreg"), (2, 20, 5, "iwae_elbo")])
 def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, monkeypatch, layers, B, k, obj):
     """BASELINE configs[0] regime (the reference's default B = 20, main.py:19-20): below 4 096 data rows iwae_train_step captures
-    the step once (serial form: one stream, no events) and replays the hipGraph, with the step counter, batch offset, Adam step
-    size and dataset offset read from a device block.  30 steps through the resident-dataset path and through a device-resident
-    batch must land on bit-identical parameters, Adam state and ELBO values as the eager step (IWAE_NO_GRAPH=1), including across a
+    the step once (serial form: one stream, no events) and replays the hipGraph (IWAE_GRAPH=1), with the step counter, batch offset,
+    Adam step size and dataset offset read from a device block.  30 steps through the resident-dataset path and through a device-resident
+    batch must land on bit-identical parameters, Adam state and ELBO values as the eager step, including across a
     change of batch shape (a second capture) and back."""
     import torch
     nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
@@ -453,10 +453,10 @@ def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, monkeypa
     xdev = torch.tensor(O.synthetic_binarized(B, 3), device="cuda")
     outs = []
     for graph in (False, True):
-        if not graph:
-            monkeypatch.setenv("IWAE_NO_GRAPH", "1")
+        if graph:
+            monkeypatch.setenv("IWAE_GRAPH", "1")          # opt-in: measured slower than the eager multi-stream step
         m = _model(layers, nh, nl)
-        monkeypatch.delenv("IWAE_NO_GRAPH", raising=False)
+        monkeypatch.delenv("IWAE_GRAPH", raising=False)
         m.set_params(O.flatten_params(P))
         m.dataset_upload(gray)
         m.dataset_begin_epoch(3, order)
