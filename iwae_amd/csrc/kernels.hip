@@ -2109,13 +2109,20 @@ __global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_k
 // One barrier per stage: behind it the compute waves own stage c + 1 (landed, scaled) and the loaders own the buffer of
 // stage c (to refill) and stage c + 2 (to scale).
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n in {0, 8, 12, 16, 20}
+#ifndef WGRADWS_XCW
+#define WGRADWS_XCW 1
+#endif
+__device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n wave-uniform, a multiple of 2 up to 24
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
     }
 }
 template <bool SC>
@@ -2123,7 +2130,11 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int AI = 7, BJ = 4, IGC = 2, NCW = 8, NLW = 4, STRIP = 16;
     constexpr int XT_BYTES = WG_SR * 512, GROW = 512, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
-    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, PPL = (XP + GP) / NLW, XPL = XP / NLW, GPL = GP / NLW;     // pieces per loader: 8 = 4 X + 4 G
+    // XCW: the COMPUTE waves fetch the X tile (2 pieces each, issued in the slack of their MFMA stream), the loaders only the G strip
+    // (4 pieces each) which they also scale: the loaders' instruction stream (8 DMA issues at ~100+ cycles + the scaling) was what a
+    // stage took (ablations: 60 us alone, 47 without DMA, 44 without scaling, 57 without the MFMAs)
+    constexpr bool XCW = WGRADWS_XCW;
+    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, XPL = XCW ? 0 : XP / NLW, GPL = GP / NLW, PPL = XPL + GPL, XPC = XCW ? XP / NCW : 0;
     typedef __attribute__((ext_vector_type(4))) short v4s;
     {   // XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
         const int nb = gx * nz;
@@ -2237,9 +2248,28 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
     const bool do_bias = ig == 0 && !(a.dbg & 4);
+    // XCW: this wave's X pieces are pc = wave and wave + 8 (rows 2pc + (lane >> 5) of a stage): the same 16-byte chunk per lane in
+    // both (2*8 = 0 mod 4 rows apart: same swizzle), so ONE per-lane base pointer + wave-uniform offsets address every piece
+    const int xh = lane >> 5, xsl = lane & 31;
+    const int xcol = (xsl ^ (((2 * wave + xh) & 3) << 2)) * 8;
+    const char* xpb = (const char*)a.X + ((size_t)(rbeg + 2 * wave + xh) * a.ldX + xcol) * 2;
+    const int xlim = xcol < a.ldX ? rend - rbeg - 2 * wave - xh : -(1 << 30);          // piece i of stage st is real iff st*32 + 16*i < xlim
+    auto issue_x = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < XPC; ++i) {
+            const char* src = (st * WG_SR + 16 * i < xlim) ? xpb + ((size_t)st * WG_SR + 16 * i) * (size_t)(a.ldX * 2) : a.zero + xsl * 16;
+            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)(wave + NCW * i) * 1024u)));
+        }
+    };
+    if (XCW) {
+        for (int st = 0; st < min(nstage, WG_NST - 1); ++st) issue_x(st);
+        wait_vmem_but_ws(XPC * max(0, min(nstage, WG_NST - 1) - 1));          // stage 0's pieces have landed (for this wave; the barrier covers the others)
+    }
     __syncthreads();
     for (int c = 0; c < nstage; ++c) {
         const int buf = c % WG_NST;
+        const bool refill = XCW && c + WG_NST - 1 < nstage && !(a.dbg & 1);
+        if (refill) issue_x(c + WG_NST - 1);                 // into the buffer stage c - 1 has left (everyone passed the barrier behind it)
         const char* xb = smem + buf * BUF + xrow_off + p * 16;
         const char* gbase = smem + buf * BUF + XT_BYTES + grow_off;
         uint4 g[BJ];
@@ -2253,7 +2283,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
             g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
         }
         if (!(a.dbg & 2)) {
-            lds_pipeline<AI, 3>(
+            lds_pipeline<AI, XCW ? 2 : 3>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
                     const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
@@ -2271,6 +2301,8 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
 #pragma unroll
             for (int u = 0; u < BJ; ++u) accb[u] = mfma16(ones, g[u], accb[u]);
         }
+        if (XCW && c + 1 < nstage)       // this wave's pieces of stage c + 1 have landed; stages c + 2 (and c + 3, if just issued) may still fly
+            wait_vmem_but_ws(XPC * ((c + 2 < nstage ? 1 : 0) + (refill ? 1 : 0)));
         __syncthreads();
     }
     if (a.dbg & 16) return;
