@@ -2110,7 +2110,8 @@ __global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_k
 // stage c (to refill) and stage c + 2 (to scale).
 // ---------------------------------------------------------------------------------
 #ifndef WGRADWS_XCW
-#define WGRADWS_XCW 1
+#define WGRADWS_XCW 0      // 1: the compute waves fetch the X tile themselves.  Measured: 68 / 40 us alone (row-weighted / plain) against 60 / 25 --
+                           // a DMA issue stalls the issuing wave ~100+ cycles, which here comes out of the MFMA stream; not used
 #endif
 __device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n wave-uniform, a multiple of 2 up to 24
     switch (n) {
