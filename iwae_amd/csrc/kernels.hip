@@ -2109,33 +2109,30 @@ __global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_k
 // One barrier per stage: behind it the compute waves own stage c + 1 (landed, scaled) and the loaders own the buffer of
 // stage c (to refill) and stage c + 2 (to scale).
 // ---------------------------------------------------------------------------------
-#ifndef WGRADWS_XCW
-#define WGRADWS_XCW 0      // 1: the compute waves fetch the X tile themselves.  Measured: 68 / 40 us alone (row-weighted / plain) against 60 / 25 --
-                           // a DMA issue stalls the issuing wave ~100+ cycles, which here comes out of the MFMA stream; not used
-#endif
-__device__ __forceinline__ void wait_vmem_but_ws(int n) {      // n wave-uniform, a multiple of 2 up to 24
+// counted wait for any count 0..24 (wave-uniform)
+__device__ __forceinline__ void wait_vmem_but_ws(int n) {
+#define IWAE_WS_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        IWAE_WS_CASE(0) IWAE_WS_CASE(1) IWAE_WS_CASE(2) IWAE_WS_CASE(3) IWAE_WS_CASE(4) IWAE_WS_CASE(5) IWAE_WS_CASE(6) IWAE_WS_CASE(7)
+        IWAE_WS_CASE(8) IWAE_WS_CASE(9) IWAE_WS_CASE(10) IWAE_WS_CASE(11) IWAE_WS_CASE(12) IWAE_WS_CASE(13) IWAE_WS_CASE(14) IWAE_WS_CASE(15)
+        IWAE_WS_CASE(16) IWAE_WS_CASE(17) IWAE_WS_CASE(18) IWAE_WS_CASE(19) IWAE_WS_CASE(20) IWAE_WS_CASE(21) IWAE_WS_CASE(22) IWAE_WS_CASE(23)
         default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
     }
+#undef IWAE_WS_CASE
 }
-template <bool SC>
+// <SC, BJ, NLW>: BJ = j-tiles per compute wave (the workgroup's G strip is 4*BJ tiles wide), NLW = loader waves.
+//   <.., 4, 4>: 224 x 256 features per workgroup, 8 + 4 waves at <= 168 registers (three per SIMD)
+//   <.., 2, 8>: 224 x 128 features, 8 + 8 waves at <= 128 registers (four per SIMD): a third of the DMA issues and a quarter of the
+//               scaling per loader and stage -- the loaders' instruction stream is what a stage takes (see above) -- for 1.75x the
+//               X-tile traffic out of L2 (seven column blocks instead of four)
+template <bool SC, int BJ, int NLW>
 __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz, const int gx, const int nz) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    constexpr int AI = 7, BJ = 4, IGC = 2, NCW = 8, NLW = 4, STRIP = 16;
-    constexpr int XT_BYTES = WG_SR * 512, GROW = 512, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
-    // XCW: the COMPUTE waves fetch the X tile (2 pieces each, issued in the slack of their MFMA stream), the loaders only the G strip
-    // (4 pieces each) which they also scale: the loaders' instruction stream (8 DMA issues at ~100+ cycles + the scaling) was what a
-    // stage took (ablations: 60 us alone, 47 without DMA, 44 without scaling, 57 without the MFMAs)
-    constexpr bool XCW = WGRADWS_XCW;
-    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, XPL = XCW ? 0 : XP / NLW, GPL = GP / NLW, PPL = XPL + GPL, XPC = XCW ? XP / NCW : 0;
+    constexpr int AI = 7, IGC = 2, NCW = 8, STRIP = 4 * BJ;
+    constexpr int XT_BYTES = WG_SR * 512, GROW = STRIP * 32, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
+    constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, XPL = XP / NLW, GPL = GP / NLW, PPL = XPL + GPL;      // pieces per loader and stage
+    constexpr int SPR = GROW / 16, RPP = 1024 / GROW;                   // G strip: 16-byte slots per row, rows per 1 KiB piece
+    static_assert(XP % NLW == 0 && GP % NLW == 0 && GPL >= 1 && GPL <= 4, "loader split");
     typedef __attribute__((ext_vector_type(4))) short v4s;
     {   // XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
         const int nb = gx * nz;
@@ -2158,13 +2155,23 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         const char* pbase[PPL];
         int plim[PPL];
         const int xstride = WG_SR * a.ldX * 2, gstride = WG_SR * a.ldG * 2;
+        int grow_l[GPL];                   // row (inside a stage) of the lane's 16 bytes in its G pieces
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             const bool isx = i < XPL;
-            const int pc = isx ? lw * XPL + i : lw * GPL + (i - XPL);          // piece index inside the X tile / the G strip
-            const int rl = 2 * pc + (lane >> 5), sl = lane & 31;
-            const int col = (isx ? 0 : gcol0) + (sl ^ ((rl & 3) << 2)) * 8;     // source 16-byte chunk of this LDS slot
-            const int ld = isx ? a.ldX : a.ldG;
+            int rl, col, ld;
+            if (isx) {
+                const int pc = lw * XPL + i;
+                rl = 2 * pc + (lane >> 5);
+                col = ((lane & 31) ^ ((rl & 3) << 2)) * 8;               // source 16-byte chunk of this LDS slot
+                ld = a.ldX;
+            } else {
+                const int pc = lw * GPL + (i - XPL);
+                rl = RPP * pc + lane / SPR;
+                col = gcol0 + ((lane % SPR) ^ ((rl & 3) << 2)) * 8;
+                ld = a.ldG;
+                grow_l[i - XPL] = rl;
+            }
             pbase[i] = (const char*)(isx ? a.X : a.G) + ((size_t)(rbeg + rl) * ld + col) * 2;
             plim[i] = col < ld ? rend - rbeg - rl : -(1 << 30);
         }
@@ -2177,7 +2184,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
                 glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)pc * 1024u)));
             }
         };
-        // row weights of the lane's rows in this loader's G pieces of a stage (asm loads: the waits below count them by hand)
+        // row weights of the lane's rows in this loader's G pieces of a stage (asm loads: the waits below count them by hand).
         // Two register sets, alternating by stage parity: a set is overwritten (by loads issued two stages ahead) only after the
         // stage it served has been scaled, and is read only behind the wait that covers its loads -- no copies of in-flight registers.
         float s0[GPL], s1[GPL];
@@ -2186,24 +2193,22 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         auto load_sc = [&](int st, float (&dst)[GPL]) {
 #pragma unroll
             for (int i = 0; i < GPL; ++i) {
-                const int r = min(rbeg + st * WG_SR + 2 * (lw * GPL + i) + (lane >> 5), a.M - 1);
+                const int r = min(rbeg + st * WG_SR + grow_l[i], a.M - 1);
                 const float* pr = a.rowscale + r;
                 asm volatile("global_load_dword %0, %1, off" : "=v"(dst[i]) : "v"(pr) : "memory");
             }
         };
         auto scale_stage = [&](int st, float (&sc)[GPL]) {
-            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));      // (behind the wait: the loads are complete from here on)
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) asm volatile("" : "+v"(sc[i]));      // (behind the wait: the loads are complete from here on)
             if (a.dbg & 8) return;
 #pragma unroll
             for (int i = 0; i < GPL; ++i) {
                 uint4* pz = (uint4*)(smem + (st % WG_NST) * BUF + (XP + lw * GPL + i) * 1024 + lane * 16);
                 const uint4 v = *pz;
-                typedef __attribute__((ext_vector_type(2))) float f32x2;
-                const f32x2 f = {sc[i], sc[i]};
-                // (packed multiplies: the loaders' instruction count is what a stage takes, and they issue no MFMAs beside them)
-                const f32x2 p0 = (f32x2){bflo(v.x), bfhi(v.x)} * f, p1 = (f32x2){bflo(v.y), bfhi(v.y)} * f;
-                const f32x2 p2 = (f32x2){bflo(v.z), bfhi(v.z)} * f, p3 = (f32x2){bflo(v.w), bfhi(v.w)} * f;
-                *pz = make_uint4(pack2(p0[0], p0[1]), pack2(p1[0], p1[1]), pack2(p2[0], p2[1]), pack2(p3[0], p3[1]));
+                const float f = sc[i];
+                *pz = make_uint4(pack2(bflo(v.x) * f, bfhi(v.x) * f), pack2(bflo(v.y) * f, bfhi(v.y) * f),
+                                 pack2(bflo(v.z) * f, bfhi(v.z) * f), pack2(bflo(v.w) * f, bfhi(v.w) * f));
             }
         };
         constexpr int NSC = SC ? GPL : 0;
@@ -2238,7 +2243,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
 
     // ---------------------------------------------------------------------- compute waves
     const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
-    const int ig = wave % IGC, jg = wave / IGC;        // the wave's i-tiles ig*7 .. +6, local j-tiles jg*4 .. +3
+    const int ig = wave % IGC, jg = wave / IGC;        // the wave's i-tiles ig*7 .. +6, local j-tiles jg*BJ .. +BJ-1
     f32x4 acc[AI][BJ], accb[BJ];
 #pragma unroll
     for (int u = 0; u < BJ; ++u) {
@@ -2249,28 +2254,9 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
     const bool do_bias = ig == 0 && !(a.dbg & 4);
-    // XCW: this wave's X pieces are pc = wave and wave + 8 (rows 2pc + (lane >> 5) of a stage): the same 16-byte chunk per lane in
-    // both (2*8 = 0 mod 4 rows apart: same swizzle), so ONE per-lane base pointer + wave-uniform offsets address every piece
-    const int xh = lane >> 5, xsl = lane & 31;
-    const int xcol = (xsl ^ (((2 * wave + xh) & 3) << 2)) * 8;
-    const char* xpb = (const char*)a.X + ((size_t)(rbeg + 2 * wave + xh) * a.ldX + xcol) * 2;
-    const int xlim = xcol < a.ldX ? rend - rbeg - 2 * wave - xh : -(1 << 30);          // piece i of stage st is real iff st*32 + 16*i < xlim
-    auto issue_x = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < XPC; ++i) {
-            const char* src = (st * WG_SR + 16 * i < xlim) ? xpb + ((size_t)st * WG_SR + 16 * i) * (size_t)(a.ldX * 2) : a.zero + xsl * 16;
-            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)(wave + NCW * i) * 1024u)));
-        }
-    };
-    if (XCW) {
-        for (int st = 0; st < min(nstage, WG_NST - 1); ++st) issue_x(st);
-        wait_vmem_but_ws(XPC * max(0, min(nstage, WG_NST - 1) - 1));          // stage 0's pieces have landed (for this wave; the barrier covers the others)
-    }
     __syncthreads();
     for (int c = 0; c < nstage; ++c) {
         const int buf = c % WG_NST;
-        const bool refill = XCW && c + WG_NST - 1 < nstage && !(a.dbg & 1);
-        if (refill) issue_x(c + WG_NST - 1);                 // into the buffer stage c - 1 has left (everyone passed the barrier behind it)
         const char* xb = smem + buf * BUF + xrow_off + p * 16;
         const char* gbase = smem + buf * BUF + XT_BYTES + grow_off;
         uint4 g[BJ];
@@ -2284,7 +2270,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
             g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
         }
         if (!(a.dbg & 2)) {
-            lds_pipeline<AI, XCW ? 2 : 3>(
+            lds_pipeline<AI, 3>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
                     const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
@@ -2302,8 +2288,6 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
 #pragma unroll
             for (int u = 0; u < BJ; ++u) accb[u] = mfma16(ones, g[u], accb[u]);
         }
-        if (XCW && c + 1 < nstage)       // this wave's pieces of stage c + 1 have landed; stages c + 2 (and c + 3, if just issued) may still fly
-            wait_vmem_but_ws(XPC * ((c + 2 < nstage ? 1 : 0) + (refill ? 1 : 0)));
         __syncthreads();
     }
     if (a.dbg & 16) return;
@@ -2327,17 +2311,16 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     }
 }
 
-template <bool SC>
-__global__ __launch_bounds__(768, 3) void wgradws_kernel(WgradPArgs a) {
-    wgradws_body<SC>(a, blockIdx.x, blockIdx.z, gridDim.x, gridDim.z);
+template <bool SC, int BJ, int NLW>
+__global__ __launch_bounds__((8 + NLW) * 64, NLW == 8 ? 4 : 3) void wgradws_kernel(WgradPArgs a) {
+    wgradws_body<SC, BJ, NLW>(a, blockIdx.x, blockIdx.z, gridDim.x, gridDim.z);
 }
-// two (or three) of them in one launch: blockIdx.z runs over the concatenated row splits (the decoder's two hidden layers need the
-// same inputs at the same time -- one launch instead of two queued behind each other on a side stream)
+// two (or three) of them in one launch: blockIdx.z runs over the concatenated row splits
 __global__ __launch_bounds__(768, 3) void wgradws_group_kernel(WgradPGroup g) {
     int l = 0;
     while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
     if ((int)blockIdx.x >= g.gx[l]) return;          // (uniform per workgroup: no barrier is skipped by part of a workgroup)
-    wgradws_body<false>(g.a[l], blockIdx.x, blockIdx.z - g.zbeg[l], g.gx[l], g.zbeg[l + 1] - g.zbeg[l]);
+    wgradws_body<false, 4, 4>(g.a[l], blockIdx.x, blockIdx.z - g.zbeg[l], g.gx[l], g.zbeg[l + 1] - g.zbeg[l]);
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks
@@ -3184,15 +3167,20 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
     for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
     hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, g);
 }
-// shape: 8 = 8 waves / 8 j-tiles per block (small), 16 = 16 waves / 16 j-tiles, 7 = 8 waves / 16 j-tiles with 7 x 4 tiles per wave (IT <= 14)
-int wgradp_strip(int shape) { return shape == 8 ? 8 : 16; }
+// shape: 8 = 8 waves / 8 j-tiles per block (small), 16 = 16 waves / 16 j-tiles; specialised waves (IT <= 14): 7 = 8 + 4 waves / 16 j-tiles,
+// 9 = 8 + 8 waves / 8 j-tiles
+int wgradp_strip(int shape) { return (shape == 8 || shape == 9) ? 8 : 16; }
 void launch_wgradp(const WgradPArgs& a, int nsplit, int shape, hipStream_t st) {
     dim3 grid((a.JT + wgradp_strip(shape) - 1) / wgradp_strip(shape), (a.IT + 15) / 16, nsplit);
     const size_t sc = a.rowscale ? 1024 : 0;
     if (shape == 7) {        // specialised waves: 8 compute + 4 loader (needs IT <= 14, one i-block)
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512);
-        if (a.rowscale) LAUNCH_EV((wgradws_kernel<true>), grid, dim3(768), lds, st, a);
-        else LAUNCH_EV((wgradws_kernel<false>), grid, dim3(768), lds, st, a);
+        if (a.rowscale) LAUNCH_EV((wgradws_kernel<true, 4, 4>), grid, dim3(768), lds, st, a);
+        else LAUNCH_EV((wgradws_kernel<false, 4, 4>), grid, dim3(768), lds, st, a);
+    } else if (shape == 9) { // specialised waves: 8 compute + 8 loader, 128-feature column blocks
+        const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 256);
+        if (a.rowscale) LAUNCH_EV((wgradws_kernel<true, 2, 8>), grid, dim3(1024), lds, st, a);
+        else LAUNCH_EV((wgradws_kernel<false, 2, 8>), grid, dim3(1024), lds, st, a);
     } else if (shape == 16) {
         const size_t lds = WG_NST * (WG_SR * 512 + WG_SR * 512 + sc);
         if (a.rowscale) LAUNCH_EV((wgradp_kernel<16, 2, 8, 2, true>), grid, dim3(1024), lds, st, a);

@@ -216,6 +216,7 @@ struct iwae_model {
     // join_side() does that, and every entry point that touches parameters, gradients or the decoder calls it.
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
+    int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
@@ -526,7 +527,7 @@ int block_fwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* XP, int R,
 int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, WgradPArgs& a, int& nsplit, int& nw) {
     const int chunks = (rows + 63) / 64;
     nw = (L.JT > 8 && chunks >= 128) ? 16 : 8;
-    if (nw == 16 && L.IT <= 14 && m->allow_wg7) nw = 7;
+    if (nw == 16 && L.IT <= 14 && m->allow_wg7) nw = (m->wg_shape9 & (L.JT > 16 ? 1 : 2)) ? 9 : 7;      // IWAE_WG9: bit 0 the output layer, bit 1 the hidden layers
     const int blocks = ((L.JT + wgradp_strip(nw) - 1) / wgradp_strip(nw)) * ((L.IT + 15) / 16);
     // Workgroup targets (measured at k=50, B=1024).  Early builds, the weight gradients alone on the machine: 64 -> 0.501,
     // 128 -> 0.425, 256 -> 0.406, 384 -> 0.443 ms/step (fewer leaves CUs idle, more pays a full fp32 slab per extra split).
@@ -1610,6 +1611,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
+    if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
