@@ -30,19 +30,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    // Each thread fetches ONE quad (4 consecutive elements along the unit-stride index) of the A tile and one of the B tile per
+    // k-step, as a float4 where the host found the operand 16-byte aligned (a.avec / a.bvec), and the NEXT k-step's quads are
+    // requested before this step's MFMAs: the global latency hides under them.
     const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
-    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+    const int a_in = a_kfast ? (tid & 3) * 4 : (tid & 15) * 4;        // k offset (kfast) or m offset (mfast) of the quad
+    const int a_out = a_kfast ? (tid >> 2) : (tid >> 4);               // m (kfast) or k (mfast)
+    const int b_in = b_nfast ? (tid & 15) * 4 : (tid & 3) * 4;         // n offset (nfast) or k offset (kfast)
+    const int b_out = b_nfast ? (tid >> 4) : (tid >> 2);               // k (nfast) or n (kfast)
+    auto fetch_a = [&](int k0) -> float4 {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int gm = m0 + (a_kfast ? a_out : a_in), gk = k0 + (a_kfast ? a_in : a_out);
+        const float* p = a.A + (size_t)gm * a.sam + (size_t)gk * a.sak;
+        const int lim = a_kfast ? k_end - gk : a.M - gm;             // elements of the quad that exist
+        const bool outer_ok = a_kfast ? gm < a.M : gk < k_end;
+        if (outer_ok && lim >= 4 && a.avec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int ka = a_kfast ? (idx & 15) : (idx >> 6), ma = a_kfast ? (idx >> 4) : (idx & 63);
-            const int gm = m0 + ma, gk = k0 + ka;
-            sA[ma][ka] = (gm < a.M && gk < k_end) ? a.A[(size_t)gm * a.sam + (size_t)gk * a.sak] : 0.0f;
-            const int nb = b_nfast ? (idx & 63) : (idx >> 4), kb = b_nfast ? (idx >> 6) : (idx & 15);
-            const int gn = n0 + nb, gk2 = k0 + kb;
-            sB[kb][nb] = (gn < a.N && gk2 < k_end) ? a.B[(size_t)gk2 * a.sbk + (size_t)gn * a.sbn] : 0.0f;
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e];
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto fetch_b = [&](int k0) -> float4 {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int gn = n0 + (b_nfast ? b_in : b_out), gk = k0 + (b_nfast ? b_out : b_in);
+        const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
+        const int lim = b_nfast ? a.N - gn : k_end - gk;
+        const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
+        if (outer_ok && lim >= 4 && a.bvec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e];
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    if (k_beg < k_end) { ra = fetch_a(k_beg); rb = fetch_b(k_beg); }
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+        const float av4[4] = {ra.x, ra.y, ra.z, ra.w}, bv4[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (a_kfast) sA[a_out][a_in + e] = av4[e]; else sA[a_in + e][a_out] = av4[e];
+            if (b_nfast) sB[b_out][b_in + e] = bv4[e]; else sB[b_in + e][b_out] = bv4[e];
         }
         __syncthreads();
+        if (k0 + 16 < k_end) { ra = fetch_a(k0 + 16); rb = fetch_b(k0 + 16); }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             float av[2], bv[2];
@@ -145,7 +177,12 @@ void launch_export_mat(const float* in, int B, int k, int X, float* out, hipStre
     hipLaunchKernelGGL(export_mat_kernel, dim3((unsigned)(((size_t)B * k * X + 255) / 256)), dim3(256), 0, st, in, B, k, X, out);
 }
 
-void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st) {
+void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
+    GemmF32Args a = a0;
+    // float4 fetches where every quad is 16-byte aligned: base pointer, the non-unit stride and the k-chunk offsets
+    const long a_str = a.sak == 1 ? a.sam : a.sak, b_str = a.sbn == 1 ? a.sbk : a.sbn;
+    a.avec = (((uintptr_t)a.A & 15) == 0 && a_str % 4 == 0 && (a.sak == 1 || a.sam == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
+    a.bvec = (((uintptr_t)a.B & 15) == 0 && b_str % 4 == 0 && (a.sbn == 1 || a.sbk == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {

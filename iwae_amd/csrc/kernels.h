@@ -230,6 +230,7 @@ struct GemmF32Args {
     const float* ACT; long ldact;         // GEMM_EPI_DTANH: stored tanh activation of the outputs
     int accumulate;                       // C += instead of C =
     int kchunk; size_t slab_stride;       // K split over blockIdx.z: split z covers kchunk k's and writes C + z*slab_stride
+    int avec, bvec;                       // set by launch_gemm_f32: the operand's quads may be fetched as float4
 };
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
