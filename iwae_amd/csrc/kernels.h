@@ -27,6 +27,9 @@ struct EpsSrc {
     uint64_t row_offset = 0;   // global index of this rank's first data row (batch_offset * k)
     uint32_t step = 0;
     uint32_t stream = 0;       // 0: first latent layer, 1: second
+    // k-chunked calls (iwae_eval_llh at large k): this call holds samples [s_off, s_off + kc) of k_total per image; the Philox row
+    // index is that of the unchunked call, (image)*k_total + sample, so chunking does not change the draws.  k_total = 0: off.
+    int k_total = 0, s_off = 0, kc = 0;
     const StepDyn* dyn = nullptr;   // graph replay: step / batch offset are read from this device block instead (eps_gen_kernel)
     int dyn_k = 0;             // samples per image (row_offset = dyn->batch_offset * dyn_k)
 };

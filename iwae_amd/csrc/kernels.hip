@@ -141,7 +141,8 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 #pragma unroll
         for (int i = 0; i < 4; ++i) n[i] = (4 * d4 + i < D) ? p[i] : 0.0f;
     } else {
-        normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
+        const uint64_t grow = e.k_total ? e.row_offset + (uint64_t)b * (uint64_t)e.k_total + (uint64_t)(e.s_off + s) : e.row_offset + (uint64_t)row;
+        normal4(grow, (uint32_t)d4, e.stream, e.step, e.seed, n);
     }
 }
 
@@ -2412,7 +2413,9 @@ __global__ __launch_bounds__(256) void eps_gen_kernel(EpsSrc e, int M, int nd4, 
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int row = (int)(idx / nd4), d4 = (int)(idx - (size_t)row * nd4);
         float n[4];
-        normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step, e.seed, n);
+        uint64_t grow = e.row_offset + (uint64_t)row;
+        if (e.k_total) { const int b = row / e.kc; grow = e.row_offset + (uint64_t)b * (uint64_t)e.k_total + (uint64_t)(e.s_off + row - b * e.kc); }
+        normal4(grow, (uint32_t)d4, e.stream, e.step, e.seed, n);
         *(float4*)(out + (size_t)row * ld + 4 * d4) = make_float4(n[0], n[1], n[2], n[3]);
     }
 }

@@ -131,6 +131,9 @@ struct iwae_model {
     // float32 mode (iwae_config.precision / iwae_set_eval_precision): row-major float32 activations, GEMMs on v_mfma_f32_16x16x4_f32
     struct F32Block { DevBuf h1, h2, dhead, d2, d1, dx; };
     struct F32State { F32Block enc1, enc2, dec2; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart; } f32;
+    int eval_tag_kill = -1;
+    int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
+    int eval_rows = 1 << 19;                  // data rows per evaluator launch (IWAE_EVAL_ROWS): images x samples, k chunked beyond it
     int eval_precision = IWAE_PREC_FP32;      // arithmetic of iwae_eval_llh (iwae_set_eval_precision)
     bool fwd_was_f32 = false;                 // the last forward ran in float32 mode (its backward must too)
     const float* f32_x = nullptr;             // device x [B][X] of the last float32 forward
@@ -440,6 +443,10 @@ EpsSrc eps_src(iwae_model* m, int layer) {
     e.step = m->noise_step;
     e.stream = (uint32_t)layer;
     if (m->serial) { e.dyn = m->d_dyn; e.dyn_k = m->k; }
+    if (m->eval_k_total > 0) {      // k-chunked evaluation: the unchunked call's Philox rows
+        e.k_total = m->eval_k_total; e.s_off = m->eval_s_off; e.kc = m->k;
+        e.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->eval_k_total;
+    }
     return e;
 }
 
@@ -678,11 +685,13 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                 for (int l = 0; l < m->cfg.n_layers; ++l) CHK(ensure(m->epsc[p3][l], (size_t)Mp * m->Dp[l] * 4, st));
             CHK(draw_eps(m, np, m->noise_step, M, st));
             m->eps_tag[np].valid = false;
-        } else if (!(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
+        } else if (m->eval_k_total > 0 || !(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
             CHK(join_side(m));          // a speculative draw into this slot may still be on the side stream
             if (m->side) HIPCHK(hipStreamSynchronize(m->side));
             CHK(draw_eps(m, np, m->noise_step, M, st));
+            if (m->eval_k_total > 0) m->eval_tag_kill = np;      // (a k-chunk's draws: the tag does not describe them)
         }
+        if (m->eval_tag_kill >= 0) { m->eps_tag[m->eval_tag_kill].valid = false; m->eval_tag_kill = -1; }
         m->epsc_par = np;
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     }
@@ -1612,6 +1621,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);
+    if (const char* e = getenv("IWAE_EVAL_ROWS")) m->eval_rows = std::max(64, atoi(e));
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
@@ -2026,28 +2036,48 @@ int iwae_set_step(iwae_handle m, uint32_t noise_step, uint32_t batch_offset) {
 int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* per_image) {
     if (!m || !x || N <= 0 || k <= 0 || !llh) return fail(IWAE_ERR_ARG, "eval_llh: bad argument");
     HIPCHK(hipSetDevice(m->cfg.device));
-    if (chunk <= 0) chunk = std::max(1, (int)(((int64_t)1 << 19) / k));
+    // Launches of at most eval_rows data rows: `chunk` images x kc samples.  k <= eval_rows: whole images (kc = k).  Larger k: the
+    // samples of an image are walked in chunks of kc and the per-chunk log-mean-exps are merged with a running log-sum-exp
+    // (src/utils.py:6-8 is associative in that form) -- the activations of ALL k samples never exist at once.
+    const int kc = std::min(k, m->eval_rows);
+    if (chunk <= 0) chunk = std::max(1, m->eval_rows / kc);
     chunk = std::min(chunk, N);
     std::vector<float> lme(chunk);
+    std::vector<double> run(chunk);
     double total = 0.0;
     const uint32_t saved_off = m->batch_offset;
-    for (int i0 = 0; i0 < N; i0 += chunk) {
+    int rc = IWAE_OK;
+    for (int i0 = 0; i0 < N && rc == IWAE_OK; i0 += chunk) {
         const int nb = std::min(chunk, N - i0);
         m->batch_offset = saved_off + (uint32_t)i0;
         m->cond_row0 = i0;
-        const bool f32 = m->eval_precision == IWAE_PREC_FP32 && m->C == 0;      // (the conditional models evaluate on the bf16 path)
-        const int rc_fwd = f32 ? forward_f32(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
-                               : forward_impl(m, x + (size_t)i0 * m->X, nb, k, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
+        for (int s0 = 0; s0 < k && rc == IWAE_OK; s0 += kc) {
+            const int kn = std::min(kc, k - s0);
+            m->eval_k_total = (kc < k) ? k : 0;
+            m->eval_s_off = s0;
+            const bool f32 = m->eval_precision == IWAE_PREC_FP32 && m->C == 0;      // (the conditional models evaluate on the bf16 path)
+            rc = f32 ? forward_f32(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
+                     : forward_impl(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
+            m->eval_k_total = 0; m->eval_s_off = 0;
+            if (rc != IWAE_OK) break;
+            if (hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+                hipStreamSynchronize(m->stream) != hipSuccess) { rc = fail(IWAE_ERR_HIP, "eval_llh: copying the per-image estimates failed"); break; }
+            for (int i = 0; i < nb; ++i) {
+                const double part = (double)lme[i] + log((double)kn);       // log sum_s exp(log_w) over this chunk
+                if (s0 == 0) run[i] = part;
+                else { const double hi = std::max(run[i], part), lo = std::min(run[i], part); run[i] = hi + log1p(exp(lo - hi)); }
+            }
+        }
         m->cond_row0 = 0;
-        if (rc_fwd != IWAE_OK) { m->batch_offset = saved_off; return rc_fwd; }
-        HIPCHK(hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
+        if (rc != IWAE_OK) break;
         for (int i = 0; i < nb; ++i) {
-            total += (double)lme[i];       // MyMetric: sum / count (src/utils.py:39-41)
-            if (per_image) per_image[i0 + i] = lme[i];
+            const double v = run[i] - log((double)k);
+            total += v;                    // MyMetric: sum / count (src/utils.py:39-41)
+            if (per_image) per_image[i0 + i] = (float)v;
         }
     }
     m->batch_offset = saved_off;
+    if (rc != IWAE_OK) return rc;
     m->noise_step += 1;
     *llh = total / (double)N;
     return IWAE_OK;

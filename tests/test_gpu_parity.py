@@ -698,6 +698,33 @@ def test_eval_llh_chunking_and_definition(big):
     m.set_eval_precision("fp32")
 
 
+@pytest.mark.parametrize("layers", [1, 2])
+def test_eval_llh_k_chunking_is_invisible(gpu, monkeypatch, layers):
+    """iwae_eval_llh walks an image's k samples in chunks when k exceeds the rows-per-launch cap (IWAE_EVAL_ROWS) and merges the
+    chunks' log-mean-exps with a running log-sum-exp (src/utils.py:6-8 in associative form); the Philox rows are those of the
+    unchunked call, so the per-image estimates must not move -- k = 1500 in chunks of 256 (5 full + 1 ragged) against one launch,
+    both arithmetics, 1- and 2-layer model."""
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    P = O.init_params(layers, nh, nl, 77, x_mean=O.synthetic_pixel_means())
+    x = O.synthetic_binarized(6, 5)
+    outs = {}
+    for rows in (0, 256):
+        if rows:
+            monkeypatch.setenv("IWAE_EVAL_ROWS", str(rows))
+        m = _model(layers, nh, nl)
+        monkeypatch.delenv("IWAE_EVAL_ROWS", raising=False)
+        m.set_params(O.flatten_params(P))
+        for prec in ("fp32", "bf16"):
+            m.set_eval_precision(prec)
+            m.set_step(31, 4)
+            outs[(rows, prec)] = m.eval_llh(x, k=1500, per_image=True)
+        m.close()
+    for prec in ("fp32", "bf16"):
+        (a, pa), (b, pb) = outs[(0, prec)], outs[(256, prec)]
+        np.testing.assert_allclose(pa, pb, atol=2e-3)
+        assert abs(a - b) < 1e-3
+
+
 # ---------------------------------------------------------------- float32 mode (iwae_config.precision = IWAE_PREC_FP32)
 # SURVEY.md 8(c): "fp32 kernels rel 1e-5 on scalars / 1e-4 on grads vs fp64 oracle".  The reference computes in float32
 # (Keras Dense defaults, src/iwae1.py:31-34,72-75); every GEMM of this mode is an exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
