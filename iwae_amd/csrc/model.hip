@@ -160,6 +160,10 @@ struct iwae_model {
     DevBuf xin, xP, epsbuf, zP[2];
     DevBuf rows[6];            // lpxz, t1, t2, t3, t4, lq_dreg   (per data row)
     DevBuf logw, wn, gx, cf, per_b, dzdir;
+    // lse_kernel's outputs once more, written by the copy of it that runs on the side stream (see forward_impl): the output layer's
+    // weight gradient takes its row weights from there
+    DevBuf logw2, wn2, gx2, cf2, per_b2;
+    bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
     MlpWs wdec1;
     DevBuf scratch;            // exports
@@ -741,11 +745,6 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
-    // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the
-    // side stream, which is idle until the backward pass forks -- behind the weight gradients it sat on the step's critical
-    // tail (the side stream's chain decides when the next decoder forward may start).  Third ring slot: the previous step's
-    // draws may still be read by its backward pass, this step's are in use.
-    if (bwd && keep_eps && m->side && !m->serial) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
     bool fuse_z = false;
     SampleArgs zin;
     memset(&zin, 0, sizeof(zin));
@@ -860,8 +859,18 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
-            { ScopedTimer tm(m, T_DEC_FWD); launch_dense(EPI_BERN, a, st); }
+            // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights -- not out_bwd -- so the
+            // side stream forks early.  Round 2: it forks behind THIS kernel (event on its dispatch packet) and runs its own copy of
+            // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
+            // a cross-stream hand-off takes now pass beside the main stream's lse_kernel, not behind it.
+            m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two && !m->serial;
+            m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1;
+            { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
+            if (m->lse_dup && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
         HIPCHK(hipGetLastError());
+        // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
+        // stream, idle until the backward pass forks -- enqueued behind the decoder kernel so that its dispatch does not delay that one
+        if (bwd && keep_eps && m->side && !m->serial) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
 
@@ -902,9 +911,24 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights lse_kernel leaves -- not
         // out_bwd -- so the side stream forks here (ev_lse on this kernel's dispatch packet), one kernel earlier, and the
         // gradient runs beside out_bwd (both read s)
-        m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two && !m->serial;
-        if (m->early_wout) set_launch_stop_event(m->ev_lse);
+        if (m->early_wout && !m->lse_dup) set_launch_stop_event(m->ev_lse);
         launch_lse(a, st);
+        if (m->lse_dup) {       // the side stream's copy: same inputs, its own outputs
+            CHK(ensure(m->logw2, (size_t)Mp * 4, st));
+            CHK(ensure(m->wn2, (size_t)Mp * 4, st));
+            {
+                const void* before = m->gx2.p;
+                CHK(ensure(m->gx2, (size_t)Mp * 4, st));
+                if (m->gx2.p != before) { HIPCHK(hipMemsetAsync(m->gx2.p, 0, m->gx2.cap, st)); HIPCHK(hipStreamSynchronize(st)); }
+            }
+            CHK(ensure(m->cf2, (size_t)Mp * 16, st));
+            CHK(ensure(m->per_b2, (size_t)PB_COUNT * B * 4, st));
+            LseArgs a2 = a;
+            a2.logw = ptr<float>(m->logw2); a2.wn = ptr<float>(m->wn2); a2.gx = ptr<float>(m->gx2);
+            a2.cf = ptr<float4>(m->cf2); a2.per_b = ptr<float>(m->per_b2);
+            HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
+            launch_lse(a2, m->side);
+        }
         // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
         if (!bwd) launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
     }
@@ -979,12 +1003,13 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     hipStream_t sd = m->serial ? st : m->side;       // serial form (graph capture): everything on the main stream, no events
     if (m->serial) {}
+    else if (m->early_wout && m->lse_dup) {}                                              // forked behind the decoder kernel already (forward_impl)
     else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
         ScopedTimer tm(m, T_WGRAD_OUT, sd);
         if (m->early_wout && m->use_side2) set_launch_stop_event(m->ev_s2);
-        CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->gx) : nullptr));
+        CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->lse_dup ? m->gx2 : m->gx) : nullptr));
     }
     if (!fused_dx) {
         { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
@@ -1618,6 +1643,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
+    m->allow_lse_dup = getenv("IWAE_NO_LSE_DUP") == nullptr;
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);
@@ -1723,7 +1749,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->comm_side && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm_side);
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
-                      &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b,
+                      &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->logw2, &m->wn2, &m->gx2, &m->cf2, &m->per_b2,
                       &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2, &m->wprior};

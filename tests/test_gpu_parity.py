@@ -223,7 +223,10 @@ def test_kernel_variants_agree(gpu, monkeypatch):
     """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
     instead of reading the stored s, the 4-wave x 32-row dense shape instead of 8 x 16, the separate sampling kernel
     instead of the first decoder layer making z itself, the Bernoulli forward on dense_kernel<EPI_BERN> instead of the
-    software-pipelined bern_pipe_kernel, and the decoder's tanh layers / the encoder block as separate launches instead of fused ones."""
+    software-pipelined bern_pipe_kernel, the decoder's tanh layers / the encoder block as separate launches instead of fused ones;
+    round 2: the decoder's dX chain as three launches instead of dec_bwd_kernel, the general weight-gradient kernel instead of the
+    specialised-wave one and that one's 8 + 8-wave shape, one side stream instead of two, the grouped launch of the hidden layers'
+    gradients, one lse_kernel instead of the side stream's own copy."""
     B, k = 170, 50
     x = O.synthetic_binarized(B, 3)
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
@@ -243,7 +246,8 @@ def test_kernel_variants_agree(gpu, monkeypatch):
 
     e0, g0 = run({})
     for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
-                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"}):
+                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"},
+                {"IWAE_NO_DEC_BWD": "1"}, {"IWAE_NO_WG7": "1"}, {"IWAE_WG9": "3"}, {"IWAE_NO_SIDE2": "1"}, {"IWAE_WG_GROUP": "1"}, {"IWAE_NO_LSE_DUP": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
