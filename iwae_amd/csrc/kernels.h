@@ -97,7 +97,8 @@ struct DecBwdArgs {                  // dec_bwd_kernel: out_bwd_s + dX of the tw
     const uint16_t* G1;               // stored first-layer activation, P-layout [M][32*KT]
     uint16_t* D1P;                    // dpre1 out, P-layout [M][32*KT]
     const char* imgB1; int MG1;       // backward image of the first decoder layer (out = latent groups, k = hidden)
-    float* DZ; int ldDZ;              // dz fp32 [M][ldDZ]
+    float* DZ; int ldDZ;              // dz fp32 [M][ldDZ] (or null)
+    uint16_t* DZH;                    // dz as bf16 [M][ldDZ], natural feature order (1-layer model: latent_bwd_kernel is its only reader), or null
 };
 
 struct WgradPArgs {
@@ -150,6 +151,7 @@ struct LseArgs {
 
 struct LatentBwdArgs {
     const float* dz; int ldDZ;
+    const uint16_t* dzh;              // dz as bf16 [rows][ldDZ] instead of `dz` (dec_bwd_kernel's output), or null
     const float* dz2; const float* dz3;   // optional further terms of dz (same layout), added on load; both or neither
     const float* head; int ldH; int D, Dp;
     const float4* cf;

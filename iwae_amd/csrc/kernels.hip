@@ -1845,8 +1845,10 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
             const int f0 = 64 * mg + 16 * t + 4 * q;
             if (64 * mg + 16 * t < d.ldDZ) {       // wave-uniform
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    if (valid[g]) *(float4*)(d.DZ + (size_t)row[g] * d.ldDZ + f0) = make_float4(acc[t][g][0], acc[t][g][1], acc[t][g][2], acc[t][g][3]);
+                for (int g = 0; g < 2; ++g) {
+                    if (valid[g] && d.DZH) *(uint2*)(d.DZH + (size_t)row[g] * d.ldDZ + f0) = make_uint2(pack2(acc[t][g][0], acc[t][g][1]), pack2(acc[t][g][2], acc[t][g][3]));
+                    else if (valid[g]) *(float4*)(d.DZ + (size_t)row[g] * d.ldDZ + f0) = make_float4(acc[t][g][0], acc[t][g][1], acc[t][g][2], acc[t][g][3]);
+                }
             }
         }
     }
@@ -2711,7 +2713,8 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                 const bool ok = s < a.k;
                 const int sc = ok ? s : a.k - 1;          // clamped, weighted by 0 below
                 const int row = b * a.k + sc;
-                dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
+                if (a.dzh) { const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0); dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y)); }
+                else dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
                 if (a.dz2) {      // 2-layer model: dz1 = decoder path + direct p(z1|z2) term + path through q(z2|z1)
                     const float4 t2 = *(const float4*)(a.dz2 + (size_t)row * a.ldDZ + f0), t3 = *(const float4*)(a.dz3 + (size_t)row * a.ldDZ + f0);
                     dz[u] = make_float4(dz[u].x + t2.x + t3.x, dz[u].y + t2.y + t3.y, dz[u].z + t2.z + t3.z, dz[u].w + t2.w + t3.w);

@@ -226,6 +226,7 @@ struct iwae_model {
     int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
+    bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
@@ -958,7 +959,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     CHK(ensure(w.d2P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.dz, (size_t)Mp * m->Dp[0] * 4, st));
-    bool fused_dx = false;
+    bool fused_dx = false, dz_half = false;
     {
         Linear& L = m->dec1[2];
         OutBwdArgs a;
@@ -989,6 +990,10 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 d.o = a;
                 d.imgB2 = m->dec1[1].imgB; d.G1 = ptr<uint16_t>(w.g1P); d.D1P = ptr<uint16_t>(w.d1P);
                 d.imgB1 = m->dec1[0].imgB; d.MG1 = m->dec1[0].MG_B; d.DZ = ptr<float>(w.dz); d.ldDZ = m->dec1[0].Kp32;
+                // 1-layer model: dz has one reader (latent_bwd_kernel): bf16 halves its 26 MB each way (the 2-layer model adds two more
+                // float32 terms to it there and keeps float32)
+                dz_half = !two && m->allow_dz_half;
+                if (dz_half) d.DZH = (uint16_t*)w.dz.p;
                 ScopedTimer tm(m, T_DEC_BWD);
                 if (!m->serial) set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
                 launch_dec_bwd(d, st);
@@ -1088,6 +1093,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         LatentBwdArgs a;
         memset(&a, 0, sizeof(a));
         a.dz = dz1; a.dz2 = dz1_b; a.dz3 = dz1_c; a.ldDZ = m->Dp[0];
+        if (dz_half) a.dzh = (const uint16_t*)w.dz.p;
         a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
         a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
         a.B = B; a.Bp = Bp; a.k = k;
@@ -1644,6 +1650,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
     m->allow_lse_dup = getenv("IWAE_NO_LSE_DUP") == nullptr;
+    m->allow_dz_half = getenv("IWAE_DZ_F32") == nullptr;
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);
