@@ -81,15 +81,18 @@ def kernel_models(cfg):
         "out_bwd": dict(name="out_bwd_s_kernel<7> (output-layer backward from the stored s: dg2 = s W^T, dpre2)",
                         bytes=M * (2 * X + 2 * H + 4 + 2 * H), flop=2 * M * H * X, match="out_bwd_s_kernel"),
         "decoder_bwd": dict(name="dec_bwd_kernel<7> (decoder dX chain in one launch: dg2 = s W3^T -> dpre2 -> dpre1 -> dz; s, g2, g1 in, dpre2, dpre1, dz out)",
-                            bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + 4 * D), flop=2 * M * (H * X + H * H + H * D), match="dec_bwd_kernel"),
-        "wgrad_out": dict(name="wgradp_kernel<16,true> (output-layer weight gradient dV3 = g2^T (g_r s), side stream)" if big else
-                               "wgradp_kernel<8,true> (output-layer weight gradient, side stream)",
-                          bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradp_kernel<16, true" if big else "wgradp_kernel<8, true"),
+                            bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + (2 if cfg["layers"] == 1 else 4) * D), flop=2 * M * (H * X + H * H + H * D), match="dec_bwd_kernel"),
+        "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, side stream)" if big else
+                               "wgradp_kernel<8,4,4,4,true> (output-layer weight gradient, side stream)",
+                          bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true"),
         "dx_hidden": dict(name="dense_kernel<EPI_DX,7> (dpre1 = (dpre2 V2^T) * (1 - g1^2))", bytes=M * 6 * H, flop=2 * M * H * H, match="dense_kernel<2, 7"),
         "dx_latent": dict(name="dense_kernel<EPI_F32,7> (dz = dpre1 V1^T, fp32)", bytes=M * (2 * H + 4 * D), flop=2 * M * H * D, match="dense_kernel<3, 7"),
-        "wgrad_hidden": dict(name="wgradp_kernel<*,false> (dV2 = g1^T dpre2, side stream)", bytes=M * 4 * H + 4 * (H * H + H), flop=2 * M * H * H, match="wgradp_kernel"),
-        "wgrad_latent": dict(name="wgradp_kernel<*,false> (dV1 = z^T dpre1, side stream)", bytes=M * (2 * D + 2 * H) + 4 * (D * H + H), flop=2 * M * D * H, match="wgradp_kernel"),
-        "latent_bwd": dict(name="latent_bwd_kernel (d mu, d sigma per image: sum over the k samples)", bytes=M * (4 * D + 4 * D + 16), flop=0, match="latent_bwd_kernel"),
+        "wgrad_hidden": dict(name=("wgradws_kernel<false,4,4>" if big else "wgradp_kernel<8,4,4,4,false>") + " (dV2 = g1^T dpre2, second side stream)",
+                             bytes=M * 4 * H + 4 * (H * H + H), flop=2 * M * H * H, match="wgradws_kernel<false" if big else "wgradp_kernel<8, 4, 4, 4, false"),
+        "wgrad_latent": dict(name=("wgradws_kernel<false,4,4>" if big else "wgradp_kernel<8,4,4,4,false>") + " (dV1 = z^T dpre1, second side stream)",
+                             bytes=M * (2 * D + 2 * H) + 4 * (D * H + H), flop=2 * M * D * H, match="wgradws_kernel<false" if big else "wgradp_kernel<8, 4, 4, 4, false"),
+        "latent_bwd": dict(name="latent_bwd_kernel (d mu, d sigma per image: sum over the k samples)",
+                           bytes=M * ((2 if (big and cfg["layers"] == 1) else 4) * D + 4 * D + 16), flop=0, match="latent_bwd_kernel"),
         "encoder_fwd": dict(name="block_fwd_kernel (encoder BasicBlock on the B images, one launch)",
                             bytes=cfg["B"] * (4 * X + 4 * H + 8 * D) + 2 * (X * H + H * H + 2 * H * D), flop=2 * cfg["B"] * (X * H + H * H + 2 * H * D), match="block_fwd_kernel"),
         "reduce_adam": dict(name="reduce_grads_kernel (main-stream slab reduction + fused Adam + weight-image refresh)", bytes=0, flop=0, match="reduce_grads_kernel"),
@@ -316,6 +319,11 @@ def run():
                          "algorithmic_bytes": int(comp_b + act_b), "algorithmic_hbm_frac": round((comp_b + act_b) / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                          "measured_hbm_bytes": step_hbm, "measured_hbm_frac": round(step_hbm / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if step_hbm else None},
             }
+        if not dom:      # float32 mode (one generic GEMM kernel, no per-kernel events): the step as a whole against the f32 MFMA peak
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (every product of the step: v_mfma_f32_16x16x4_f32), whole step", "timed_as": "step",
+                               "stream": "main", "achieved": round(flop_step / (ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                               "frac": round(flop_step / (ms * 1e-3) / (peak_tf * 1e12), 4), "traffic": None, "traffic_source": None,
+                               "avg_launch_us": round(ms * 1e3, 2), "launches": args.steps, "flop_per_launch": flop_step}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         return out, dist
