@@ -226,6 +226,8 @@ struct iwae_model {
     int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
+    bool small_dec_bwd = true; int small_rows = 8191;   // the one-launch dX chain also below 8 192 rows (IWAE_NO_SMALL_DEC_BWD=1: the per-pixel-group out_bwd + finish + two dX launches
+                                                        // there).  Measured: B=20,k=1 0.1417 -> 0.1383 ms/step, B=100,k=5 150.7 -> 144.6 us, B=160,k=50 189.1 -> 165.7 us
     bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
@@ -970,7 +972,8 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DPP = ptr<uint16_t>(w.d2P);
         if (m->s_mode) a.SP = ptr<uint16_t>(w.dlP);     // dlP holds s: one product, no recompute
-        if (m->s_mode && M < 8192 && L.MG > 1) {         // small row counts: one pixel group per block, partial sums + finish kernel
+        const bool small_fused = m->small_dec_bwd && m->allow_dec_bwd && m->s_mode && M <= m->small_rows && out_bwd_has_s_mode(L.KT) && !m->want_stamps;      // dec_bwd_kernel at small row counts too
+        if (m->s_mode && M < 8192 && L.MG > 1 && !small_fused) {         // small row counts: one pixel group per block, partial sums + finish kernel
             a.gpb = 1;
             CHK(ensure(m->dg2_part, (size_t)L.MG * M * L.Kp32 * 4, st));
             a.part = ptr<float>(m->dg2_part);
@@ -982,7 +985,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         }
             // One launch for out_bwd + dX of d2 + dX of d1 (dec_bwd_kernel) where it exists: large row counts, s kept by the forward
             // pass, hidden width with an instantiation; dpre2 / dpre1 stay in registers from product to product.
-            fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && M >= 8192 && !a.stamps && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
+            fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && (M >= 8192 || small_fused) && !a.stamps && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
                        m->dec1[0].KT_B == L.KT && m->dec1[1].Kp32 == L.Kp32 && m->dec1[0].Np32 == L.Kp32;
             if (fused_dx) {
                 DecBwdArgs d;
@@ -1651,6 +1654,8 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
     m->allow_lse_dup = getenv("IWAE_NO_LSE_DUP") == nullptr;
     m->allow_dz_half = getenv("IWAE_DZ_F32") == nullptr;
+    m->small_dec_bwd = getenv("IWAE_NO_SMALL_DEC_BWD") == nullptr;
+    if (const char* e = getenv("IWAE_SMALL_ROWS")) m->small_rows = atoi(e);
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);

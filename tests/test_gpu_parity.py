@@ -247,7 +247,7 @@ def test_kernel_variants_agree(gpu, monkeypatch):
     e0, g0 = run({})
     for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
                 {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"},
-                {"IWAE_NO_DEC_BWD": "1"}, {"IWAE_NO_WG7": "1"}, {"IWAE_WG9": "3"}, {"IWAE_NO_SIDE2": "1"}, {"IWAE_WG_GROUP": "1"}, {"IWAE_NO_LSE_DUP": "1"}, {"IWAE_DZ_F32": "1"}):
+                {"IWAE_NO_DEC_BWD": "1"}, {"IWAE_NO_WG7": "1"}, {"IWAE_WG9": "3"}, {"IWAE_NO_SIDE2": "1"}, {"IWAE_WG_GROUP": "1"}, {"IWAE_NO_LSE_DUP": "1"}, {"IWAE_DZ_F32": "1"}, {"IWAE_NO_SMALL_DEC_BWD": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
