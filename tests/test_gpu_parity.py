@@ -219,15 +219,15 @@ def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
     m.close()
 
 
-def test_kernel_variants_agree(gpu, monkeypatch):
+@pytest.mark.parametrize("B,k", [(170, 50), (24, 5)])
+def test_kernel_variants_agree(gpu, monkeypatch, B, k):
     """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
     instead of reading the stored s, the 4-wave x 32-row dense shape instead of 8 x 16, the separate sampling kernel
     instead of the first decoder layer making z itself, the Bernoulli forward on dense_kernel<EPI_BERN> instead of the
     software-pipelined bern_pipe_kernel, the decoder's tanh layers / the encoder block as separate launches instead of fused ones;
     round 2: the decoder's dX chain as three launches instead of dec_bwd_kernel, the general weight-gradient kernel instead of the
     specialised-wave one and that one's 8 + 8-wave shape, one side stream instead of two, the grouped launch of the hidden layers'
-    gradients, one lse_kernel instead of the side stream's own copy."""
-    B, k = 170, 50
+    gradients, one lse_kernel instead of the side stream's own copy; the per-pixel-group dX kernels at small row counts."""
     x = O.synthetic_binarized(B, 3)
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
 
