@@ -858,8 +858,22 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             }
         }
         if (!fuse_dec) {
-            CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
-            CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
+            // few rows: the two tanh layers as ONE launch of block_fwd_kernel (a BasicBlock without its head: 16-row workgroups,
+            // weights straight from the L2-resident images) instead of two latency-bound dense_kernel launches
+            bool two_in_one = false;
+            if (m->allow_block_fused && !fuse_z && M <= 4096 && m->dec1[1].Np32 == m->dec1[0].Np32 && m->dec1[1].Kp32 == m->dec1[0].Np32) {
+                BlockFwdArgs bf;
+                memset(&bf, 0, sizeof(bf));
+                bf.X = ptr<uint16_t>(m->zP[0]); bf.ldX = m->dec1[0].Kp32; bf.img0 = m->dec1[0].imgF; bf.img1 = m->dec1[1].imgF; bf.img2 = m->dec1[1].imgF;
+                bf.KT0 = m->dec1[0].KT; bf.KT1 = m->dec1[1].KT; bf.NT1 = m->dec1[0].Np32 / 16; bf.NT2 = 0; bf.R = M;
+                bf.H1 = ptr<uint16_t>(w.g1P); bf.H2 = ptr<uint16_t>(w.g2P); bf.ldH = m->dec1[0].Np32;
+                bf.YF = nullptr; bf.ldYF = 0; bf.split = 1 << 30;
+                if (block_fwd_ok(bf)) { launch_block_fwd(bf, st); two_in_one = true; }
+            }
+            if (!two_in_one) {
+                CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
+                CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
+            }
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
             // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights -- not out_bwd -- so the
