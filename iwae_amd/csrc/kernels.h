@@ -73,6 +73,16 @@ struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <
     uint16_t *H1, *H2; int ldH;       // hidden activations, P-layout [R][32*KT1]
     float* YF; int ldYF; int split;   // head, fp32 [R][ldYF]; out-features >= split are the sigma head
 };
+struct BlockBwdArgs {                 // block_bwd_kernel: the dX chain of a BasicBlock on R <= 4096 rows
+    const uint16_t* DH; int ldDH;     // dhead, bf16 P-layout [R][32*KTH]
+    const char *imgH, *imgL2;         // backward images (MG-major: out-feature groups over hidden) of the head (KTH k-steps) and of l2 (KT1)
+    int KTH, KT1, NT1;                // NT1 = hidden tiles = 2*KT1
+    int R;
+    const uint16_t *H2, *H1; int ldH; // stored tanh activations, P-layout [R][32*KT1]
+    uint16_t *D2, *D1;                // outputs: dpre of l2 and of l1, P-layout [R][32*KT1]
+};
+bool block_bwd_ok(const BlockBwdArgs& a);
+void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
 bool block_fwd_ok(const BlockFwdArgs& a);
 void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st);
 

@@ -692,6 +692,69 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// block_bwd_kernel: the dX chain of a BasicBlock on few rows (the encoder's backward pass on the B images) in ONE launch, the
+// mirror image of block_fwd_kernel: d2 = (dhead Whead^T) * (1 - h2^2), d1 = (d2 W2^T) * (1 - h1^2).  A 16-wave workgroup owns 16
+// rows, wave w owns hidden tile w of both products, the backward images' fragments come straight from L2 into registers (the
+// second layer's are requested before the first product starts), the data operands sit in LDS as 1 KiB k-step blocks.
+// As two dense_kernel<EPI_DX> launches this was 6.5 + 6.4 us alone and 20 - 35 us beside the weight gradients.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int row = r0 + rho;
+    const bool valid = row < a.R;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    char* act0 = smem;                                   // dhead tile: KTH blocks
+    char* act1 = smem + (size_t)a.KTH * 1024;            // d2 tile: KT1 blocks
+    for (int c = threadIdx.x; c < a.KTH * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
+        const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < a.R) v = *(const uint4*)(a.DH + (size_t)(r0 + rr) * a.ldDH + ks * 32 + qq * 8);
+        *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
+    }
+    const int mg = wave >> 2, tg = wave & 3;
+    const bool has = wave < a.NT1;
+    const char* wh = a.imgH + (size_t)mg * img_mg_group_bytes(a.KTH) + tg * 1024 + a_off;
+    const char* w2 = a.imgL2 + (size_t)mg * img_mg_group_bytes(a.KT1) + tg * 1024 + a_off;
+    uint4 AH[BLOCKFWD_MAX_KT], A2[BLOCKFWD_MAX_KT];
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        AH[ks] = make_uint4(0, 0, 0, 0); A2[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KTH && has) AH[ks] = *(const uint4*)(wh + (size_t)ks * 4096);
+        if (ks < a.KT1 && has) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
+    }
+    // the lane's 4 activations of hidden tile `wave` (k-step wave >> 1, half wave & 1 of the P-layout row)
+    const int kso = wave >> 1, hh = wave & 1;
+    uint2 y2 = make_uint2(0, 0), y1 = make_uint2(0, 0);
+    if (valid && has) {
+        y2 = *(const uint2*)(a.H2 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+        y1 = *(const uint2*)(a.H1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+    }
+    auto dtanh = [&](const f32x4& acc, const uint2& y) {
+        const float ya = bflo(y.x), yb = bfhi(y.x), yc = bflo(y.y), yd = bfhi(y.y);
+        return make_uint2(pack2(acc[0] * (1.0f - ya * ya), acc[1] * (1.0f - yb * yb)), pack2(acc[2] * (1.0f - yc * yc), acc[3] * (1.0f - yd * yd)));
+    };
+    __syncthreads();
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KTH) acc = mfma16(AH[ks], *(const uint4*)(act0 + ks * 1024 + a_off), acc);
+    if (has) {
+        const uint2 v = valid ? dtanh(acc, y2) : make_uint2(0, 0);
+        *(uint2*)(act1 + kso * 1024 + a_off + 8 * hh) = v;
+        if (valid) *(uint2*)(a.D2 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
+    }
+    __syncthreads();
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT1) acc = mfma16(A2[ks], *(const uint4*)(act1 + ks * 1024 + a_off), acc);
+    if (has && valid) *(uint2*)(a.D1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = dtanh(acc, y1);
+}
+
+// ---------------------------------------------------------------------------------
 // bern_pipe_kernel: the Bernoulli forward (decoder output layer + log p(x|z), iwae1.py:74-75,83,111) at large row counts,
 // software-pipelined INSIDE each wave.  dense_kernel<EPI_BERN> runs "MFMAs of a 64-pixel group, then its epilogue": the
 // waves of a workgroup pass those phases in lockstep (barriers) and two workgroups sharing a CU fall into step with each
@@ -3075,6 +3138,12 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
 bool block_fwd_ok(const BlockFwdArgs& a) {
     return a.R <= 4096 && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT2 <= 16 && a.NT1 == 2 * a.KT1 &&
            (size_t)(a.KT0 + 2 * a.KT1) * 1024 <= 150 * 1024;
+}
+bool block_bwd_ok(const BlockBwdArgs& a) {
+    return a.R <= 4096 && a.KTH <= BLOCKFWD_MAX_KT && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT1;
+}
+void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(block_bwd_kernel, dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KTH + a.KT1) * 1024, st, a);
 }
 void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((block_fwd_kernel<6>), dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KT0 + 2 * a.KT1) * 1024, st, a);

@@ -591,8 +591,20 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
 int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side) {
-    CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
-    CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
+    bool chain_fused = false;
+    if (m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
+        BlockBwdArgs b;      // few rows (the encoder on the batch's images): both dX products in one launch
+        memset(&b, 0, sizeof(b));
+        b.DH = ptr<uint16_t>(w.dheadP); b.ldDH = blk[2].Np32; b.imgH = blk[2].imgB; b.imgL2 = blk[1].imgB;
+        b.KTH = blk[2].KT_B; b.KT1 = blk[1].KT_B; b.NT1 = blk[0].Np32 / 16; b.R = R;
+        b.H2 = ptr<uint16_t>(w.h2P); b.H1 = ptr<uint16_t>(w.h1P); b.ldH = blk[0].Np32;
+        b.D2 = ptr<uint16_t>(w.d2P); b.D1 = ptr<uint16_t>(w.d1P);
+        if (block_bwd_ok(b)) { launch_block_bwd(b, m->stream); chain_fused = true; }
+    }
+    if (!chain_fused) {
+        CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
+        CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
+    }
     if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
     const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
     const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
