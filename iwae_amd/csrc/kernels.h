@@ -73,6 +73,20 @@ struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <
     uint16_t *H1, *H2; int ldH;       // hidden activations, P-layout [R][32*KT1]
     float* YF; int ldYF; int split;   // head, fp32 [R][ldYF]; out-features >= split are the sigma head
 };
+struct DecBwdRowsArgs {               // dec_bwd_rows_kernel: the decoder's dX chain on few rows (16-row workgroups, weights straight from L2)
+    const uint16_t* SP; int ldS; int KTX;     // s = x - sigmoid(l), P-layout [M][ldS], KTX = ldS/32 pixel k-steps
+    const char* imgK3; int MT3;               // K-major image of the output layer's W (block (pixel k-step, hidden tile)), MT3 hidden tiles per k-step
+    const char *imgB2, *imgB1;                // backward images of the second / first tanh layer (MG-major, KT k-steps each)
+    int KT, NT1, NT3;                         // hidden k-steps, hidden tiles (= 2*KT), latent tiles of dz
+    int M;
+    const uint16_t *G2, *G1; int ldH;         // stored tanh activations, P-layout [M][32*KT]
+    const float* gx;                          // [M] row weights
+    uint16_t *D2P, *D1P;                      // dpre2, dpre1 out, P-layout [M][32*KT]
+    float* DZ; uint16_t* DZH; int ldDZ;       // dz out: float32 or (DZH != null) bf16, [M][ldDZ]
+};
+bool dec_bwd_rows_ok(const DecBwdRowsArgs& a);
+void launch_dec_bwd_rows(const DecBwdRowsArgs& a, hipStream_t st);
+
 struct BlockBwdArgs {                 // block_bwd_kernel: the dX chain of a BasicBlock on R <= 4096 rows
     const uint16_t* DH; int ldDH;     // dhead, bf16 P-layout [R][32*KTH]
     const char *imgH, *imgL2;         // backward images (MG-major: out-feature groups over hidden) of the head (KTH k-steps) and of l2 (KT1)

@@ -755,6 +755,107 @@ __global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// dec_bwd_rows_kernel: the decoder's dX chain (dec_bwd_kernel's three products) on FEW rows, in block_bwd_kernel's form: a 16-wave
+// workgroup owns 16 rows, wave w owns hidden tile w of the first two products (latent tile w of the third), the weight fragments
+// come straight from the L2-resident images -- for dg2 = s W3^T the K-major image of W3 (rows = hidden tile, k = pixels), streamed
+// AD deep over the 25 pixel k-steps -- and s / dpre2 / dpre1 sit in LDS as 1 KiB k-step blocks.  dec_bwd_kernel streams every weight
+// unit through ONE workgroup's LDS per 128 rows: at 20 rows that is a single workgroup walking 19 units in turn (27 us).
+// ---------------------------------------------------------------------------------
+template <int AD>
+__global__ __launch_bounds__(1024, 5) void dec_bwd_rows_kernel(DecBwdRowsArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int row = r0 + rho;
+    const bool valid = row < a.M;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    char* act0 = smem;                                   // s tile: KTX blocks
+    char* act1 = smem + (size_t)a.KTX * 1024;            // dpre2: KT blocks
+    char* act2 = act1 + (size_t)a.KT * 1024;             // dpre1: KT blocks
+    for (int c = threadIdx.x; c < a.KTX * 64; c += 1024) {
+        const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < a.M) v = *(const uint4*)(a.SP + (size_t)(r0 + rr) * a.ldS + ks * 32 + qq * 8);
+        *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
+    }
+    const int mg = wave >> 2, tg = wave & 3;
+    const bool has = wave < a.NT1, has3 = wave < a.NT3;
+    const char* w3 = a.imgK3 + (size_t)wave * 1024 + a_off;                    // block (pixel k-step ks, hidden tile wave) = (ks*MT + wave) KiB
+    const char* w2 = a.imgB2 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
+    const char* w1 = a.imgB1 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
+    uint4 A2[BLOCKFWD_MAX_KT], A1[BLOCKFWD_MAX_KT];
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A2[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT && has) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
+    }
+    const int kso = wave >> 1, hh = wave & 1;
+    uint2 y2 = make_uint2(0, 0), y1 = make_uint2(0, 0);
+    float gxr = 0.0f;
+    if (valid && has) {
+        y2 = *(const uint2*)(a.G2 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+        y1 = *(const uint2*)(a.G1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+        gxr = a.gx[row];
+    }
+    auto dtanh = [&](const f32x4& acc, const uint2& y, float sc) {
+        const float ya = bflo(y.x), yb = bfhi(y.x), yc = bflo(y.y), yd = bfhi(y.y);
+        return make_uint2(pack2(sc * acc[0] * (1.0f - ya * ya), sc * acc[1] * (1.0f - yb * yb)), pack2(sc * acc[2] * (1.0f - yc * yc), sc * acc[3] * (1.0f - yd * yd)));
+    };
+    // ---- product 1: dg2 = s W3^T over the KTX pixel k-steps, A fragments streamed AD deep
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const size_t kstride = (size_t)a.MT3 * 1024;
+        uint4 av[AD];
+#pragma unroll
+        for (int i = 0; i < AD; ++i) av[i] = (i < a.KTX && has) ? *(const uint4*)(w3 + (size_t)i * kstride) : make_uint4(0, 0, 0, 0);
+        __syncthreads();                         // s tile staged
+        for (int k0 = 0; k0 < a.KTX; k0 += AD) {
+#pragma unroll
+            for (int i = 0; i < AD; ++i) {
+                const int ks = k0 + i;
+                if (ks < a.KTX) {
+                    acc = mfma16(av[i], *(const uint4*)(act0 + ks * 1024 + a_off), acc);
+                    if (ks + AD < a.KTX && has) av[i] = *(const uint4*)(w3 + (size_t)(ks + AD) * kstride);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A1[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT && has3) A1[ks] = *(const uint4*)(w1 + (size_t)ks * 4096);
+    }
+    if (has) {
+        const uint2 v = valid ? dtanh(acc, y2, gxr) : make_uint2(0, 0);      // dpre2 = g_r * dg2 * (1 - g2^2)
+        *(uint2*)(act1 + kso * 1024 + a_off + 8 * hh) = v;
+        if (valid) *(uint2*)(a.D2P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
+    }
+    __syncthreads();
+    // ---- product 2: dpre1 = (dpre2 V2^T) * (1 - g1^2)
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT) acc = mfma16(A2[ks], *(const uint4*)(act1 + ks * 1024 + a_off), acc);
+    if (has) {
+        const uint2 v = valid ? dtanh(acc, y1, 1.0f) : make_uint2(0, 0);
+        *(uint2*)(act2 + kso * 1024 + a_off + 8 * hh) = v;
+        if (valid) *(uint2*)(a.D1P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
+    }
+    __syncthreads();
+    // ---- product 3: dz = dpre1 V1^T (latent tile `wave`)
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT) acc = mfma16(A1[ks], *(const uint4*)(act2 + ks * 1024 + a_off), acc);
+    if (has3 && valid) {
+        const int f0 = 16 * wave + 4 * q;
+        if (a.DZH) *(uint2*)(a.DZH + (size_t)row * a.ldDZ + f0) = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
+        else *(float4*)(a.DZ + (size_t)row * a.ldDZ + f0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // bern_pipe_kernel: the Bernoulli forward (decoder output layer + log p(x|z), iwae1.py:74-75,83,111) at large row counts,
 // software-pipelined INSIDE each wave.  dense_kernel<EPI_BERN> runs "MFMAs of a 64-pixel group, then its epilogue": the
 // waves of a workgroup pass those phases in lockstep (barriers) and two workgroups sharing a CU fall into step with each
@@ -2612,7 +2713,14 @@ __global__ void lse_kernel(LseArgs a) {
         const int r = b * k + s;
         float px = a.term[0][r];
         if (a.n_px_part > 1) {      // log p(x|z) as partial sums over pixel groups (small row counts): fixed order
-            for (int i = 1; i < a.n_px_part; ++i) px += a.term[0][(size_t)i * a.px_stride + r];
+            // (all partials requested at once: as a loop of dependent adds each load waited for the one before it -- 13 L2 round
+            // trips, most of this kernel's 10 us at B = 20)
+            float part[16];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) part[i] = (i < a.n_px_part) ? a.term[0][(size_t)i * a.px_stride + r] : 0.0f;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) px += part[i];
+            for (int i = 16; i < a.n_px_part; ++i) px += a.term[0][(size_t)i * a.px_stride + r];
             a.term0_out[r] = px;
         }
         float lw = a.coef[0] * px;
@@ -3138,6 +3246,12 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
 bool block_fwd_ok(const BlockFwdArgs& a) {
     return a.R <= 4096 && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT2 <= 16 && a.NT1 == 2 * a.KT1 &&
            (size_t)(a.KT0 + 2 * a.KT1) * 1024 <= 150 * 1024;
+}
+bool dec_bwd_rows_ok(const DecBwdRowsArgs& a) {
+    return a.KT <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT && a.NT3 <= 16 && (size_t)(a.KTX + 2 * a.KT) * 1024 <= 150 * 1024;
+}
+void launch_dec_bwd_rows(const DecBwdRowsArgs& a, hipStream_t st) {
+    LAUNCH_EV((dec_bwd_rows_kernel<6>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
 }
 bool block_bwd_ok(const BlockBwdArgs& a) {
     return a.R <= 4096 && a.KTH <= BLOCKFWD_MAX_KT && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT1;

@@ -226,6 +226,7 @@ struct iwae_model {
     int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
+    int dec_rows_max = 1024;    // dec_bwd_rows_kernel up to this many rows (IWAE_DEC_ROWS), dec_bwd_kernel beyond
     bool small_dec_bwd = true; int small_rows = 8191;   // the one-launch dX chain also below 8 192 rows (IWAE_NO_SMALL_DEC_BWD=1: the per-pixel-group out_bwd + finish + two dX launches
                                                         // there).  Measured: B=20,k=1 0.1417 -> 0.1383 ms/step, B=100,k=5 150.7 -> 144.6 us, B=160,k=50 189.1 -> 165.7 us
     bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
@@ -1013,7 +1014,25 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             // pass, hidden width with an instantiation; dpre2 / dpre1 stay in registers from product to product.
             fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && (M >= 8192 || small_fused) && !a.stamps && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
                        m->dec1[0].KT_B == L.KT && m->dec1[1].Kp32 == L.Kp32 && m->dec1[0].Np32 == L.Kp32;
-            if (fused_dx) {
+            bool rows_kernel = false;
+            if (fused_dx && M <= m->dec_rows_max && m->allow_block_fused && L.kmajor && L.imgB) {      // few rows: 16-row workgroups, weights straight from L2
+                DecBwdRowsArgs r;
+                memset(&r, 0, sizeof(r));
+                r.SP = ptr<uint16_t>(w.dlP); r.ldS = Xp; r.KTX = Xp / 32; r.imgK3 = L.imgB; r.MT3 = L.MT_B;
+                r.imgB2 = m->dec1[1].imgB; r.imgB1 = m->dec1[0].imgB; r.KT = L.KT; r.NT1 = L.Kp32 / 16; r.NT3 = m->dec1[0].Kp32 / 16; r.M = M;
+                r.G2 = ptr<uint16_t>(w.g2P); r.G1 = ptr<uint16_t>(w.g1P); r.ldH = L.Kp32; r.gx = ptr<float>(m->gx);
+                r.D2P = ptr<uint16_t>(w.d2P); r.D1P = ptr<uint16_t>(w.d1P); r.ldDZ = m->dec1[0].Kp32;
+                dz_half = !two && m->allow_dz_half;
+                r.DZ = ptr<float>(w.dz); r.DZH = dz_half ? (uint16_t*)w.dz.p : nullptr;
+                if (dec_bwd_rows_ok(r)) {
+                    ScopedTimer tm(m, T_DEC_BWD);
+                    if (!m->serial) set_launch_stop_event(m->ev_fork2);
+                    launch_dec_bwd_rows(r, st);
+                    rows_kernel = true;
+                }
+            }
+            if (rows_kernel) {
+            } else if (fused_dx) {
                 DecBwdArgs d;
                 memset(&d, 0, sizeof(d));
                 d.o = a;
@@ -1682,6 +1701,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     m->allow_dz_half = getenv("IWAE_DZ_F32") == nullptr;
     m->small_dec_bwd = getenv("IWAE_NO_SMALL_DEC_BWD") == nullptr;
     if (const char* e = getenv("IWAE_SMALL_ROWS")) m->small_rows = atoi(e);
+    if (const char* e = getenv("IWAE_DEC_ROWS")) m->dec_rows_max = atoi(e);
     m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
     if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
     if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);

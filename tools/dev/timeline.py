@@ -3,8 +3,10 @@ usage: python tools/dev/timeline.py <dir containing *kernel_trace.csv> [step ind
 import csv, glob, sys
 fn = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:58], r["Queue_Id"]) for r in csv.DictReader(open(fn)))
-starts = [i for i, e in enumerate(ev) if "prep_rows" in e[2] or "gather_binarize" in e[2]]
-if len(starts) < 4: starts = [i for i, e in enumerate(ev) if "block_fwd_kernel" in e[2]]      # the fused encoder kernel converts the batch itself
+# one step = from one reduce on the main queue to the next (exactly one per training step; the window is a whole step, phase-shifted:
+# it opens with the encoder forward of the next step)
+starts = [i + 1 for i, e in enumerate(ev) if "latent_bwd_kernel" in e[2]]
+starts = [i for i in starts if i < len(ev)]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 i0, i1 = starts[n], starts[n + 1]
 t0 = ev[i0][0]
