@@ -63,6 +63,17 @@ struct DenseArgs {
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
 };
 
+struct SampleArgs {
+    const float* head; int ldH; int Dp; int D; int head_per_row;
+    int M, Mp, k, B;
+    EpsSrc eps;
+    uint16_t* ZP;                     // z as bf16 P-layout [M][Dp], or null
+    float* ZF; int ldZF;              // z as float32 rows [M][ldZF] (float32 mode), or null
+    const float* prior_head;          // conditional prior: per-image head [B][ldH] (mu_p | sigma_p) scoring z, or null = N(0,1)
+    const float* cond; int C;         // conditional model: y [B][C] goes into features D..D+C-1 of the z rows (decoder input concat(z, y))
+    float* lp_prior; float* lq; float* lq_dreg;
+};
+
 struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <= 4096 rows
     const uint16_t* X; int ldX;       // input rows, P-layout [R][32*KT0]
     const float* Xf; int Xdim; uint16_t* XPout;   // or (Xf != null) fp32 rows [R][Xdim], converted on the way in and kept in XPout (P-layout, ldX)
@@ -72,6 +83,7 @@ struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <
     int R;
     uint16_t *H1, *H2; int ldH;       // hidden activations, P-layout [R][32*KT1]
     float* YF; int ldYF; int split;   // head, fp32 [R][ldYF]; out-features >= split are the sigma head
+    int sample; SampleArgs S;         // sample != 0: the input rows are z = mu + sigma*eps made HERE (sample_kernel's job, without its launch): S.Dp = 32*KT0
 };
 struct DecBwdRowsArgs {               // dec_bwd_rows_kernel: the decoder's dX chain on few rows (16-row workgroups, weights straight from L2)
     const uint16_t* SP; int ldS; int KTX;     // s = x - sigmoid(l), P-layout [M][ldS], KTX = ldS/32 pixel k-steps
@@ -141,17 +153,6 @@ struct WgradPGroup {                        // up to 3 independent 8-wave weight
     int n;
     int gx[3], gy[3];                       // j-blocks / i-blocks of each
     int zbeg[4];                            // first blockIdx.z of each (zbeg[n] = total)
-};
-
-struct SampleArgs {
-    const float* head; int ldH; int Dp; int D; int head_per_row;
-    int M, Mp, k, B;
-    EpsSrc eps;
-    uint16_t* ZP;                     // z as bf16 P-layout [M][Dp], or null
-    float* ZF; int ldZF;              // z as float32 rows [M][ldZF] (float32 mode), or null
-    const float* prior_head;          // conditional prior: per-image head [B][ldH] (mu_p | sigma_p) scoring z, or null = N(0,1)
-    const float* cond; int C;         // conditional model: y [B][C] goes into features D..D+C-1 of the z rows (decoder input concat(z, y))
-    float* lp_prior; float* lq; float* lq_dreg;
 };
 
 struct GaussLpArgs {

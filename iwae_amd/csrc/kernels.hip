@@ -146,6 +146,51 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
     }
 }
 
+// One 32-feature step t of z = mu + sigma*eps for the lane's (row, quad): the lane's 8 features of P-layout chunk 4t+q (features
+// 32t+4q..+3 and 32t+16+4q..+3) and their contributions to the row's log-densities (sample_kernel; block_fwd_kernel's sampling mode)
+__device__ __forceinline__ void sample_step(const SampleArgs& a, int t, int q, int rowc, int b, int s, const float* hd, float z8[8], float& lp, float& lq, float& lq2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int f0 = 32 * t + 16 * h + 4 * q;
+        float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float4 mu4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sg4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        float4 pm4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ps4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);     // prior: N(0,1) unless a head is given
+        if (f0 < a.D) {
+            eps4(a.eps, b, s, rowc, f0 >> 2, a.D, e);
+            mu4 = *(const float4*)(hd + f0);
+            sg4 = *(const float4*)(hd + a.Dp + f0);
+            if (a.prior_head) {      // learned conditional prior p(z|y) of tasks/task04.py:124-130, one head per image
+                pm4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + f0);
+                ps4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + a.Dp + f0);
+            }
+        }
+        const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+        const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float z = 0.0f;
+            if (a.cond && f0 + i >= a.D && f0 + i < a.D + a.C) z = a.cond[(size_t)b * a.C + (f0 + i - a.D)];   // decoder input = concat(z, y)
+            if (f0 + i < a.D) {
+                const float mu = muv[i], sg = sgv[i];
+                z = mu + sg * e[i];                                  // iwae1.py:59
+                if (a.prior_head) {
+                    const float up = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
+                    lp += -0.5f * up * up - 0.5f * LOG2PI_F - __logf(psv[i]);   // task04.py:130
+                } else {
+                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;           // iwae1.py:107
+                }
+                const float u = (z - mu) * __builtin_amdgcn_rcpf(sg);
+                lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
+                if (a.lq_dreg) {                                     // tasks/task02.py:63-65
+                    const float s2 = sg + 1e-6f, u2 = (z - mu) * __builtin_amdgcn_rcpf(s2);
+                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
+                }
+            }
+            z8[4 * h + i] = z;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // Bernoulli log-likelihood of the lane's 8 logits of one 32-pixel step (accumulator tiles a0: pixels f0..f0+3,
 // a1: f0+16..f0+19, bias already in), x = the lane's 8 bf16 pixel values:
@@ -577,7 +622,7 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
 // ---------------------------------------------------------------------------------
 #define BLOCKFWD_MAX_KT 8      // k-steps of the two later layers (hidden <= 256)
 template <int AD>
-__global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
+__global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void block_fwd_kernel(BlockFwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -592,6 +637,25 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
     // stage the x tile (rows beyond R: zeros).  Xf != null: the rows arrive as fp32 [R][Xdim] (the batch as the caller
     // handed it over) and are converted here -- prep_rows_kernel's job, without its launch; the bf16 P-layout rows also go
     // to HBM (XPout) for the kernels that read x later (Bernoulli forward, weight gradient of the first layer).
+    // sample != 0: the rows are z = mu + sigma*eps, made here in sample_kernel's arithmetic and summation order: wave t makes the
+    // 32-feature step t of the 16 rows (all loads of the tile in flight at once; sample_kernel walks its steps in turn), the lanes'
+    // partial log-density sums meet in LDS and wave 15 adds them up once the tile is staged.
+    float* red = (float*)(act2 + (size_t)a.KT1 * 1024);      // [3][KT0][64]
+    if (a.sample) {
+        if (wave < a.KT0) {
+            const int rowc = valid ? row : a.S.M - 1;
+            const int b = rowc / a.S.k, sidx = rowc - b * a.S.k;
+            const float* hd = a.S.head + (size_t)(a.S.head_per_row ? rowc : b) * a.S.ldH;
+            float z8[8], lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
+            sample_step(a.S, wave, q, rowc, b, sidx, hd, z8, lp, lq, lq2);
+            const uint4 v = valid ? make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7])) : make_uint4(0, 0, 0, 0);
+            *(uint4*)(act0 + wave * 1024 + a_off) = v;
+            if (valid) *(uint4*)(a.S.ZP + (size_t)row * a.S.Dp + 8 * (4 * wave + q)) = v;
+            red[(0 * a.KT0 + wave) * 64 + lane] = lp;
+            red[(1 * a.KT0 + wave) * 64 + lane] = lq;
+            red[(2 * a.KT0 + wave) * 64 + lane] = lq2;
+        }
+    } else
     for (int c = threadIdx.x; c < a.KT0 * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
         const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -666,6 +730,22 @@ __global__ __launch_bounds__(1024, 5) void block_fwd_kernel(BlockFwdArgs a) {
     for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
         A2[ks] = make_uint4(0, 0, 0, 0);
         if (ks < a.KT1 && has2) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
+    }
+    if (a.sample && wave == 15) {      // the rows' log-densities: the lane's steps in turn, then the four quads (sample_kernel's order)
+        float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
+        for (int t = 0; t < a.KT0; ++t) {
+            lp += red[(0 * a.KT0 + t) * 64 + lane];
+            lq += red[(1 * a.KT0 + t) * 64 + lane];
+            lq2 += red[(2 * a.KT0 + t) * 64 + lane];
+        }
+        lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+        lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
+        lq2 += __shfl_xor(lq2, 16); lq2 += __shfl_xor(lq2, 32);
+        if (q == 0 && valid) {
+            if (a.S.lp_prior) a.S.lp_prior[row] = lp;
+            a.S.lq[row] = lq;
+            if (a.S.lq_dreg) a.S.lq_dreg[row] = lq2;
+        }
     }
     if (has1) emit_tanh(acc, b0, act1, a.H1, a.ldH);
     __syncthreads();
@@ -762,7 +842,7 @@ __global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
 // unit through ONE workgroup's LDS per 128 rows: at 20 rows that is a single workgroup walking 19 units in turn (27 us).
 // ---------------------------------------------------------------------------------
 template <int AD>
-__global__ __launch_bounds__(1024, 5) void dec_bwd_rows_kernel(DecBwdRowsArgs a) {
+__global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(DecBwdRowsArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -2602,46 +2682,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     const int nt = a.Dp / 32;
     for (int t = 0; t < nt; ++t) {
         float z8[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int f0 = 32 * t + 16 * h + 4 * q;
-            float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            float4 mu4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sg4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-            float4 pm4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), ps4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f);     // prior: N(0,1) unless a head is given
-            if (f0 < a.D) {
-                eps4(a.eps, b, s, rowc, f0 >> 2, a.D, e);
-                mu4 = *(const float4*)(hd + f0);
-                sg4 = *(const float4*)(hd + a.Dp + f0);
-                if (a.prior_head) {      // learned conditional prior p(z|y) of tasks/task04.py:124-130, one head per image
-                    pm4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + f0);
-                    ps4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + a.Dp + f0);
-                }
-            }
-            const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
-            const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float z = 0.0f;
-                if (a.cond && f0 + i >= a.D && f0 + i < a.D + a.C) z = a.cond[(size_t)b * a.C + (f0 + i - a.D)];   // decoder input = concat(z, y)
-                if (f0 + i < a.D) {
-                    const float mu = muv[i], sg = sgv[i];
-                    z = mu + sg * e[i];                                  // iwae1.py:59
-                    if (a.prior_head) {
-                        const float up = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
-                        lp += -0.5f * up * up - 0.5f * LOG2PI_F - __logf(psv[i]);   // task04.py:130
-                    } else {
-                        lp += -0.5f * z * z - 0.5f * LOG2PI_F;           // iwae1.py:107
-                    }
-                    const float u = (z - mu) * __builtin_amdgcn_rcpf(sg);
-                    lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
-                    if (a.lq_dreg) {                                     // tasks/task02.py:63-65
-                        const float s2 = sg + 1e-6f, u2 = (z - mu) * __builtin_amdgcn_rcpf(s2);
-                        lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
-                    }
-                }
-                z8[4 * h + i] = z;
-            }
-        }
+        sample_step(a, t, q, rowc, b, s, hd, z8, lp, lq, lq2);
         if (valid && a.ZP)
             *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * (4 * t + q)) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
         if (valid && a.ZF) {       // float32 mode: z in natural feature order, unrounded
@@ -3244,6 +3285,7 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
     return false;
 }
 bool block_fwd_ok(const BlockFwdArgs& a) {
+    if (a.sample && (a.S.Dp != 32 * a.KT0 || a.KT0 > 15 || !a.S.ZP || a.S.ZF || a.S.M != a.R)) return false;
     return a.R <= 4096 && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT2 <= 16 && a.NT1 == 2 * a.KT1 &&
            (size_t)(a.KT0 + 2 * a.KT1) * 1024 <= 150 * 1024;
 }
@@ -3251,7 +3293,8 @@ bool dec_bwd_rows_ok(const DecBwdRowsArgs& a) {
     return a.KT <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT && a.NT3 <= 16 && (size_t)(a.KTX + 2 * a.KT) * 1024 <= 150 * 1024;
 }
 void launch_dec_bwd_rows(const DecBwdRowsArgs& a, hipStream_t st) {
-    LAUNCH_EV((dec_bwd_rows_kernel<6>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
+    if (a.M <= 512 && a.KTX > 8) LAUNCH_EV((dec_bwd_rows_kernel<13>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
+    else LAUNCH_EV((dec_bwd_rows_kernel<6>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
 }
 bool block_bwd_ok(const BlockBwdArgs& a) {
     return a.R <= 4096 && a.KTH <= BLOCKFWD_MAX_KT && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT1;
@@ -3260,7 +3303,11 @@ void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(block_bwd_kernel, dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KTH + a.KT1) * 1024, st, a);
 }
 void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((block_fwd_kernel<6>), dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KT0 + 2 * a.KT1) * 1024, st, a);
+    const size_t lds = (size_t)(a.KT0 + 2 * a.KT1) * 1024 + (a.sample ? (size_t)a.KT0 * 768 : 0);
+    // a handful of workgroups and a long first layer (the encoder on <= 512 images): 13 weight fragments in flight per wave instead of
+    // 6 (the 25 k-steps of the 784-pixel layer in two round trips to L2 instead of five) -- at the price of the whole CU's registers
+    if (a.R <= 512 && a.KT0 > 8) hipLaunchKernelGGL((block_fwd_kernel<13>), dim3((a.R + 15) / 16), dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((block_fwd_kernel<6>), dim3((a.R + 15) / 16), dim3(1024), lds, st, a);
 }
 // the pipelined Bernoulli forward exists for the reference's hidden width (7 k-steps), one block owning all pixel groups,
 // and k large enough that a block's 128 rows span <= BERN_XIMG_MAX images

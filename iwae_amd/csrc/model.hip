@@ -761,7 +761,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
-    bool fuse_z = false;
+    bool fuse_z = false, sample_in_block = false;
     SampleArgs zin;
     memset(&zin, 0, sizeof(zin));
     if (m->has_prior) {     // p(z|y) = N(mu_p(y), sigma_p(y)) (tasks/task04.py:124): the prior block on the B condition rows
@@ -786,7 +786,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // 1-layer training step on the device's own noise: the first decoder layer makes z itself (dense_kernel ZIN mode)
         fuse_z = m->allow_zin && !two && m->C == 0 && bwd && !want_dreg && s.eps.cache != nullptr && M >= 8192 &&
                  (m->dec1[0].KT == 4 || m->dec1[0].KT == 2) && m->dec1[0].Kp32 == m->Dp[0];
-        if (fuse_z) zin = s;
+        // few rows: block_fwd_kernel (the decoder's two tanh layers in one launch, below) makes z itself -- one latency-bound launch less
+        sample_in_block = m->allow_block_fused && m->allow_zin && !two && !fuse_z && M <= 4096 && !s.ZF && m->dec1[0].Kp32 == m->Dp[0];
+        if (fuse_z || sample_in_block) zin = s;
         else launch_sample(s, st);
     }
     if (two) {
@@ -870,6 +872,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                 a.zhead = nullptr; a.zeps = nullptr; a.ZPout = nullptr; a.zlp = a.zlq = nullptr;
             }
         }
+        if (fuse_dec && sample_in_block) { launch_sample(zin, st); sample_in_block = false; }
         if (!fuse_dec) {
             // few rows: the two tanh layers as ONE launch of block_fwd_kernel (a BasicBlock without its head: 16-row workgroups,
             // weights straight from the L2-resident images) instead of two latency-bound dense_kernel launches
@@ -881,8 +884,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                 bf.KT0 = m->dec1[0].KT; bf.KT1 = m->dec1[1].KT; bf.NT1 = m->dec1[0].Np32 / 16; bf.NT2 = 0; bf.R = M;
                 bf.H1 = ptr<uint16_t>(w.g1P); bf.H2 = ptr<uint16_t>(w.g2P); bf.ldH = m->dec1[0].Np32;
                 bf.YF = nullptr; bf.ldYF = 0; bf.split = 1 << 30;
-                if (block_fwd_ok(bf)) { launch_block_fwd(bf, st); two_in_one = true; }
+                if (sample_in_block) { bf.sample = 1; bf.S = zin; }
+                if (block_fwd_ok(bf)) { launch_block_fwd(bf, st); two_in_one = true; sample_in_block = false; }
             }
+            if (sample_in_block) { launch_sample(zin, st); sample_in_block = false; }      // (shapes the fused kernel does not cover)
             if (!two_in_one) {
                 CHK(dense_fwd(m, m->dec1[0], EPI_TANH, ptr<uint16_t>(m->zP[0]), M, ptr<uint16_t>(w.g1P), nullptr, 0, fuse_z ? &zin : nullptr));
                 CHK(dense_fwd(m, m->dec1[1], EPI_TANH, ptr<uint16_t>(w.g1P), M, ptr<uint16_t>(w.g2P), nullptr, 0));
