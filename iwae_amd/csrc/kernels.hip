@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     // started from the bias block) are issued in four chunks between the epilogue arithmetic of half h (accC, two logits
     // per chunk); sched_barrier fences keep the chunks apart, inside a chunk the compiler schedules freely.  MF = false:
     // epilogue only (last half).  The per-logit arithmetic is bern8's (see there).
-    auto stage = [&](auto masked, auto domfma, f32x4 (&accC)[2], f32x4 (&accN)[2], int h, int bufN, int tbN, float4 (&xq)[2], uint4& sp) {
+    auto stage = [&](auto masked, auto domfma, f32x4 (&accC)[2], f32x4 (&accN)[2], int h, int bufN, int tbN, float4 (&xq)[2], float4 (&xnx)[2], uint4& sp) {
         constexpr bool MASKED = decltype(masked)::value, MF = decltype(domfma)::value;
         const char* lb = smem + bufN * UNIT + a_off + tbN * 1024;
         uint4 av[P];
@@ -1164,20 +1164,22 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         }
         float s_xl = 0.0f, s_al = 0.0f, prod = 1.0f, sv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const int f0 = 32 * h + 4 * q;
-        // x - 1/2 of this half was read a stage ago (xq); the next half's is requested here and pinned at the end of the stage,
+        // x - 1/2 of this half was read a stage ago (xq); the next half's is requested here (xnx: the two register sets swap roles
+        // from stage to stage, like the accumulators -- a copy back would be 8 v_mov per stage) and pinned at the end of the stage,
         // so no epilogue instruction waits on an LDS read issued right in front of it
-        float xm8[8] = {xq[0].x, xq[0].y, xq[0].z, xq[0].w, xq[1].x, xq[1].y, xq[1].z, xq[1].w};
-        asm volatile("" : "+v"(xm8[0]), "+v"(xm8[1]), "+v"(xm8[2]), "+v"(xm8[3]), "+v"(xm8[4]), "+v"(xm8[5]), "+v"(xm8[6]), "+v"(xm8[7]));
-        float4 xn0 = *(const float4*)(lxrow + (h + 1) * 128), xn1 = *(const float4*)(lxrow + (h + 1) * 128 + 16);   // <= one half past the end: the pad
+        asm volatile("" : "+v"(xq[0].x), "+v"(xq[0].y), "+v"(xq[0].z), "+v"(xq[0].w), "+v"(xq[1].x), "+v"(xq[1].y), "+v"(xq[1].z), "+v"(xq[1].w));
+        const float xm8[8] = {xq[0].x, xq[0].y, xq[0].z, xq[0].w, xq[1].x, xq[1].y, xq[1].z, xq[1].w};
+        xnx[0] = *(const float4*)(lxrow + (h + 1) * 128); xnx[1] = *(const float4*)(lxrow + (h + 1) * 128 + 16);   // <= one half past the end: the pad
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             // chunk fence.  The arithmetic is pure, so a scheduling barrier alone does not hold it in its chunk: the
             // chunk's inputs (two logits, the running accumulators) and the previous chunk's results pass through an
             // empty volatile asm, which pins both ends of every chunk's dependence chains.
-            float l0 = (c < 2) ? accC[0][(2 * c) & 3] : accC[1][(2 * c) & 3];
-            float l1 = (c < 2) ? accC[0][(2 * c + 1) & 3] : accC[1][(2 * c + 1) & 3];
-            if (MF && c > 0) asm volatile("" : "+v"(l0), "+v"(l1), "+v"(prod), "+v"(s_al), "+v"(s_xl), "+v"(accN[0]), "+v"(accN[1]));
-            else asm volatile("" : "+v"(l0), "+v"(l1), "+v"(prod), "+v"(s_al), "+v"(s_xl));
+            // (the logits pass through it in place, as whole accumulator tiles: pinning copies of the two logits cost 8 v_mov per stage)
+            if (MF && c > 0) asm volatile("" : "+v"(accC[0]), "+v"(accC[1]), "+v"(prod), "+v"(s_al), "+v"(s_xl), "+v"(accN[0]), "+v"(accN[1]));
+            else asm volatile("" : "+v"(accC[0]), "+v"(accC[1]), "+v"(prod), "+v"(s_al), "+v"(s_xl));
+            const float l0 = (c < 2) ? accC[0][(2 * c) & 3] : accC[1][(2 * c) & 3];
+            const float l1 = (c < 2) ? accC[0][(2 * c + 1) & 3] : accC[1][(2 * c + 1) & 3];
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MF) {     // chunk 0 is arithmetic only: it covers the latency of the LDS reads issued just above
                 if (c > 0) {
@@ -1209,8 +1211,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             if (KEEP) asm volatile("" : "+v"(sv[2 * c]), "+v"(sv[2 * c + 1]));
         }
         if constexpr (MF) asm volatile("" : "+v"(prod), "+v"(s_al), "+v"(s_xl), "+v"(accN[0]), "+v"(accN[1]));
-        asm volatile("" : "+v"(xn0.x), "+v"(xn0.y), "+v"(xn0.z), "+v"(xn0.w), "+v"(xn1.x), "+v"(xn1.y), "+v"(xn1.z), "+v"(xn1.w));
-        xq[0] = xn0; xq[1] = xn1;
+        asm volatile("" : "+v"(xnx[0].x), "+v"(xnx[0].y), "+v"(xnx[0].z), "+v"(xnx[0].w), "+v"(xnx[1].x), "+v"(xnx[1].y), "+v"(xnx[1].z), "+v"(xnx[1].w));
         __builtin_amdgcn_sched_barrier(0);
         if (KEEP) sp = make_uint4(pack2(sv[0], sv[1]), pack2(sv[2], sv[3]), pack2(sv[4], sv[5]), pack2(sv[6], sv[7]));
         rowacc += s_xl - 0.5f * s_al - LN2_F * log2_raw(prod);
@@ -1295,12 +1296,12 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             store_s(h - 1, st[0]);
         }
     };
-    float4 xbq[2] = {*(const float4*)lxrow, *(const float4*)(lxrow + 16)};
+    float4 xbq[2] = {*(const float4*)lxrow, *(const float4*)(lxrow + 16)}, xbr[2];
     const int Hmain = min(a.Xdim >> 5, H - 1) & ~1;      // halves [0, Hmain): all 32 pixels real, a next half to multiply; in pairs
     int h = 0;
     for (; h < Hmain; h += 2) {
         const int buf = (h >> 1) & 1;
-        if (fullw) stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, st[0]);          // MFMAs: tiles 2, 3 of this group
+        if (fullw) stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, xbr, st[0]);          // MFMAs: tiles 2, 3 of this group
         {       // boundary(h + 1, true) with st[1] still holding half h - 1
             wait_all_vmem();
             __syncthreads();
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                 store_s(h, st[0]);
             }
         }
-        if (fullw) stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbq, st[1]);   // tiles 0, 1 of the next group
+        if (fullw) stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbr, xbq, st[1]);   // tiles 0, 1 of the next group
         else if (q_real(h >> 1)) q_stage(h >> 1, q_real((h >> 1) + 1));
     }
     for (; h < H; ++h) {        // the last halves (masked epilogue; the very last one has nothing left to multiply)
@@ -1325,9 +1326,10 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         // (the tail always multiplies from accA into accB and copies back: the main loop's role swap would cost two more
         // instantiations of the stage here, and their register pressure -- 13 spilled registers in round 1 -- for <= 3 halves)
         uint4 sp = make_uint4(0, 0, 0, 0);
-        if (domf) stage(std::true_type{}, std::true_type{}, accA, accB, h, bufN, tbN, xbq, sp);
-        else stage(std::true_type{}, std::false_type{}, accA, accB, h, bufN, tbN, xbq, sp);
+        if (domf) stage(std::true_type{}, std::true_type{}, accA, accB, h, bufN, tbN, xbq, xbr, sp);
+        else stage(std::true_type{}, std::false_type{}, accA, accB, h, bufN, tbN, xbq, xbr, sp);
         accA[0] = accB[0]; accA[1] = accB[1];
+        xbq[0] = xbr[0]; xbq[1] = xbr[1];
         if (h & 1) st[1] = sp; else st[0] = sp;
     }
     if (fullw) {
