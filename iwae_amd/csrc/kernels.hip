@@ -2887,6 +2887,10 @@ __global__ __launch_bounds__(256) void scalars_kernel(const float* per_b, int B,
 //   dmu = sum_s dz_tot + kmu*mu ; dsigma = sum_s (dz_tot*eps + cs/sigma) + ksig*(sigma - 1/sigma)
 //   da = dsigma * exp(a) = dsigma * (sigma - 1e-6)
 __device__ __forceinline__ float sigp_of(const LatentBwdArgs& a, int b, int f) { return a.prior_head[(size_t)b * a.ldH + a.Dp + f]; }
+// FAST: the 1-layer training step on the device's own noise (dz as bf16, draws from the step's cache, N(0,1) prior) -- with the
+// sources known at compile time the sample loop's loads are straight-line code and all of them are in flight at once; the general
+// body's run-time source switches made the compiler wait for each iteration's loads in turn (22 us alone for 42 MB).
+template <bool FAST>
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
     __shared__ float red[256][8];
     const int nf4 = a.Dp / 4;              // <= 32
@@ -2911,7 +2915,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             const float s2 = sgm[i] + 1e-6f;
             rs2[i] = 1.0f / (s2 * s2);
             rsg[i] = 1.0f / sgm[i];
-            if (a.prior_head && f0 + i < a.D) {
+            if (!FAST && a.prior_head && f0 + i < a.D) {
                 pmu[i] = a.prior_head[(size_t)b * a.ldH + f0 + i];
                 prs[i] = 1.0f / a.prior_head[(size_t)b * a.ldH + a.Dp + f0 + i];
             }
@@ -2927,6 +2931,13 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                 const bool ok = s < a.k;
                 const int sc = ok ? s : a.k - 1;          // clamped, weighted by 0 below
                 const int row = b * a.k + sc;
+                if constexpr (FAST) {
+                    const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0);
+                    dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y));
+                    cf[u] = a.cf[row];
+                    const float4 ev = *(const float4*)(a.eps.cache + (size_t)row * a.eps.ldC + f0);
+                    e[u][0] = ev.x; e[u][1] = ev.y; e[u][2] = ev.z; e[u][3] = ev.w;
+                } else {
                 if (a.dzh) { const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0); dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y)); }
                 else dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
                 if (a.dz2) {      // 2-layer model: dz1 = decoder path + direct p(z1|z2) term + path through q(z2|z1)
@@ -2934,11 +2945,14 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                     dz[u] = make_float4(dz[u].x + t2.x + t3.x, dz[u].y + t2.y + t3.y, dz[u].z + t2.z + t3.z, dz[u].w + t2.w + t3.w);
                 }
                 cf[u] = a.cf[row];
-                if (!ok) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 eps4(a.eps, b, sc, row, f4, a.D, e[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
+                // (a clamped sample weighs 0 -- decided here, behind the loads: zeroing the coefficient registers in the load
+                // loop made every iteration wait for its own loads)
+                if (s0 + u * SG >= a.k) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 const float dzv[4] = {dz[u].x, dz[u].y, dz[u].z, dz[u].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -2982,7 +2996,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             *(float4*)(a.DHF + (size_t)b * (2 * a.Dp) + a.Dp + f0) = make_float4(dsg[0], dsg[1], dsg[2], dsg[3]);
         }
     }
-    if (!a.prior_head) return;       // block-uniform
+    if (FAST || !a.prior_head) return;       // block-uniform
     // same reduction for the conditional prior's head: d/dmu_p, d/dsigma_p -> pre-activation of exp (sigma_p - 1e-6)
     __syncthreads();
 #pragma unroll
@@ -3454,7 +3468,8 @@ void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sam
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { LAUNCH_EV(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(a.Bp), dim3(256), 0, st, a);
+    if (a.dzh && !a.dz2 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<true>, dim3(a.Bp), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(latent_bwd_kernel<false>, dim3(a.Bp), dim3(256), 0, st, a);
 }
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
