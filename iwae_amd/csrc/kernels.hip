@@ -958,6 +958,10 @@ __global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(De
 // log p(x|z) sums meet in LDS.
 template <int KTC, bool KEEP, bool PRE, bool QW = false>
 __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs a) {
+#ifdef IWAE_DENSE_STAMPS       // diagnostic build: cycles per phase and wave -> a.stamps[wave][8] (prologue + z | layer 1 | layer 2 | fill | main loop | tail | end)
+    unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int NWV = QW ? 16 : 8, ROWS = QW ? 200 : 128;
     constexpr int UNIT = KTC * 4096 + 1024, NPC = 4 * KTC + 1, NIDX = (NPC + NWV - 1) / NWV, NF = 2 * KTC, P = 4;
@@ -968,6 +972,11 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     const int row = blockIdx.x * ROWS + tile * 16 + rho;
     const bool valid = row < a.M && tile * 16 + rho < ROWS;
     const bool storer = qw <= 0;                          // quarter waves 1..3 recompute tile 12's activations but do not store them
+    // A quarter wave's stage is a short DEPENDENT chain (7 MFMAs into one accumulator, 4 logits per lane, an LDS round trip): sharing
+    // its SIMD's issue round-robin with three full waves, it took LONGER per group than they did (phase stamps: 51.6k vs 41.0k cycles
+    // of main-loop work) and the full waves waited for it at every group boundary (17k cycles, 14 % of the kernel).  Issued first, it
+    // is out of their way instead.
+    if (QW && qw >= 0) __builtin_amdgcn_s_setprio(3);
     const int rowc = min(row, a.M - 1);
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     const int H = a.Np32 >> 5;                  // 32-pixel halves that hold real pixels
@@ -1136,8 +1145,11 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         };
         char* xch1 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096;      // g1 / g2 of the shared tile: 7 KiB each
         char* xch2 = xch1 + KTC * 1024;
+        DS_STAMP(0);
         hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1);
+        DS_STAMP(1);
         hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2, xch1, xch2);
+        DS_STAMP(2);
     }
 
     f32x4 accA[2], accB[2];      // the two tile pairs swap roles every stage (multiply into one, epilogue from the other)
@@ -1280,6 +1292,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     }
     if (fullw) mfma_only(0, 0, accA);      // half 0: MFMAs only
     else if (q_real(0)) q_mfma(0);
+    DS_STAMP(3);
 
     // at the top of an odd half: half h+1 opens group gN -- its weights must have landed, and group gN-1's buffer is free
     // for group gN+1 once every wave is here; the s fragments of the two previous halves go out now (deferred by a group:
@@ -1303,8 +1316,10 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         const int buf = (h >> 1) & 1;
         if (fullw) stage(std::false_type{}, std::true_type{}, accA, accB, h, buf, 2, xbq, xbr, st[0]);          // MFMAs: tiles 2, 3 of this group
         {       // boundary(h + 1, true) with st[1] still holding half h - 1
+            DS_STAMP(4);
             wait_all_vmem();
             __syncthreads();
+            DS_STAMP(7);
             const int gN = (h >> 1) + 1;
             if (2 * (gN + 1) < H) dma_group(gN + 1, buf);
             if (fullw) {
@@ -1315,6 +1330,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         if (fullw) stage(std::false_type{}, std::true_type{}, accB, accA, h + 1, buf ^ 1, 0, xbr, xbq, st[1]);   // tiles 0, 1 of the next group
         else if (q_real(h >> 1)) q_stage(h >> 1, q_real((h >> 1) + 1));
     }
+    DS_STAMP(4);
     for (; h < H; ++h) {        // the last halves (masked epilogue; the very last one has nothing left to multiply)
         const int nh = h + 1, bufN = (nh >> 1) & 1, tbN = (nh & 1) * 2;
         const bool domf = nh < H;
@@ -1339,9 +1355,18 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         q_stage((H - 1) >> 1, false);       // the last group opened at an even half: its epilogue is still due
     }
 
+    DS_STAMP(5);
     float v = rowacc;
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
+#ifdef IWAE_DENSE_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        ds_sum[6] = t_ - ds_prev;
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NWV + wave) * 8 + i] = ds_sum[i];
+    }
+#endif
     if constexpr (QW) {         // tile 12: the four quarter waves' sums, added in wave order
         __syncthreads();        // (every wave is past its last LDS read: buffer 0 is free)
         float* part = (float*)smem;
@@ -3329,7 +3354,7 @@ void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
 // and k large enough that a block's 128 rows span <= BERN_XIMG_MAX images
 bool bern_pipe_ok(const DenseArgs& a) {
     if (a.pre_img1 && (a.pre_KT1 < 1 || a.pre_KT1 > 4)) return false;
-    return a.KT == 7 && a.M >= 8192 && a.mg_per_block >= a.MG && !a.logits_out && !a.stamps && a.lpxz_stride == 0 &&
+    return a.KT == 7 && a.M >= 8192 && a.mg_per_block >= a.MG && !a.logits_out && a.lpxz_stride == 0 &&
            (126 + a.k) / a.k + 1 <= BERN_XIMG_MAX && (a.Np32 >> 5) >= 2 && (a.Np32 >> 5) <= 2 * a.MG &&
            2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128 <= 80 * 1024;
 }

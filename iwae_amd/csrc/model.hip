@@ -172,7 +172,9 @@ struct iwae_model {
     int ds_N = 0;
     int wg_target16_1 = 64;    // same, for layers that are a single block wide (IWAE_WG16_1): the hidden layers' gradients -- with the specialised-wave kernel 64 row splits (12.8 MB of slabs each) beat 128 (0.259 -> 0.249-0.254 ms/step); 48 and 32 are slower again
     int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
-    int wg_target8 = 256;      // same for the 8-wave launches (small row counts: the encoder's layers) (IWAE_WG8)
+    int wg_target8 = 256;      // same for the 8-wave launches on many rows (narrow layers of the 2-layer model) (IWAE_WG8)
+    int wg_target8_few = 32;   // 8-wave launches on < 8 192 rows (the encoder's layers on the batch's images; IWAE_WG8_FEW): the 784-wide first layer in 4 row
+                               // splits instead of 16 (10.6 -> 2.7 MB of slabs each way): 0.2439 -> 0.2351 ms/step at B = 1 024; 8 / 16 / 48: 0.2374 / 0.2374 / 0.2360
     int wg_target16 = 128;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
                                // workgroups (128 KB of LDS); 256 of them lock every CU against the kernels running beside them on the main
                                // stream (256 -> 0.294, 192 -> 0.280, 160 -> 0.279 ms/step while the gradient forked behind out_bwd; forked
@@ -461,7 +463,7 @@ EpsSrc eps_src(iwae_model* m, int layer) {
 // diagnostic (STAMPS=1 build + IWAE_DENSE_STAMPS="<epi>:<KT>"): record the phase stamps of the matching dense launch
 int attach_dense_stamps(iwae_model* m, int epi, DenseArgs& a) {
     if (m->dstamp_epi != epi || m->dstamp_kt != a.KT || (a.M < 4096 && a.KT <= 8)) return IWAE_OK;
-    m->dstamp_waves = ((a.M + 127) / 128) * ((a.MG + a.mg_per_block - 1) / a.mg_per_block) * 4;
+    m->dstamp_waves = std::max(((a.M + 127) / 128) * ((a.MG + a.mg_per_block - 1) / a.mg_per_block) * 4, epi == EPI_BERN ? ((a.M + 127) / 128) * 16 : 0);      // (bern_pipe_kernel: <= 16 waves per 128+ rows)
     CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, m->stream));
     a.stamps = ptr<unsigned long long>(m->dstamps);
     return IWAE_OK;
@@ -548,7 +550,7 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     // 128 -> 0.425, 256 -> 0.406, 384 -> 0.443 ms/step (fewer leaves CUs idle, more pays a full fp32 slab per extra split).
     // Since they run beside the dX chain and with the register-blocked kernel: 160 (see wg_target16); the
     // single-block-wide hidden layers prefer 128.
-    const int target = (nw != 8) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : m->wg_target8;
+    const int target = (nw != 8) ? (blocks == 1 ? m->wg_target16_1 : m->wg_target16) : (chunks < 128 ? m->wg_target8_few : m->wg_target8);
     nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;
     nsplit = (chunks + cps - 1) / cps;
@@ -1722,6 +1724,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     }
     if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
     if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
+    if (const char* e = getenv("IWAE_WG8_FEW")) m->wg_target8_few = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_EPS_BLOCKS")) m->eps_blocks = std::max(0, atoi(e));
     if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
     if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
