@@ -49,7 +49,7 @@ struct DenseArgs {
     const uint16_t* XB; int ldXB; int k; int B; int Xdim;
     // sampled-input mode (dense_kernel<..., ZIN>): z = mu + sigma*eps made in place of reading X (X's layout: ldX = 32*KT)
     const float* zhead; int ldZH;     // encoder head per image [B][ldZH] (mu | sigma at zDp)
-    const float* zeps; int zD, zDp;   // the step's draws fp32 [rows][zDp]; latent width and its padding
+    const float* zeps; int zldE; int zD, zDp;   // the step's draws fp32 [rows][zldE]; latent width and its 32-padding (head layout, z rows)
     uint16_t* ZPout;                  // z as bf16 P-layout [M][ldX] (kept for the weight gradient)
     float* zlp; float* zlq;           // per-row log p(z), log q(z|x)
     float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]

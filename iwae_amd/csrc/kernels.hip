@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
             lp[g] = 0.0f; lq[g] = 0.0f;
             const int b = rowc[g] / a.k;
             const float* hd = a.zhead + (size_t)b * a.ldZH;
-            const float* er = a.zeps + (size_t)rowc[g] * a.zDp;
+            const float* er = a.zeps + (size_t)rowc[g] * a.zldE;
 #pragma unroll
             for (int ks = 0; ks < KTC; ++ks) {
                 float z8[8];
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         if (a.zhead) {      // z = mu + sigma*eps of this row, its prior and posterior log-densities (iwae1.py:59,107,109)
             float lp = 0.0f, lq = 0.0f;
             const float* hd = a.zhead + (size_t)(rowc / a.k) * a.ldZH;
-            const float* er = a.zeps + (size_t)rowc * a.zDp;
+            const float* er = a.zeps + (size_t)rowc * a.zldE;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 zf[ks] = make_uint4(0, 0, 0, 0);

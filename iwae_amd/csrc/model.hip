@@ -441,11 +441,14 @@ struct ScopedTimer {     // records a start/stop event pair around a launch when
     }
 };
 
+// row stride of the cached draws: the latent width rounded to 4, NOT the 32-padded operand width -- D = 100: 400 B instead of 512 B per row,
+// 5.7 MB less per pass over the k = 50, B = 1 024 step's draws (written once, read by the decoder kernel and by latent_bwd_kernel)
+static inline int eps_ld(const iwae_model* m, int layer) { return 4 * ((m->D[layer] + 3) / 4); }
 EpsSrc eps_src(iwae_model* m, int layer) {
     EpsSrc e;
     e.user = nullptr;
     e.cache = m->epsc_ptr[layer];
-    e.ldC = m->Dp[layer];
+    e.ldC = eps_ld(m, layer);
     if (m->user_eps) e.user = ptr<float>(m->epsbuf) + (layer == 0 ? 0 : (size_t)m->k * m->B * m->D[0]);
     e.B = m->B;
     e.seed = m->cfg.seed;
@@ -486,7 +489,7 @@ int dense_fwd(iwae_model* m, Linear& L, int epi, const uint16_t* XP, int rows, u
     a.M = rows; a.KT = L.KT; a.MG = L.MG; a.mg_per_block = (rows <= 8192) ? 1 : L.MG; a.Np32 = L.Np32; a.g1_mask = m->dense_g1_mask;
     a.stage_all = (a.mg_per_block == 1 && L.KT > 8 && (L.KT + 7) / 8 <= 4) ? 1 : 0;
     if (zin) {      // sampled-input mode: the layer makes its own input rows z = mu + sigma*eps (and keeps them in zin->ZP)
-        a.zhead = zin->head; a.ldZH = zin->ldH; a.zeps = zin->eps.cache; a.zD = zin->D; a.zDp = zin->Dp;
+        a.zhead = zin->head; a.ldZH = zin->ldH; a.zeps = zin->eps.cache; a.zldE = zin->eps.ldC; a.zD = zin->D; a.zDp = zin->Dp;
         a.ZPout = zin->ZP; a.zlp = zin->lp_prior; a.zlq = zin->lq; a.k = zin->k;
         a.mg_per_block = L.MG;          // one block owns all out-feature groups of its rows (the z rows are made once)
     }
@@ -670,7 +673,7 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
         CHK(ensure(m->epsc[par][l], (size_t)Mp * m->Dp[l] * 4, m->stream));
         EpsSrc e = eps_src(m, l);
         e.user = nullptr; e.cache = nullptr; e.step = step;
-        launch_eps_gen(e, M, m->D[l], m->Dp[l], ptr<float>(m->epsc[par][l]), gs, max_blocks);
+        launch_eps_gen(e, M, m->D[l], eps_ld(m, l), ptr<float>(m->epsc[par][l]), gs, max_blocks);
     }
     HIPCHK(hipGetLastError());
     tg.valid = true; tg.step = step; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
@@ -865,7 +868,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             // g1, g2 are kept for the backward pass only: a forward-only call (val_step, the k = 5000 evaluator) never reads them back
             a.pre_G1 = bwd ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = bwd ? ptr<uint16_t>(w.g2P) : nullptr;
             if (fuse_z) {
-                a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zD = zin.D; a.zDp = zin.Dp;
+                a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zldE = zin.eps.ldC; a.zD = zin.D; a.zDp = zin.Dp;
                 a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq;
             }
             fuse_dec = bern_pipe_ok(a);
