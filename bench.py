@@ -80,8 +80,10 @@ def kernel_models(cfg):
             flop=2 * M * ((D * H + H * H if big else 0) + H * X), match="bern_pipe_kernel" if big else "dense_kernel<4"),
         "out_bwd": dict(name="out_bwd_s_kernel<7> (output-layer backward from the stored s: dg2 = s W^T, dpre2)",
                         bytes=M * (2 * X + 2 * H + 4 + 2 * H), flop=2 * M * H * X, match="out_bwd_s_kernel"),
-        "decoder_bwd": dict(name="dec_bwd_kernel<7> (decoder dX chain in one launch: dg2 = s W3^T -> dpre2 -> dpre1 -> dz; s, g2, g1 in, dpre2, dpre1, dz out)",
-                            bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + (2 if cfg["layers"] == 1 else 4) * D), flop=2 * M * (H * X + H * H + H * D), match="dec_bwd_kernel"),
+        "decoder_bwd": dict(name=("dec_bwd_rows_kernel (<= 1 024 rows: 16-row workgroups, weights straight from L2)" if M <= 1024 else "dec_bwd_kernel<7>") +
+                                 " (decoder dX chain in one launch: dg2 = s W3^T -> dpre2 -> dpre1 -> dz; s, g2, g1 in, dpre2, dpre1, dz out)",
+                            bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + (2 if cfg["layers"] == 1 else 4) * D), flop=2 * M * (H * X + H * H + H * D),
+                            match="dec_bwd_rows_kernel" if M <= 1024 else "dec_bwd_kernel"),
         "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, side stream)" if big else
                                "wgradp_kernel<8,4,4,4,true> (output-layer weight gradient, side stream)",
                           bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true"),
