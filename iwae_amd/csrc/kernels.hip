@@ -3176,10 +3176,25 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* laye
         const float* p = is_b ? (L.slabB + L.joff + j) : (L.slabW + (size_t)i * L.slab_ld + L.joff + j);
         const size_t stride = is_b ? (size_t)L.slab_ld : L.slab_stride;
         // slab rows start 16-byte aligned (joff, slab_ld multiples of 16 floats): float4 loads; columns >= Nout are pads (zeros / ignored)
+        // 8 slabs' loads in flight per thread, summed in slab order (a 64-split layer was 4 round trips of 4 loads: the kernel's time
+        // was this chain, not its bytes)
+        if (L.nsplit <= 16) {      // few row splits (the encoder's layers): at most 4 loads per thread, all in flight
 #pragma unroll 4
-        for (int sp = sg; sp < L.nsplit; sp += 4) {
-            const float4 v = *(const float4*)(p + (size_t)sp * stride);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            for (int sp = sg; sp < L.nsplit; sp += 4) {
+                const float4 v = *(const float4*)(p + (size_t)sp * stride);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else
+        for (int sp0 = sg; sp0 < L.nsplit; sp0 += 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int sp = sp0 + 4 * u;
+                v[u] = *(const float4*)(p + (size_t)(sp < L.nsplit ? sp : sg) * stride);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sp0 + 4 * u < L.nsplit) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
     }
     red[sg][threadIdx.x & 63] = s;
