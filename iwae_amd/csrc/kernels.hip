@@ -1961,7 +1961,6 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     bool valid[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
-    const int tr_off = (4 * q + (rho >> 2)) * 64 + (((rho & 3) ^ hperm(q)) * 16);
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     constexpr int MG2 = (KTC + 1) / 2;                             // 64-feature groups of the hidden width (32*KTC features)
     const int U1 = a.NG, U2 = U1 + MG2, U3 = U2 + d.MG1;          // unit ranges of the three products
@@ -1970,7 +1969,11 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     auto dma_piece = [&](int u, int idx) {
         const int p = wave + 4 * idx;                 // wave-uniform
         if (p >= NP) return;
-        const char* src = u < U1 ? a.img1 + (size_t)u * unit : u < U2 ? d.imgB2 + (size_t)(u - U1) * unit : d.imgB1 + (size_t)(u - U2) * unit;
+        // product 1 reads W3 from its K-MAJOR image (blocks [pixel k-step][hidden tile]: a pixel group is 2 * MT contiguous 1 KiB blocks, each
+        // ALREADY the A fragment of dg2 = s W3^T): plain conflict-free ds_read_b128, where the MG-major image of W3^T needed two transposing
+        // ds_read_b64_tr_b16 per fragment with their inherent 2-way bank conflict (41 % of this kernel's LDS cycles)
+        if (u < U1 && p >= 2 * MT) return;
+        const char* src = u < U1 ? a.img2 + (size_t)u * (2 * MT * 1024) : u < U2 ? d.imgB2 + (size_t)(u - U1) * unit : d.imgB1 + (size_t)(u - U2) * unit;
         glds16(src + (size_t)p * 1024 + lane * 16,
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (u & 1) * unit) + (uint32_t)p * 1024u)));
     };
@@ -2004,17 +2007,9 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
             wait_all_vmem();
             __syncthreads();
             if (ng + 1 < U1) load_s(ng + 1, sf_n);
-            const char* l2 = smem + buf * unit + tr_off;
+            const char* l2 = smem + buf * unit + a_off;
             lds_pipeline<2 * MT, 8>(
-                [&](int i) {       // A fragment (hidden tile mt, pixel k-step kk) = two transposed 4x16 blocks of pixel tiles 2kk, 2kk+1
-                    const int kk = i / MT, mt = i % MT;
-                    typedef __attribute__((ext_vector_type(4))) short v4s;
-                    const char* p0 = l2 + ((mt >> 1) * 4 + 2 * kk) * 1024 + 8 * (mt & 1);
-                    const v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
-                    const v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 1024));
-                    const uint2 lo = __builtin_bit_cast(uint2, t0), hi = __builtin_bit_cast(uint2, t1);
-                    return make_uint4(lo.x, lo.y, hi.x, hi.y);
-                },
+                [&](int i) { return *(const uint4*)(l2 + i * 1024); },      // A fragment (pixel k-step kk = i / MT, hidden tile mt = i % MT): block kk * MT + mt of the unit
                 [&](int i, const uint4& av) {
 #pragma unroll
                     for (int g = 0; g < 2; ++g) acc2[i % MT][g] = mfma16(av, (i / MT) ? sf[1][g] : sf[0][g], acc2[i % MT][g]);

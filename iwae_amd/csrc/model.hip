@@ -1022,7 +1022,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         }
             // One launch for out_bwd + dX of d2 + dX of d1 (dec_bwd_kernel) where it exists: large row counts, s kept by the forward
             // pass, hidden width with an instantiation; dpre2 / dpre1 stay in registers from product to product.
-            fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && (M >= 8192 || small_fused) && !a.stamps && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
+            fused_dx = m->allow_dec_bwd && m->s_mode && !a.part && (M >= 8192 || small_fused) && !a.stamps && L.kmajor && L.imgB && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 &&
                        m->dec1[0].KT_B == L.KT && m->dec1[1].Kp32 == L.Kp32 && m->dec1[0].Np32 == L.Kp32;
             bool rows_kernel = false;
             if (fused_dx && M <= m->dec_rows_max && m->allow_block_fused && L.kmajor && L.imgB) {      // few rows: 16-row workgroups, weights straight from L2
