@@ -1950,6 +1950,10 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
 // ---------------------------------------------------------------------------------
 template <int KTC>
 __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
+#ifdef IWAE_DENSE_STAMPS       // diagnostic build: cycles per phase and wave -> d.o.stamps[wave][8] (p1 wait | p1 multiply | dpre2 | p2/p3 wait | p2/p3 multiply + epilogue | - | end)
+    unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const OutBwdArgs& a = d.o;
     constexpr int KT = KTC, MT = 2 * KTC;
@@ -2004,8 +2008,10 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
             for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         for (int ng = 0; ng < U1; ++ng) {
             const int buf = ng & 1;
+            DS_STAMP(1);
             wait_all_vmem();
             __syncthreads();
+            DS_STAMP(0);
             if (ng + 1 < U1) load_s(ng + 1, sf_n);
             const char* l2 = smem + buf * unit + a_off;
             lds_pipeline<2 * MT, 8>(
@@ -2023,14 +2029,26 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
                 for (int g = 0; g < 2; ++g) sf[kk][g] = sf_n[kk][g];
         }
         // dpre2 = gx * dg2 * (1 - g2^2); the lane's 8 features of hidden k-step ks are tiles 2ks (j < 4) and 2ks+1 (j >= 4)
+        DS_STAMP(1);
         float gxv[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) gxv[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+        // the stored g2 of the wave's rows: ALL fragments requested before the first is used (one round trip; as a load per use the
+        // 14 of them came back one after the other: 18.6k of the kernel's 107k cycles per wave)
+        uint4 y8a[KT][2];
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) y8a[ks][g] = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(y8a[ks][g].x), "+v"(y8a[ks][g].y), "+v"(y8a[ks][g].z), "+v"(y8a[ks][g].w));
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                const uint4 y8 = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
+                const uint4 y8 = y8a[ks][g];
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -2043,12 +2061,15 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
             }
         }
     }
+    DS_STAMP(2);
     // ---------------- products 2 and 3: Y^T = backward image x X^T with X in registers, one 64-out-feature group per unit
     constexpr int NF = KT * 4, STEP = (NF / NIDX > 0) ? NF / NIDX : 1;
     auto group_mfma = [&](int u, const uint4 (&xin)[KT][2], f32x4 (&acc)[4][2]) {
         const int buf = u & 1;
+        DS_STAMP(4);
         wait_all_vmem();
         __syncthreads();
+        DS_STAMP(3);
         const bool more = u + 1 < U3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -2118,6 +2139,13 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
             }
         }
     }
+#ifdef IWAE_DENSE_STAMPS
+    DS_STAMP(4);
+    wait_all_vmem();
+    DS_STAMP(6);
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ds_sum[i];
+#endif
 }
 
 // dpre2 = gx * (sum of the partial dg2 slices) * (1 - g2^2), elementwise in P order: one thread per 8-feature chunk

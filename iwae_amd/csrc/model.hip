@@ -1052,6 +1052,11 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 // float32 terms to it there and keeps float32)
                 dz_half = !two && m->allow_dz_half;
                 if (dz_half) d.DZH = (uint16_t*)w.dz.p;
+                if (m->dstamp_epi == 9) {      // diagnostic (STAMPS=1 build, IWAE_DENSE_STAMPS=9:0): phase stamps of dec_bwd_kernel
+                    m->dstamp_waves = ((M + 127) / 128) * 4;
+                    CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st));
+                    d.o.stamps = ptr<unsigned long long>(m->dstamps);
+                }
                 ScopedTimer tm(m, T_DEC_BWD);
                 if (!m->serial) set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
                 launch_dec_bwd(d, st);
