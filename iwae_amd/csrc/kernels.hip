@@ -2938,7 +2938,8 @@ __device__ __forceinline__ float sigp_of(const LatentBwdArgs& a, int b, int f) {
 // FAST: the 1-layer training step on the device's own noise (dz as bf16, draws from the step's cache, N(0,1) prior) -- with the
 // sources known at compile time the sample loop's loads are straight-line code and all of them are in flight at once; the general
 // body's run-time source switches made the compiler wait for each iteration's loads in turn (22 us alone for 42 MB).
-template <bool FAST>
+// FAST = 2: the 2-layer model's step (three float32 dz terms, summed here).
+template <int FAST>
 __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
     __shared__ float red[256][8];
     const int nf4 = a.Dp / 4;              // <= 32
@@ -2969,7 +2970,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
             }
         }
         // the sample loop is latency-bound (3 dependent-free loads, little math): keep UN iterations' loads in flight
-        constexpr int UN = 8;
+        constexpr int UN = (FAST == 2) ? 4 : 8;      // (three float32 terms per sample: 4 samples' loads fill the registers)
         for (int s0 = sg; s0 < a.k; s0 += UN * SG) {
             float4 dz[UN], cf[UN];
             float e[UN][4];
@@ -2979,7 +2980,14 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(LatentBwdArgs a) {
                 const bool ok = s < a.k;
                 const int sc = ok ? s : a.k - 1;          // clamped, weighted by 0 below
                 const int row = b * a.k + sc;
-                if constexpr (FAST) {
+                if constexpr (FAST == 2) {
+                    const float4 t1 = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0), t2 = *(const float4*)(a.dz2 + (size_t)row * a.ldDZ + f0),
+                                 t3 = *(const float4*)(a.dz3 + (size_t)row * a.ldDZ + f0);
+                    dz[u] = make_float4(t1.x + t2.x + t3.x, t1.y + t2.y + t3.y, t1.z + t2.z + t3.z, t1.w + t2.w + t3.w);
+                    cf[u] = a.cf[row];
+                    const float4 ev = *(const float4*)(a.eps.cache + (size_t)row * a.eps.ldC + f0);
+                    e[u][0] = ev.x; e[u][1] = ev.y; e[u][2] = ev.z; e[u][3] = ev.w;
+                } else if constexpr (FAST == 1) {
                     const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0);
                     dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y));
                     cf[u] = a.cf[row];
@@ -3531,8 +3539,9 @@ void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sam
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_lse(const LseArgs& a, hipStream_t st) { LAUNCH_EV(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
-    if (a.dzh && !a.dz2 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<true>, dim3(a.Bp), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(latent_bwd_kernel<false>, dim3(a.Bp), dim3(256), 0, st, a);
+    if (a.dzh && !a.dz2 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<1>, dim3(a.Bp), dim3(256), 0, st, a);
+    else if (!a.dzh && a.dz && a.dz2 && a.dz3 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<2>, dim3(a.Bp), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(latent_bwd_kernel<0>, dim3(a.Bp), dim3(256), 0, st, a);
 }
 void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
