@@ -2798,6 +2798,16 @@ __global__ void lse_kernel(LseArgs a) {
     if (b >= a.B) return;
     const int k = a.k;
     const bool single = k <= 64;          // one sample per lane: log_w stays in a register between the passes
+    // the image's head (for the KL term at the end): requested first, so that its round trip runs beside the log_w terms' instead of
+    // behind the whole kernel
+    float kmu[2] = {0.0f, 0.0f}, ksg[2] = {1.0f, 1.0f};
+    if (a.head) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = lane + 64 * i;
+            if (f < a.D) { kmu[i] = a.head[(size_t)b * a.ldH + f]; ksg[i] = a.head[(size_t)b * a.ldH + a.Dp + f]; }
+        }
+    }
     float lw_reg = 0.0f;
     float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
     for (int s = lane; s < k; s += 64) {
@@ -2869,7 +2879,14 @@ __global__ void lse_kernel(LseArgs a) {
     // KL(q(z|x) || N(0,1)) per image (iwae1.py:116), TFP closed form
     float kl = 0.0f;
     if (a.head) {
-        for (int f = lane; f < a.D; f += 64) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (lane + 64 * i < a.D) {
+                const float ls = __logf(ksg[i]);
+                kl += 0.5f * kmu[i] * kmu[i] + 0.5f * expm1f(2.0f * ls) - ls;
+            }
+        }
+        for (int f = lane + 128; f < a.D; f += 64) {      // (latent widths beyond 128)
             const float mu = a.head[(size_t)b * a.ldH + f], sg = a.head[(size_t)b * a.ldH + a.Dp + f];
             const float ls = __logf(sg);
             kl += 0.5f * mu * mu + 0.5f * expm1f(2.0f * ls) - ls;
