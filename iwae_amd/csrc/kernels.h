@@ -84,6 +84,11 @@ struct BlockFwdArgs {                 // block_fwd_kernel: one BasicBlock on R <
     uint16_t *H1, *H2; int ldH;       // hidden activations, P-layout [R][32*KT1]
     float* YF; int ldYF; int split;   // head, fp32 [R][ldYF]; out-features >= split are the sigma head
     int sample; SampleArgs S;         // sample != 0: the input rows are z = mu + sigma*eps made HERE (sample_kernel's job, without its launch): S.Dp = 32*KT0
+    // oimg != null (decoder on few rows, NT2 = 0): the Bernoulli output layer follows in the same launch -- logits = h2 W3 + c3 from the MG-major
+    // image oimg (KT1 k-steps), log p(x|z) per row -> olpxz, s = x - sigmoid(l) -> oSP (P-layout [R][oldS], or null: forward-only call)
+    const char* oimg; int oXdim, oH;  // pixels, 32-pixel halves that hold real pixels
+    const uint16_t* oXB; int oldXB; int ok;   // x as bf16 P-layout [B][oldXB]; samples per image (row r belongs to image r / ok)
+    uint16_t* oSP; int oldS; float* olpxz;
 };
 struct DecBwdRowsArgs {               // dec_bwd_rows_kernel: the decoder's dX chain on few rows (16-row workgroups, weights straight from L2)
     const uint16_t* SP; int ldS; int KTX;     // s = x - sigmoid(l), P-layout [M][ldS], KTX = ldS/32 pixel k-steps

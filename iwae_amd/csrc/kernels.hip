@@ -621,8 +621,8 @@ __global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) v
 //     a layer's output goes back there (and to HBM for the backward pass) as bf16, 8 bytes per lane.
 // ---------------------------------------------------------------------------------
 #define BLOCKFWD_MAX_KT 8      // k-steps of the two later layers (hidden <= 256)
-template <int AD>
-__global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void block_fwd_kernel(BlockFwdArgs a) {
+template <int AD, bool OUT = false>
+__global__ __launch_bounds__(1024, ((AD > 6 || OUT) ? 2 : 5)) void block_fwd_kernel(BlockFwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -768,6 +768,49 @@ __global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void block_fwd_kernel(Block
         for (int i = 0; i < 4; ++i)
             if (f0 + i >= a.split) o[i] = exp2_raw(o[i] * LOG2E_F) + 1e-6f;
         *(float4*)(a.YF + (size_t)row * a.ldYF + f0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if constexpr (OUT) {
+        // ---- the Bernoulli output layer of the decoder on the tile's 16 rows (iwae1.py:83,111): wave w takes the 32-pixel halves w, w + 16 of the
+        // pixel range -- two accumulator tiles each, weight fragments straight from the L2-resident image, g2 from LDS (act2, complete behind
+        // the barrier above) -- and bern8's epilogue; the rows' sums over the waves meet in LDS in wave order.
+        float rowacc = 0.0f;
+        const int bimg = min(row, a.R - 1) / a.ok;
+        for (int h = wave; h < a.oH; h += 16) {
+            const int mg = h >> 1, tg = 2 * (h & 1);
+            const char* wb = a.oimg + (size_t)mg * img_mg_group_bytes(a.KT1) + a_off;
+            uint4 A0[BLOCKFWD_MAX_KT], A1v[BLOCKFWD_MAX_KT];
+#pragma unroll
+            for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+                A0[ks] = make_uint4(0, 0, 0, 0); A1v[ks] = make_uint4(0, 0, 0, 0);
+                if (ks < a.KT1) { A0[ks] = *(const uint4*)(wb + (size_t)(ks * 4 + tg) * 1024); A1v[ks] = *(const uint4*)(wb + (size_t)(ks * 4 + tg + 1) * 1024); }
+            }
+            const float* bb = (const float*)(a.oimg + (size_t)mg * img_mg_group_bytes(a.KT1) + (size_t)a.KT1 * 4096) + 16 * tg + 4 * q;
+            const float4 c0 = *(const float4*)bb, c1 = *(const float4*)(bb + 16);
+            const uint4 xb = *(const uint4*)(a.oXB + (size_t)bimg * a.oldXB + 32 * h + 8 * q);
+            f32x4 l0 = (f32x4){c0.x, c0.y, c0.z, c0.w}, l1 = (f32x4){c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+                if (ks < a.KT1) {
+                    const uint4 bv = *(const uint4*)(act2 + ks * 1024 + a_off);
+                    l0 = mfma16(A0[ks], bv, l0);
+                    l1 = mfma16(A1v[ks], bv, l1);
+                }
+            uint4 sp = make_uint4(0, 0, 0, 0);
+            const bool full = 32 * h + 32 <= a.oXdim;
+            if (a.oSP) rowacc += full ? bern8<false, true>(l0, l1, xb, 32 * h + 4 * q, a.oXdim, sp) : bern8<true, true>(l0, l1, xb, 32 * h + 4 * q, a.oXdim, sp);
+            else rowacc += full ? bern8<false, false>(l0, l1, xb, 32 * h + 4 * q, a.oXdim, sp) : bern8<true, false>(l0, l1, xb, 32 * h + 4 * q, a.oXdim, sp);
+            if (a.oSP && valid) *(uint4*)(a.oSP + (size_t)row * a.oldS + 32 * h + 8 * q) = sp;
+        }
+        rowacc += __shfl_xor(rowacc, 16);
+        rowacc += __shfl_xor(rowacc, 32);
+        float* red2 = (float*)act0;        // (the input tile is no longer read: every wave is past the second barrier)
+        if (q == 0) red2[wave * 16 + rho] = rowacc;
+        __syncthreads();
+        if (wave == 0 && q == 0 && valid) {
+            float v = 0.0f;
+            for (int w = 0; w < 16; ++w) v += red2[w * 16 + rho];
+            a.olpxz[row] = v;
+        }
     }
 }
 
@@ -3390,6 +3433,7 @@ static bool launch_dense_g1(int epi, const DenseArgs& a, dim3 grid, size_t lds, 
 }
 bool block_fwd_ok(const BlockFwdArgs& a) {
     if (a.sample && (a.S.Dp != 32 * a.KT0 || a.KT0 > 15 || !a.S.ZP || a.S.ZF || a.S.M != a.R)) return false;
+    if (a.oimg && (a.NT2 != 0 || a.oH < 1 || !a.oXB || !a.olpxz || a.ok < 1)) return false;
     return a.R <= 4096 && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT2 <= 16 && a.NT1 == 2 * a.KT1 &&
            (size_t)(a.KT0 + 2 * a.KT1) * 1024 <= 150 * 1024;
 }
@@ -3410,6 +3454,7 @@ void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(a.KT0 + 2 * a.KT1) * 1024 + (a.sample ? (size_t)a.KT0 * 768 : 0);
     // a handful of workgroups and a long first layer (the encoder on <= 512 images): 13 weight fragments in flight per wave instead of
     // 6 (the 25 k-steps of the 784-pixel layer in two round trips to L2 instead of five) -- at the price of the whole CU's registers
+    if (a.oimg) { hipLaunchKernelGGL((block_fwd_kernel<6, true>), dim3((a.R + 15) / 16), dim3(1024), lds, st, a); return; }
     if (a.R <= 512 && a.KT0 > 8) hipLaunchKernelGGL((block_fwd_kernel<13>), dim3((a.R + 15) / 16), dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((block_fwd_kernel<6>), dim3((a.R + 15) / 16), dim3(1024), lds, st, a);
 }

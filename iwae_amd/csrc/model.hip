@@ -234,6 +234,7 @@ struct iwae_model {
     bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
+    bool allow_out_in_block = true;  // IWAE_NO_OUT_IN_BLOCK=1: the output layer of a few-row decoder stays a dense_kernel<EPI_BERN> launch (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
     int num_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool bern_qw_force = false;      // IWAE_BERN_QW_FORCE=1: that shape at every row count it exists for (tests)
@@ -834,7 +835,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // in turn is 40 us of latency -- one pixel group per block instead, log p(x|z) as per-group partial sums that
         // lse_kernel adds up in fixed order
         m->px_parts = 1;
-        if (M < 8192 && L.MG > 1) {
+        // few rows: the output layer runs inside block_fwd_kernel, behind the two tanh layers of the same 16-row tile (one launch for the
+        // whole decoder; log p(x|z) per row comes out whole, not as per-group partial sums)
+        const bool out_in_block = m->allow_block_fused && m->allow_out_in_block && !fuse_z && M <= 4096 && !(want && want->logits) && !m->want_stamps &&
+                                  m->dec1[1].Np32 == m->dec1[0].Np32 && m->dec1[1].Kp32 == m->dec1[0].Np32 && L.Kp32 == m->dec1[1].Np32 && L.KT == m->dec1[1].KT && L.KT <= 8;
+        if (M < 8192 && L.MG > 1 && !out_in_block) {
             a.mg_per_block = 1;
             m->px_parts = L.MG;
             CHK(ensure(m->px_part, (size_t)L.MG * Mp * 4, st));
@@ -878,6 +883,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             }
         }
         if (fuse_dec && sample_in_block) { launch_sample(zin, st); sample_in_block = false; }
+        bool out_done = false;
         if (!fuse_dec) {
             // few rows: the two tanh layers as ONE launch of block_fwd_kernel (a BasicBlock without its head: 16-row workgroups,
             // weights straight from the L2-resident images) instead of two latency-bound dense_kernel launches
@@ -890,7 +896,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                 bf.H1 = ptr<uint16_t>(w.g1P); bf.H2 = ptr<uint16_t>(w.g2P); bf.ldH = m->dec1[0].Np32;
                 bf.YF = nullptr; bf.ldYF = 0; bf.split = 1 << 30;
                 if (sample_in_block) { bf.sample = 1; bf.S = zin; }
-                if (block_fwd_ok(bf)) { launch_block_fwd(bf, st); two_in_one = true; sample_in_block = false; }
+                if (out_in_block) {
+                    bf.oimg = L.imgF; bf.oXdim = X; bf.oH = L.Np32 >> 5; bf.oXB = ptr<uint16_t>(m->xP); bf.oldXB = Xinp; bf.ok = k;
+                    bf.oSP = m->s_mode ? ptr<uint16_t>(m->wdec1.dlP) : nullptr; bf.oldS = Xp; bf.olpxz = lpxz;
+                }
+                if (block_fwd_ok(bf)) {
+                    ScopedTimer tm(m, T_DEC_FWD);
+                    launch_block_fwd(bf, st); two_in_one = true; sample_in_block = false; out_done = out_in_block;
+                }
             }
             if (sample_in_block) { launch_sample(zin, st); sample_in_block = false; }      // (shapes the fused kernel does not cover)
             if (!two_in_one) {
@@ -904,8 +917,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
             // a cross-stream hand-off takes now pass beside the main stream's lse_kernel, not behind it.
             m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two && !m->serial;
-            m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1;
-            { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
+            m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1 && !out_done;
+            if (!out_done) { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
             if (m->lse_dup && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
         HIPCHK(hipGetLastError());
         // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
@@ -1723,6 +1736,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (const char* e = getenv("IWAE_EVAL_ROWS")) m->eval_rows = std::max(64, atoi(e));
     m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
     m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
+    m->allow_out_in_block = getenv("IWAE_NO_OUT_IN_BLOCK") == nullptr;
     m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
     m->bern_qw = getenv("IWAE_NO_BERN_QW") == nullptr;
     m->bern_qw_force = getenv("IWAE_BERN_QW_FORCE") != nullptr;

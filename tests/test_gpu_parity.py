@@ -228,7 +228,7 @@ def test_kernel_variants_agree(gpu, monkeypatch, B, k):
     round 2: the decoder's dX chain as three launches instead of dec_bwd_kernel, the general weight-gradient kernel instead of the
     specialised-wave one and that one's 8 + 8-wave shape, one side stream instead of two, the grouped launch of the hidden layers'
     gradients, one lse_kernel instead of the side stream's own copy; the per-pixel-group dX kernels at small row counts; the decoder's
-    dX chain by dec_bwd_kernel at few rows and by dec_bwd_rows_kernel at many."""
+    dX chain by dec_bwd_kernel at few rows and by dec_bwd_rows_kernel at many; the few-row decoder's output layer as its own launch."""
     x = O.synthetic_binarized(B, 3)
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
 
@@ -249,7 +249,7 @@ def test_kernel_variants_agree(gpu, monkeypatch, B, k):
     for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
                 {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"},
                 {"IWAE_NO_DEC_BWD": "1"}, {"IWAE_NO_WG7": "1"}, {"IWAE_WG9": "3"}, {"IWAE_NO_SIDE2": "1"}, {"IWAE_WG_GROUP": "1"}, {"IWAE_NO_LSE_DUP": "1"}, {"IWAE_DZ_F32": "1"}, {"IWAE_NO_SMALL_DEC_BWD": "1"},
-                {"IWAE_DEC_ROWS": "0"}, {"IWAE_DEC_ROWS": "16384"}):
+                {"IWAE_DEC_ROWS": "0"}, {"IWAE_DEC_ROWS": "16384"}, {"IWAE_NO_OUT_IN_BLOCK": "1"}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
