@@ -73,11 +73,13 @@ def kernel_models(cfg):
     big = M >= 8192
     out = {
         "decoder_fwd": dict(
-            name=("bern_pipe_kernel<7,true,true,*> (whole decoder forward in one launch: " if big else "dense_kernel<EPI_BERN> (output layer: ") +
-                 ("z = mu + sigma*eps, " if fused_z else "") + ("two tanh layers, " if big else "") +
+            name=("bern_pipe_kernel<7,true,true,*> (whole decoder forward in one launch: " if big else
+                  "block_fwd_kernel<6,true> (few rows: whole decoder forward in one launch: " if M <= 4096 else "dense_kernel<EPI_BERN> (output layer: ") +
+                 ("z = mu + sigma*eps, " if (fused_z or M <= 4096) else "") + ("two tanh layers, " if (big or M <= 4096) else "") +
                  "Bernoulli log-likelihood, keeps s = x - sigmoid(l))",
-            bytes=M * (zin + (4 * H if big else 2 * H) + 2 * X + 4),
-            flop=2 * M * ((D * H + H * H if big else 0) + H * X), match="bern_pipe_kernel" if big else "dense_kernel<4"),
+            bytes=M * (zin + (4 * H if (big or M <= 4096) else 2 * H) + 2 * X + 4),
+            flop=2 * M * ((D * H + H * H if (big or M <= 4096) else 0) + H * X),
+            match="bern_pipe_kernel" if big else "block_fwd_kernel<6, true" if M <= 4096 else "dense_kernel<4"),
         "out_bwd": dict(name="out_bwd_s_kernel<7> (output-layer backward from the stored s: dg2 = s W^T, dpre2)",
                         bytes=M * (2 * X + 2 * H + 4 + 2 * H), flop=2 * M * H * X, match="out_bwd_s_kernel"),
         "decoder_bwd": dict(name=("dec_bwd_rows_kernel (<= 1 024 rows: 16-row workgroups, weights straight from L2)" if M <= 1024 else "dec_bwd_kernel<7>") +
