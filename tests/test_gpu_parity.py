@@ -196,17 +196,18 @@ def test_two_layer_large_row_count_matches_oracle(gpu, B, k, obj):
     m.close()
 
 
-def test_device_noise_step_matches_oracle_on_the_same_draws(gpu):
+@pytest.mark.parametrize("B,k,nh,nl", [(170, 50, 200, 100), (20, 3, 200, 100), (9, 4, 64, 10), (6, 5, 64, 2)])
+def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl):
     """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
-    decoder layer making z = mu + sigma*eps itself) against the oracle fed the same draws, restated on the host from the
-    published Philox4x32-10 + Box-Muller (oracle/philox_np.py).  The host draws are float64, the device's float32: the
-    tolerances are the bf16-emulation ones."""
-    B, k, step = 170, 50, 9
+    decoder layer making z = mu + sigma*eps itself; on few rows block_fwd_kernel's sampling mode) against the oracle fed the same
+    draws, restated on the host from the published Philox4x32-10 + Box-Muller (oracle/philox_np.py).  The host draws are float64,
+    the device's float32: the tolerances are the bf16-emulation ones.  Latent widths 10 and 2: cached draws in rows of 12 / 4 floats."""
+    step = 9
     x = O.synthetic_binarized(B, 23)
-    P = O.init_params(1, 200, 100, 29, x_mean=O.synthetic_pixel_means())
-    eps = philox_np.device_eps(123, step, B, k, 100)                     # [k, B, D], seed 123 = _model's
+    P = O.init_params(1, nh, nl, 29, x_mean=O.synthetic_pixel_means())
+    eps = philox_np.device_eps(123, step, B, k, nl)                      # [k, B, D], seed 123 = _model's
     res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
-    m = _model(1, 200, 100)
+    m = _model(1, nh, nl)
     m.set_params(O.flatten_params(P))
     m.set_step(step, 0)
     r = m.forward_backward(x, k, 1.0, "iwae_elbo", want=("lpxz", "lpz", "lqzx", "z"))
