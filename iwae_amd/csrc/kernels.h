@@ -52,6 +52,7 @@ struct DenseArgs {
     const float* zeps; int zldE; int zD, zDp;   // the step's draws fp32 [rows][zldE]; latent width and its 32-padding (head layout, z rows)
     uint16_t* ZPout;                  // z as bf16 P-layout [M][ldX] (kept for the weight gradient)
     float* zlp; float* zlq;           // per-row log p(z), log q(z|x)
+    float* zlq_dreg;                  // DReG (tasks/task02.py:63-65): log q(z|x) with sigma + 1e-6 as the scale, or null (bern_pipe_kernel's prologue only)
     float* lpxz; size_t lpxz_stride;  // log p(x|z) per row; stride > 0: block row y of the grid writes its partial sum to lpxz[y*stride + row]
     float* logits_out;
     int pipe;                         // EPI_BERN: take bern_pipe_kernel where it exists (IWAE_NO_BERN_PIPE=1 clears it)

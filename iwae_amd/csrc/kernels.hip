@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         const int KT1 = a.pre_KT1, ldZ = 32 * KT1;       // <= 4 k-steps of latent features
         uint4 zf[4];
         if (a.zhead) {      // z = mu + sigma*eps of this row, its prior and posterior log-densities (iwae1.py:59,107,109)
-            float lp = 0.0f, lq = 0.0f;
+            float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
             const float* hd = a.zhead + (size_t)(rowc / a.k) * a.ldZH;
             const float* er = a.zeps + (size_t)rowc * a.zldE;
 #pragma unroll
@@ -1106,6 +1106,10 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                                 z = fmaf(sgv[i], ev[i], muv[i]);
                                 lp += -0.5f * z * z - 0.5f * LOG2PI_F;
                                 lq += -0.5f * ev[i] * ev[i] - 0.5f * LOG2PI_F - __logf(sgv[i]);
+                                if (a.zlq_dreg) {                                    // tasks/task02.py:63-65 (sample_kernel's arithmetic)
+                                    const float s2 = sgv[i] + 1e-6f, u2 = (z - muv[i]) * __builtin_amdgcn_rcpf(s2);
+                                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
+                                }
                             }
                             z8[4 * h + i] = z;
                         }
@@ -1117,7 +1121,8 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             }
             lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
             lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
-            if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; }
+            lq2 += __shfl_xor(lq2, 16); lq2 += __shfl_xor(lq2, 32);
+            if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; if (a.zlq_dreg) a.zlq_dreg[row] = lq2; }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {

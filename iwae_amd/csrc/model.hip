@@ -790,7 +790,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
         s.lq_dreg = want_dreg ? lqd : nullptr;
         // 1-layer training step on the device's own noise: the first decoder layer makes z itself (dense_kernel ZIN mode)
-        fuse_z = m->allow_zin && !two && m->C == 0 && bwd && !want_dreg && s.eps.cache != nullptr && M >= 8192 &&
+        // (the DReG step too: the decoder kernel's prologue also sums the second log q; if that kernel turns out not to apply, sample_kernel runs after all)
+        fuse_z = m->allow_zin && !two && m->C == 0 && bwd && s.eps.cache != nullptr && M >= 8192 &&
                  (m->dec1[0].KT == 4 || m->dec1[0].KT == 2) && m->dec1[0].Kp32 == m->Dp[0];
         // few rows: block_fwd_kernel (the decoder's two tanh layers in one launch, below) makes z itself -- one latency-bound launch less
         sample_in_block = m->allow_block_fused && m->allow_zin && !two && !fuse_z && M <= 4096 && !s.ZF && m->dec1[0].Kp32 == m->Dp[0];
@@ -874,14 +875,15 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.pre_G1 = bwd ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = bwd ? ptr<uint16_t>(w.g2P) : nullptr;
             if (fuse_z) {
                 a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zldE = zin.eps.ldC; a.zD = zin.D; a.zDp = zin.Dp;
-                a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq;
+                a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq; a.zlq_dreg = zin.lq_dreg;
             }
             fuse_dec = bern_pipe_ok(a);
             if (!fuse_dec) {
                 a.pre_img1 = a.pre_img2 = nullptr; a.pre_Z = nullptr; a.pre_G1 = a.pre_G2 = nullptr; a.pre_KT1 = 0;
-                a.zhead = nullptr; a.zeps = nullptr; a.ZPout = nullptr; a.zlp = a.zlq = nullptr;
+                a.zhead = nullptr; a.zeps = nullptr; a.ZPout = nullptr; a.zlp = a.zlq = nullptr; a.zlq_dreg = nullptr;
             }
         }
+        if (fuse_z && zin.lq_dreg && !fuse_dec) { launch_sample(zin, st); fuse_z = false; }      // (dense_kernel's sampled-input mode has no DReG sum)
         if (fuse_dec && sample_in_block) { launch_sample(zin, st); sample_in_block = false; }
         bool out_done = false;
         if (!fuse_dec) {
