@@ -196,8 +196,9 @@ def test_two_layer_large_row_count_matches_oracle(gpu, B, k, obj):
     m.close()
 
 
-@pytest.mark.parametrize("B,k,nh,nl", [(170, 50, 200, 100), (20, 3, 200, 100), (9, 4, 64, 10), (6, 5, 64, 2)])
-def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl):
+@pytest.mark.parametrize("B,k,nh,nl,obj", [(170, 50, 200, 100, "iwae_elbo"), (20, 3, 200, 100, "iwae_elbo"), (9, 4, 64, 10, "iwae_elbo"), (6, 5, 64, 2, "iwae_elbo"),
+                                           (170, 50, 200, 100, "dreg"), (20, 3, 200, 100, "dreg")])
+def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl, obj):
     """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
     decoder layer making z = mu + sigma*eps itself; on few rows block_fwd_kernel's sampling mode) against the oracle fed the same
     draws, restated on the host from the published Philox4x32-10 + Box-Muller (oracle/philox_np.py).  The host draws are float64,
@@ -206,16 +207,18 @@ def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl):
     x = O.synthetic_binarized(B, 23)
     P = O.init_params(1, nh, nl, 29, x_mean=O.synthetic_pixel_means())
     eps = philox_np.device_eps(123, step, B, k, nl)                      # [k, B, D], seed 123 = _model's
-    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
+    res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, obj, rnd=O.bf16_round)
     m = _model(1, nh, nl)
     m.set_params(O.flatten_params(P))
     m.set_step(step, 0)
-    r = m.forward_backward(x, k, 1.0, "iwae_elbo", want=("lpxz", "lpz", "lqzx", "z"))
+    r = m.forward_backward(x, k, 1.0, obj, want=("lpxz", "lpz", "lqzx", "z"))
     np.testing.assert_allclose(r["z"], res_e["z"], rtol=0, atol=1e-2)
     for key in ("lpxz", "lpz", "lqzx"):
         assert np.max(np.abs(r[key] - res_e[key])) < EMU_ROW_ATOL, key
-    for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+    for key in (("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "iwae_elbo", "iwae_eq14")):
         assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    if obj == "dreg":      # (tasks/task02.py:61-76; at >= 8 192 rows the second log q is summed in the decoder kernel's prologue)
+        assert abs(r["inference_loss"] - res_e["inference_loss"]) < 5e-3 * abs(res_e["inference_loss"]) + 0.05
     assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
     m.close()
 
