@@ -23,7 +23,11 @@ import numpy as np
 import torch
 
 X_DIM = 784
-TIMING_EVERY = 8             # HIP events bracket the timed kernels on every 8th step of the timed region
+TIMING_EVERY = 2             # the per-kernel pass AFTER the timed region: HIP events bracket the timed kernels on every 2nd step
+TIMING_STEPS = 48            # steps of that pass (>= 16 launches per kernel; an event record costs a few us of stream bubble,
+                             # so none of it happens inside the timed region)
+SETTLE_STEPS = 100           # untimed steps run in any case before the timed region (--warmup if that is larger): clocks ramped, the noise
+                             # ring primed, every buffer at its final size.  A fixed COUNT: every rank must issue the same collectives
 PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain device copy reaches ~4.8 TB/s on this box
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
 PEAK_FP32_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 (precision fp32)
@@ -202,7 +206,17 @@ def run():
     ap.add_argument("--precision", choices=("bf16", "fp32"), default="bf16", help="GEMM arithmetic (iwae_config.precision); the headline is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-llh-eval", action="store_true", help="skip the untimed k = 5000 evaluator run (profiling: keeps its kernels out of the statistics)")
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS, help="untimed steps in front of the timed region in any case (profiling scripts pass 0: then exactly --warmup)")
+    ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel event pass behind the timed region (profiling)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="iwae_set_option switch for A/B measurements (repeatable; tools/README.md)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearse the data-parallel code path with ONE rank (trivial collectives)")
+    ap.add_argument("--dp-torch", action="store_true", help="data-parallel exchange through torch.distributed.all_reduce instead of the library's own RCCL calls")
     args = ap.parse_args()
+    force_dist = args.force_dist or bool(os.environ.get("IWAE_BENCH_FORCE_DIST"))
+    options = {}
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        options[name] = int(val or "1")
     cfg = CONFIGS[args.config]
     B, K = cfg["B"], cfg["k"]
 
@@ -213,7 +227,7 @@ def run():
         raise SystemExit("--gpus %d needs torchrun with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or os.environ.get("IWAE_BENCH_FORCE_DIST"):      # the env switch rehearses the RCCL path on one GPU
+    if world > 1 or force_dist:      # --force-dist rehearses the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -225,19 +239,26 @@ def run():
     lo = rank * B
     x_dev = torch.tensor(x_np[lo:lo + B], device="cuda")       # inputs resident in HBM before timing
     net = NativeModel(cfg["layers"], cfg["nh"], cfg["nl"], x_dim=X_DIM, device=local_rank, seed=123, world_size=world, rank=rank,
-                      precision=args.precision)
+                      precision=args.precision, options=options)
     net.set_output_bias(utils.bias_from_mean(p))                       # identical init on every rank (same seed)
-    dp = DataParallelStep(net, rank, world)
+    # world > 1: the in-library RCCL exchange, or an exception on every rank -- never a silent fallback (iwae_amd/parallel.py)
+    dp = DataParallelStep(net, rank, world, in_library=not args.dp_torch, force_dist=force_dist)
+    rccl_ranks = net.comm_info()[0] if dp.in_library else (dist.get_world_size() if dist and dp.path == "torch_fallback" else 0)
     lr = 1e-3
     obj_id = OBJ_ID[cfg["obj"]]
 
     def step():
         dp.step(x_dev.data_ptr(), B, K, 1.0, lr, obj_id)
 
-    for _ in range(args.warmup):
+    # untimed: --warmup steps, and in any case enough steps / time for the clocks, the noise ring and the allocator to settle
+    # (the driver's --warmup 5 alone left the timed region 7-11 % slower than a 200-step run of the same build)
+    settle = max(args.warmup, args.settle)
+    for i in range(settle):
         step()
+        if i % 16 == 15:
+            net.sync()
+    net.sync()
     torch.cuda.synchronize()
-    net.enable_timing(int(os.environ.get("IWAE_BENCH_TIMING", TIMING_EVERY)))
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -254,9 +275,16 @@ def run():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # per-kernel launch durations: a SEPARATE pass behind the timed region (HIP events on the stream each kernel runs on)
     models = kernel_models(cfg)
-    ktimes = {k: net.kernel_time(k) for k in models}
-    net.enable_timing(0)
+    ktimes = {k: (0.0, 0) for k in models}
+    if not args.no_kernel_times:
+        net.enable_timing(int(os.environ.get("IWAE_BENCH_TIMING", TIMING_EVERY)))
+        for _ in range(TIMING_STEPS):
+            step()
+        net.sync()
+        ktimes = {k: net.kernel_time(k) for k in models}
+        net.enable_timing(0)
     elbo = net.forward(x_np[lo:lo + B], K)["iwae_elbo"]
     llh_eval = None
     if world == 1 and not args.no_llh_eval and cfg["layers"] == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
@@ -293,6 +321,8 @@ def run():
             "config": {"workload": cfg["label"] + ", objective %s, train step = forward + backward + Adam(eps=1e-4)" % cfg["obj"]
                                    + (" + RCCL all-reduce of the flat fp32 gradient" if world > 1 else ""),
                        "config_id": args.config, "global_batch": B * world, "n_samples": K, "parallelism": "dp%d" % world,
+                       # which exchange path ran, and over how many ranks RCCL itself says (ncclCommCount on the library's communicator)
+                       "dp_path": dp.path, "rccl_ranks": rccl_ranks, "settle_steps": settle, "options": options,
                        "step_gemm_tflops": round(flop_step * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3), "llh_eval_k5000": llh_eval},
         }

@@ -60,7 +60,8 @@ typedef struct {
     int32_t device;            /* HIP device ordinal */
     uint64_t seed;             /* Philox key for the reparameterisation noise (main.py:40-41 seeds TF) */
     int32_t world_size;        /* data-parallel ranks (1 = single GPU); iwae_comm_init must be given the same values */
-    int32_t rank;              /* this process's rank: images [rank*B, (rank+1)*B) of every global batch (noise keys) */
+    int32_t rank;              /* this process's rank (checked against iwae_comm_init).  The library does NOT derive noise keys from it:
+                                  the caller passes the global index of the shard's first image, rank*B, through iwae_set_step */
     int32_t cond_dim;          /* 0, or C > 0: the conditional model of tasks/task05.py:101-168 (1-layer only): the encoder
                                   sees concat(x, y), the decoder concat(z, y), y [B, C] set with iwae_set_condition
                                   (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
@@ -164,15 +165,21 @@ int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /*
  * Rank 0 obtains an opaque id blob (iwae_comm_unique_id: RCCL ncclGetUniqueId, one per internal communicator), the caller
  * ships it to the other ranks by any means (MPI, a file, torch.distributed's store), and EVERY rank calls iwae_comm_init
  * with it (collective: ncclCommInitRank).  From then on iwae_train_step / iwae_train_step_dataset take the rank's shard
- * of the global batch (B = global batch / world_size images; noise keyed by the global image index: batch_offset of
- * iwae_set_step + rank * B) and all-reduce the flat fp32 gradient with ncclAllReduce on the library's own streams before Adam
- * (grad_scale 1/world_size, identical on every rank: replicas stay bit-identical): the decoder's segment (done early, on the
+ * of the global batch (B = global batch / world_size images) and all-reduce the flat fp32 gradient with ncclAllReduce on the
+ * library's own streams before Adam.  NOISE KEYS ARE THE CALLER'S JOB: the draws of an image are keyed by its global index,
+ * batch_offset + row, and the library never adds rank * B itself -- every rank must call
+ * iwae_set_step(step, global_batch_offset + rank * B) before each step (main.py and iwae_amd/parallel.py do), otherwise all ranks
+ * draw the same noise and N ranks no longer reproduce what one rank would compute on the whole batch.  Adam runs with
+ * grad_scale 1/world_size, identical on every rank (replicas stay bit-identical): the decoder's segment (done early, on the
  * side stream) is exchanged and applied there, beside the encoder's backward pass and the next encoder forward, exactly as
  * the single-GPU step defers it; the encoder's segment follows on the main stream.  RCCL is loaded at run time (dlopen):
  * the library itself does not link against it.  iwae_comm_destroy (or iwae_destroy) releases the communicators. */
 int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes);
 int iwae_comm_init(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
 int iwae_comm_destroy(iwae_handle h);
+/* what RCCL itself reports for the handle's communicators (ncclCommCount / ncclCommUserRank): *world_size = 0, *rank = -1 when
+ * the handle has none.  bench.py records it so a multi-GPU line shows which exchange path ran and over how many ranks. */
+int iwae_comm_info(iwae_handle h, int32_t* world_size, int32_t* rank);
 
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
  * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
@@ -206,6 +213,11 @@ int iwae_train_step_dataset(iwae_handle h, int32_t start, int32_t B, int32_t k, 
  * "encoder_fwd", "reduce_adam" (main-stream slab reduction + Adam).  A kernel a configuration does not launch reports 0 launches. */
 int iwae_enable_timing(iwae_handle h, int32_t enable);
 int iwae_kernel_time(iwae_handle h, const char* name, double* avg_us, int64_t* launches);
+
+/* Kernel-selection switches of a handle, for A/B measurements and for the parity tests that compare kernel variants of the same
+ * mathematics (names and meanings: tools/README.md; the defaults are the measured best).  This call is the ONLY way to steer the
+ * library: it never reads the environment.  Synchronises the handle's streams.  Unknown names fail with IWAE_ERR_ARG. */
+int iwae_set_option(iwae_handle h, const char* name, int64_t value);
 
 /* debugging: fetch an internal activation / gradient as float32 [rows, feat] (names in DESIGN.md) */
 int iwae_debug_tensor(iwae_handle h, const char* name, float* out, size_t cap, int32_t* rows, int32_t* cols);

@@ -2256,6 +2256,13 @@ __device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0
 // load against ~1 us of MFMA + LDS work; 3.9 us per chunk measured on the output layer's gradient = 0.13 of the HBM peak).
 #define WG_SR 32
 #define WG_NST 4
+// diagnostic ablations of the weight-gradient kernels (WgradPArgs.dbg: timing only, results are wrong) exist in DIAG=1 builds only;
+// in the shipped kernels the conditions fold to false at compile time
+#ifdef IWAE_DIAG
+#define WG_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define WG_DBG(a, bit) false
+#endif
 // Shapes <NW waves, IGC i-groups, AI x BJ accumulator tiles per wave>: the waves form an IGC x (NW/IGC) grid, the workgroup's
 // output tile is IGC*AI i-tiles x (NW/IGC)*BJ j-tiles.  A 32-row stage costs a wave AI + BJ fragment reads for AI*BJ MFMAs:
 //   <16, 4, 4, 4>  256 x 256 features, 0.50 reads per MFMA (round 1's shape; the hidden layers at large row counts)
@@ -2345,7 +2352,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
         const int buf = c % WG_NST;
         wait_vmem_but(my_pieces * min(WG_NST - 2, nstage - 1 - c));      // stage c has landed; the (<= 2) younger stages may still fly
         __syncthreads();                                                 // ... for every wave; and everyone is done reading stage c - 1
-        const bool more = c + WG_NST - 1 < nstage && !(a.dbg & 1);       // stage c + 3 goes into the buffer stage c - 1 has just left
+        const bool more = c + WG_NST - 1 < nstage && !WG_DBG(a, 1);       // stage c + 3 goes into the buffer stage c - 1 has just left
         int dma_idx = 0;
         auto dma_next = [&]() {
             if (more && dma_idx < NIDX) dma_piece(c + WG_NST - 1, dma_idx);
@@ -2365,7 +2372,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
                 const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
                 g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
             }
-            if (SC && !(a.dbg & 8)) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row stage (output layer: G = s, weight = dLoss/dlpxz)
+            if (SC && !WG_DBG(a, 8)) {      // the lane's 8 data rows: 4q..4q+3 and 16+4q..16+4q+3 of this 32-row stage (output layer: G = s, weight = dLoss/dlpxz)
                 const float* scl = (const float*)(smem + buf * BUF + XT_BYTES + GT_BYTES) + 4 * q;
                 const float4 s0 = *(const float4*)scl, s1 = *(const float4*)(scl + 16);
 #pragma unroll
@@ -2373,12 +2380,12 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
                     g[u] = make_uint4(pack2(bflo(g[u].x) * s0.x, bfhi(g[u].x) * s0.y), pack2(bflo(g[u].y) * s0.z, bfhi(g[u].y) * s0.w),
                                       pack2(bflo(g[u].z) * s1.x, bfhi(g[u].z) * s1.y), pack2(bflo(g[u].w) * s1.z, bfhi(g[u].w) * s1.w));
             }
-            if (ig == 0 && !(a.dbg & 4)) {       // bias gradient = column sums of G: one wave per j-tile (wave-uniform branch)
+            if (ig == 0 && !WG_DBG(a, 4)) {       // bias gradient = column sums of G: one wave per j-tile (wave-uniform branch)
 #pragma unroll
                 for (int u = 0; u < BJ; ++u)
                     bsum[u] += bflo(g[u].x) + bfhi(g[u].x) + bflo(g[u].y) + bfhi(g[u].y) + bflo(g[u].z) + bfhi(g[u].z) + bflo(g[u].w) + bfhi(g[u].w);
             }
-            if (!(a.dbg & 2)) lds_pipeline<AI, (AI < 3 ? AI : 3)>(
+            if (!WG_DBG(a, 2)) lds_pipeline<AI, (AI < 3 ? AI : 3)>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
                     const char* p0 = xb + ((((4 * (i >> 1)) ^ (qp << 2))) * 16) + 8 * (i & 1);
@@ -2400,7 +2407,7 @@ __device__ __forceinline__ void wgradp_body(const WgradPArgs& a, const int bx, c
 
     // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
     float* slab = a.slabW + (size_t)split * a.IT * 16 * a.JT * 16;
-    if (a.dbg & 16) return;
+    if (WG_DBG(a, 16)) return;
 #pragma unroll
     for (int u = 0; u < BJ; ++u) {
         const int jt = bx * STRIP + jg * BJ + u;
@@ -2546,7 +2553,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         auto scale_stage = [&](int st, float (&sc)[GPL]) {
 #pragma unroll
             for (int i = 0; i < GPL; ++i) asm volatile("" : "+v"(sc[i]));      // (behind the wait: the loads are complete from here on)
-            if (a.dbg & 8) return;
+            if (WG_DBG(a, 8)) return;
 #pragma unroll
             for (int i = 0; i < GPL; ++i) {
                 uint4* pz = (uint4*)(smem + (st % WG_NST) * BUF + (XP + lw * GPL + i) * 1024 + lane * 16);
@@ -2570,7 +2577,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         // issue order sc(c+2), P(c+3), so that the wait for stage c + 1 may leave P(c+2), sc(c+2), P(c+3) in flight
         auto iter = [&](int c, float (&cur)[GPL], float (&nxt)[GPL]) {      // cur: weights of stage c + 1; nxt: receives those of stage c + 2
             if (SC && c + 2 < nstage) load_sc(c + 2, nxt);
-            const bool refill = c + 3 < nstage && !(a.dbg & 1);
+            const bool refill = c + 3 < nstage && !WG_DBG(a, 1);
             if (refill) issue(c + 3);
             if (c + 1 < nstage) {
                 wait_vmem_but_ws((c + 2 < nstage ? PPL + NSC : 0) + (refill ? PPL : 0));
@@ -2598,7 +2605,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     }
     const int xrow_off = (4 * q + qp) * 512, grow_off = (4 * q + qp) * GROW;
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
-    const bool do_bias = ig == 0 && !(a.dbg & 4);
+    const bool do_bias = ig == 0 && !WG_DBG(a, 4);
     __syncthreads();
     for (int c = 0; c < nstage; ++c) {
         const int buf = c % WG_NST;
@@ -2614,7 +2621,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
             const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
             g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
         }
-        if (!(a.dbg & 2)) {
+        if (!WG_DBG(a, 2)) {
             lds_pipeline<AI, 3>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
                     const int i = ig * AI + t;
@@ -2635,7 +2642,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         }
         __syncthreads();
     }
-    if (a.dbg & 16) return;
+    if (WG_DBG(a, 16)) return;
     // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
     float* slab = a.slabW + (size_t)bz * a.IT * 16 * a.JT * 16;
 #pragma unroll
@@ -3533,10 +3540,12 @@ void launch_out_bwd(const OutBwdArgs& a, hipStream_t st) {
     constexpr int PAIRS = 2;
     const size_t ldsp = 2 * ((size_t)a.KT * 4096 + 1024) + (size_t)PAIRS * 4096;
     dim3 gridp((a.M + PAIRS * 32 - 1) / (PAIRS * 32));
+#ifdef IWAE_DIAG
     if (a.stamps) {   // diagnostic build
         LAUNCH_EV((out_bwd_pair_kernel<7, PAIRS, true>), gridp, dim3(PAIRS * 128), 2 * ((size_t)7 * 4096 + 1024) + (size_t)PAIRS * 4096, st, a);
         return;
     }
+#endif
     switch (a.KT) {
         case 7: LAUNCH_EV((out_bwd_pair_kernel<7, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;
         case 4: LAUNCH_EV((out_bwd_pair_kernel<4, PAIRS, false>), gridp, dim3(PAIRS * 128), ldsp, st, a); break;

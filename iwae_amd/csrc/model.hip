@@ -78,6 +78,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi g_rccl;
@@ -94,8 +96,10 @@ static int load_rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(lib, "ncclCommInitRank");
     r.AllReduce = (decltype(r.AllReduce))dlsym(lib, "ncclAllReduce");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(lib, "ncclCommUserRank");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) return fail(IWAE_ERR_STATE, "librccl.so lacks an expected symbol");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.CommCount || !r.CommUserRank || !r.GetErrorString) return fail(IWAE_ERR_STATE, "librccl.so lacks an expected symbol");
     g_rccl = r;
     return IWAE_OK;
 }
@@ -215,6 +219,8 @@ struct iwae_model {
                                        // both at once take more of the machine from the output layer's gradient, which is what the step waits for)
     hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
     hipEvent_t ev_s2 = nullptr;
+    hipEvent_t ev_ar = nullptr;        // data-parallel step: recorded behind the decoder segment's all-reduce (dp_finish)
+    bool dp_concurrent = false;        // option dp_concurrent: the two all-reduces of a step may run at the same time (see dp_finish)
     bool use_side2 = true;
     hipEvent_t ev_lse = nullptr;
     bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
@@ -1393,6 +1399,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         const int np = (m->epsc_par + 1) % 3;
         if (m->side) HIPCHK(hipStreamSynchronize(m->side));
         CHK(draw_eps(m, np, m->noise_step, M, st));
+        if (m->eval_k_total > 0) m->eps_tag[np].valid = false;      // a k-chunk's draws: the tag (step, offset, rows) does not describe them
         m->epsc_par = np;
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     } else {
@@ -1667,8 +1674,13 @@ int dp_finish(iwae_model* m, float lr) {
         const int b0 = m->descs[m->dec1[0].sub[0]].block_begin;
         NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail));
         set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
+        // Two communicators, one per stream.  Until an N > 1 run has shown that the two collectives may be co-resident, they are ORDERED
+        // on the device: the main stream's all-reduce waits for an event behind the side stream's (issued long before -- the wait is
+        // normally already satisfied).  Every rank enqueues them in this order.  Option dp_concurrent = 1 drops the wait.
+        if (!m->dp_concurrent) HIPCHK(hipEventRecord(m->ev_ar, m->tail));
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
                     m->tail, b0);
+        if (!m->dp_concurrent) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_ar, 0));
         NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
         launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
     } else {
@@ -1720,38 +1732,10 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     std::unique_ptr<iwae_model, void (*)(iwae_model*)> guard(new iwae_model(), iwae_destroy);
     iwae_model* m = guard.get();
     m->cfg = *cfg;
-    if (const char* e = getenv("IWAE_DENSE_STAMPS")) sscanf(e, "%d:%d", &m->dstamp_epi, &m->dstamp_kt);
-    m->want_stamps = getenv("IWAE_STAMPS") != nullptr;
-    m->allow_s_mode = getenv("IWAE_OUT_RECOMPUTE") == nullptr;
-    if (m->want_stamps) m->allow_s_mode = false;      // the phase stamps instrument the recompute kernel
-    m->allow_defer = getenv("IWAE_NO_DEFER") == nullptr;
-    m->allow_zin = getenv("IWAE_NO_ZIN") == nullptr;
-    m->allow_dec_bwd = getenv("IWAE_NO_DEC_BWD") == nullptr;
-    m->allow_lse_dup = getenv("IWAE_NO_LSE_DUP") == nullptr;
-    m->allow_dz_half = getenv("IWAE_DZ_F32") == nullptr;
-    m->small_dec_bwd = getenv("IWAE_NO_SMALL_DEC_BWD") == nullptr;
-    if (const char* e = getenv("IWAE_SMALL_ROWS")) m->small_rows = atoi(e);
-    if (const char* e = getenv("IWAE_DEC_ROWS")) m->dec_rows_max = atoi(e);
-    m->allow_wg7 = getenv("IWAE_NO_WG7") == nullptr;
-    if (const char* e = getenv("IWAE_WG_DEBUG")) m->wg_debug = atoi(e);
-    if (const char* e = getenv("IWAE_WG9")) m->wg_shape9 = atoi(e);
-    if (const char* e = getenv("IWAE_EVAL_ROWS")) m->eval_rows = std::max(64, atoi(e));
-    m->allow_bern_pipe = getenv("IWAE_NO_BERN_PIPE") == nullptr && !m->want_stamps;
-    m->allow_block_fused = getenv("IWAE_NO_BLOCK_FUSED") == nullptr && !m->want_stamps;
-    m->allow_out_in_block = getenv("IWAE_NO_OUT_IN_BLOCK") == nullptr;
-    m->allow_dec_fused = getenv("IWAE_NO_DEC_FUSED") == nullptr && !m->want_stamps;
-    m->bern_qw = getenv("IWAE_NO_BERN_QW") == nullptr;
-    m->bern_qw_force = getenv("IWAE_BERN_QW_FORCE") != nullptr;
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) m->num_cus = ncu;
     }
-    if (const char* e = getenv("IWAE_DENSE_G1")) m->dense_g1_mask = (unsigned)atoi(e);
-    if (const char* e = getenv("IWAE_WG8")) m->wg_target8 = std::max(1, atoi(e));
-    if (const char* e = getenv("IWAE_WG8_FEW")) m->wg_target8_few = std::max(1, atoi(e));
-    if (const char* e = getenv("IWAE_EPS_BLOCKS")) m->eps_blocks = std::max(0, atoi(e));
-    if (const char* e = getenv("IWAE_WG16")) m->wg_target16 = std::max(1, atoi(e));
-    if (const char* e = getenv("IWAE_WG16_1")) m->wg_target16_1 = std::max(1, atoi(e));
 
     m->X = cfg->x_dim;
     m->Xp32 = round_up(cfg->x_dim, 32);
@@ -1767,22 +1751,14 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
         // priority, so the main stream's dependency chain gets the CUs first whenever both have workgroups ready
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // IWAE_SIDE_PRIO = low | normal | high: priority of the stream that carries the output layer's weight gradient (tuning aid)
         int prio = least;
-        if (const char* e = getenv("IWAE_SIDE_PRIO")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "normal") ? 0 : least;
-        if (getenv("IWAE_SIDE_PRIO_NORMAL")) prio = 0;
         HIPCHK(hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, prio));
         prio = least;
         HIPCHK(hipStreamCreateWithPriority(&m->side2, hipStreamNonBlocking, prio));
         HIPCHK(hipEventCreateWithFlags(&m->ev_s2, hipEventDisableTiming));
-        m->use_side2 = getenv("IWAE_NO_SIDE2") == nullptr;
-        m->allow_wg_group = getenv("IWAE_WG_GROUP") != nullptr;
-        m->allow_graph = getenv("IWAE_GRAPH") != nullptr && getenv("IWAE_NO_GRAPH") == nullptr;
-        if (const char* e = getenv("IWAE_GRAPH_ROWS")) m->graph_max_rows = atoi(e);
         m->tail = m->side;
     }
     HIPCHK(hipEventCreateWithFlags(&m->ev_lse, hipEventDisableTiming));
-    m->allow_early_wout = getenv("IWAE_NO_EARLY_WOUT") == nullptr;
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
@@ -1834,6 +1810,7 @@ void iwae_destroy(iwae_handle m) {
     if (!m) return;
     (void)hipSetDevice(m->cfg.device);
     if (m->side) (void)hipStreamSynchronize(m->side);
+    if (m->side2) (void)hipStreamSynchronize(m->side2);      // the decoder's all-reduce + Adam run on `tail`, which may be side2
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->comm_main && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm_main);
     if (m->comm_side && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm_side);
@@ -1874,6 +1851,7 @@ void iwae_destroy(iwae_handle m) {
     }
     if (m->side2) { (void)hipStreamSynchronize(m->side2); (void)hipStreamDestroy(m->side2); }
     if (m->ev_s2) (void)hipEventDestroy(m->ev_s2);
+    if (m->ev_ar) (void)hipEventDestroy(m->ev_ar);
     if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
@@ -2037,6 +2015,64 @@ int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
     return adam_impl(m, lr, grad_scale);
 }
 
+// Kernel-selection switches of a handle (A/B measurements and the parity tests that compare kernel variants; the defaults are the
+// measured best).  The library never reads the environment: this call is the only way to steer it.  Names: tools/README.md.
+int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
+    if (!m || !name) return fail(IWAE_ERR_ARG, "set_option: null argument");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    // a switch changes which kernels the next call launches: nothing of the previous calls may still be in flight, and
+    // captured steps (which hold the old choice) are dropped
+    CHK(join_side(m));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+    if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
+    for (auto& ge : m->graphs) { if (ge.exec) (void)hipGraphExecDestroy(ge.exec); if (ge.d_descs) (void)hipFree(ge.d_descs); }
+    m->graphs.clear();
+    m->have_forward = false;
+    const bool on = value != 0;
+    const int iv = (int)value;
+    const std::string n(name);
+    if (n == "out_recompute") m->allow_s_mode = !on;                  // recompute the logits in out_bwd instead of keeping s
+    else if (n == "no_defer") m->allow_defer = !on;                   // join the decoder update at the end of every step
+    else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
+    else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
+    else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
+    else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32
+    else if (n == "no_small_dec_bwd") m->small_dec_bwd = !on;         // per-pixel-group out_bwd + finish + two dX launches below 8 192 rows
+    else if (n == "small_rows") m->small_rows = iv;
+    else if (n == "dec_rows") m->dec_rows_max = iv;                   // dec_bwd_rows_kernel up to this many rows
+    else if (n == "no_wg7") m->allow_wg7 = !on;                       // the 16-wave weight-gradient shapes everywhere
+    else if (n == "wg9") m->wg_shape9 = iv;                           // bit mask: layers that take the 8 + 8-wave / 128-feature wgradws shape
+    else if (n == "eval_rows") m->eval_rows = std::max(64, iv);       // data rows per evaluator launch
+    else if (n == "no_bern_pipe") m->allow_bern_pipe = !on;           // the Bernoulli forward on dense_kernel<EPI_BERN>
+    else if (n == "no_block_fused") m->allow_block_fused = !on;       // a BasicBlock on few rows as three dense_kernel launches
+    else if (n == "no_out_in_block") m->allow_out_in_block = !on;     // the few-row decoder's output layer as its own launch
+    else if (n == "no_dec_fused") m->allow_dec_fused = !on;           // the decoder's tanh layers as dense_kernel launches
+    else if (n == "no_bern_qw") m->bern_qw = !on;                     // the decoder kernel's 8-wave / 128-row shape
+    else if (n == "bern_qw_force") m->bern_qw_force = on;             // the 16-wave / 200-row shape at every row count
+    else if (n == "dense_g1") m->dense_g1_mask = (unsigned)iv;        // EPI bit mask of the 8-wave x 16-row dense shape
+    else if (n == "wg8") m->wg_target8 = std::max(1, iv);             // workgroup targets of the weight-gradient launches
+    else if (n == "wg8_few") m->wg_target8_few = std::max(1, iv);
+    else if (n == "wg16") m->wg_target16 = std::max(1, iv);
+    else if (n == "wg16_1") m->wg_target16_1 = std::max(1, iv);
+    else if (n == "eps_blocks") m->eps_blocks = std::max(0, iv);      // blocks of the ahead-of-time noise draw
+    else if (n == "no_side2") m->use_side2 = !on;                     // the hidden layers' weight gradients behind the output layer's
+    else if (n == "wg_group") m->allow_wg_group = on;                 // ... as one grouped launch
+    else if (n == "no_early_wout") m->allow_early_wout = !on;         // the output layer's weight gradient forks behind out_bwd
+    else if (n == "dp_concurrent") m->dp_concurrent = on;             // data-parallel step: no device-side order between its two all-reduces
+    else if (n == "graph") m->allow_graph = on;                       // captured small-batch step (hipGraph replay)
+    else if (n == "graph_rows") m->graph_max_rows = iv;
+#ifdef IWAE_DIAG
+    // diagnostic builds only (DIAG=1 ./build.sh): in-kernel phase stamps and the weight-gradient ablations -- results are wrong or slower
+    else if (n == "stamps") { m->want_stamps = on; if (on) { m->allow_s_mode = false; m->allow_bern_pipe = false; m->allow_block_fused = false; m->allow_dec_fused = false; } }
+    else if (n == "dense_stamps_epi") m->dstamp_epi = iv;
+    else if (n == "dense_stamps_kt") m->dstamp_kt = iv;
+    else if (n == "wg_debug") m->wg_debug = iv;
+#endif
+    else return fail(IWAE_ERR_ARG, "set_option: unknown option '" + n + "'");
+    return IWAE_OK;
+}
+
 int iwae_set_eval_precision(iwae_handle m, int32_t precision) {
     if (!m) return fail(IWAE_ERR_ARG, "null handle");
     if (precision != IWAE_PREC_BF16 && precision != IWAE_PREC_FP32) return fail(IWAE_ERR_ARG, "precision must be IWAE_PREC_BF16 or IWAE_PREC_FP32");
@@ -2115,8 +2151,17 @@ int iwae_comm_init(iwae_handle m, const void* unique_id, size_t id_bytes, int32_
     HIPCHK(hipStreamSynchronize(m->stream));
     ncclUniqueId ids[2];
     memcpy(ids, unique_id, sizeof(ids));
-    NCCLCHK(g_rccl.CommInitRank(&m->comm_main, world_size, ids[0], rank));
-    NCCLCHK(g_rccl.CommInitRank(&m->comm_side, world_size, ids[1], rank));
+    // both communicators or neither: a half-initialised pair would send the next train step into ncclAllReduce with a null
+    // communicator, and could not be retried ("communicators already exist")
+    if (!m->ev_ar) HIPCHK(hipEventCreateWithFlags(&m->ev_ar, hipEventDisableTiming));
+    ncclComm_t cm = nullptr, cs = nullptr;
+    ncclResult_t r1 = g_rccl.CommInitRank(&cm, world_size, ids[0], rank);
+    ncclResult_t r2 = r1 == ncclSuccess ? g_rccl.CommInitRank(&cs, world_size, ids[1], rank) : r1;
+    if (r1 != ncclSuccess || r2 != ncclSuccess) {
+        if (r1 == ncclSuccess && cm) (void)g_rccl.CommDestroy(cm);
+        return fail(IWAE_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r1 != ncclSuccess ? r1 : r2));
+    }
+    m->comm_main = cm; m->comm_side = cs;
     m->comm_world = world_size; m->comm_rank = rank;
     return IWAE_OK;
 }
@@ -2126,9 +2171,23 @@ int iwae_comm_destroy(iwae_handle m) {
     CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+    if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));      // `tail` (the decoder's exchange + update) may be either side stream
     if (m->comm_main) { NCCLCHK(g_rccl.CommDestroy(m->comm_main)); m->comm_main = nullptr; }
     if (m->comm_side) { NCCLCHK(g_rccl.CommDestroy(m->comm_side)); m->comm_side = nullptr; }
     m->comm_world = 1; m->comm_rank = 0;
+    return IWAE_OK;
+}
+
+int iwae_comm_info(iwae_handle m, int32_t* world_size, int32_t* rank) {
+    if (!m || !world_size || !rank) return fail(IWAE_ERR_ARG, "comm_info: null argument");
+    *world_size = 0; *rank = -1;
+    if (!m->comm_main) return IWAE_OK;            // no communicator: the handle trains alone
+    int n = 0, r = -1, n2 = 0;
+    NCCLCHK(g_rccl.CommCount(m->comm_main, &n));
+    NCCLCHK(g_rccl.CommUserRank(m->comm_main, &r));
+    NCCLCHK(g_rccl.CommCount(m->comm_side, &n2));
+    if (n2 != n) return fail(IWAE_ERR_STATE, "comm_info: the two communicators disagree about the world size");
+    *world_size = n; *rank = r;
     return IWAE_OK;
 }
 

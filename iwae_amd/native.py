@@ -18,7 +18,8 @@ def _f32(a):
 
 
 class NativeModel:
-    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0, cond_prior=False, precision="bf16"):
+    def __init__(self, n_layers, n_hidden, n_latent, x_dim=784, device=0, seed=123, world_size=1, rank=0, cond_dim=0, cond_prior=False, precision="bf16",
+                 options=None):
         self.lib = _capi.load()
         cfg = Config()
         cfg.n_layers = int(n_layers)
@@ -42,6 +43,11 @@ class NativeModel:
         n = C.c_size_t()
         check(self.lib.iwae_param_count(self.h, C.byref(n)))
         self.n_params = n.value
+        for name, value in (options or {}).items():      # kernel-selection switches (A/B measurements, variant tests): iwae_set_option
+            self.set_option(name, value)
+
+    def set_option(self, name, value=1):
+        check(self.lib.iwae_set_option(self.h, str(name).encode(), int(value)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -124,6 +130,12 @@ class NativeModel:
         blob = bytes(unique_id)
         check(self.lib.iwae_comm_init(self.h, blob, len(blob), int(world_size), int(rank)))
         self.comm = True
+
+    def comm_info(self):
+        """(world size, rank) as RCCL reports them for the handle's communicators; (0, -1) without communicators."""
+        w, r = C.c_int32(), C.c_int32()
+        check(self.lib.iwae_comm_info(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
 
     def comm_destroy(self):
         check(self.lib.iwae_comm_destroy(self.h))

@@ -109,8 +109,10 @@ def main(argv=None):
         model = iwae2.IWAE([200, 100], [100, 50], device=device, output_bias=bias, world_size=world, rank=rank)
 
     if world > 1:      # the gradient exchange happens inside the library from here on (RCCL over xGMI)
-        from iwae_amd.parallel import share_comm_id
-        model._net.comm_init(share_comm_id(type(model._net).comm_unique_id, rank), world, rank)
+        from iwae_amd.parallel import init_in_library_exchange
+        why = init_in_library_exchange(model._net, rank, world)      # on every rank or on none (collective agreement)
+        if why is not None:
+            raise RuntimeError("data-parallel training needs the library's RCCL exchange on every rank: " + why)
 
     optimizer = Adam(learning_rate_dict[0], epsilon=1e-4)
     if rank == 0:

@@ -25,9 +25,10 @@ O_ID = {"vae_elbo": 0, "iwae_elbo": 1, "iwae_eq14": 2, "vae_elbo_kl": 3, "dreg":
 EXACT_SCALAR_ATOL, EXACT_GRAD_REL = 0.15, 3e-2
 
 
-def _model(n_layers, nh, nl, x_dim=784):
+def _model(n_layers, nh, nl, x_dim=784, options=None):
+    """options: kernel-selection switches (iwae_set_option) -- the library does not read the environment."""
     from iwae_amd.native import NativeModel
-    return NativeModel(n_layers, nh, nl, x_dim=x_dim, seed=123)
+    return NativeModel(n_layers, nh, nl, x_dim=x_dim, seed=123, options=options)
 
 
 def _grad_rel_errors(flat, grads):
@@ -155,7 +156,7 @@ def test_large_row_count_kernels_match_oracle(gpu, obj):
 
 @pytest.mark.parametrize("force_qw", [False, True])
 @pytest.mark.parametrize("B,k,xd", [(170, 50, 100), (260, 33, 1000), (2, 5000, 784), (175, 48, 48)])
-def test_pipelined_bernoulli_forward_shapes(gpu, monkeypatch, B, k, xd, force_qw):
+def test_pipelined_bernoulli_forward_shapes(gpu, B, k, xd, force_qw):
     """bern_pipe_kernel (>= 8 192 rows, hidden 200, k >= 32) beyond the reference's 784 pixels and k = 50: pixel counts whose
     last 32-pixel half is partial (100 = 3 x 32 + 4) or that fill an even / minimal number of halves (1000 -> 32, 48 -> 2),
     blocks of 128 rows that straddle images at other k, a ragged last block, and k = 5000 (the test-LLH evaluator's regime:
@@ -166,10 +167,7 @@ def test_pipelined_bernoulli_forward_shapes(gpu, monkeypatch, B, k, xd, force_qw
     res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo", rnd=O.bf16_round)
     # force_qw: the 16-wave / 200-row workgroup shape (12 full-tile waves + four waves sharing the 13th tile), which the
     # library otherwise takes only where its workgroups fill the machine's CUs evenly (the full-size benchmark shape)
-    if force_qw:
-        monkeypatch.setenv("IWAE_BERN_QW_FORCE", "1")
-    m = _model(1, nh, nl, xd)
-    monkeypatch.delenv("IWAE_BERN_QW_FORCE", raising=False)
+    m = _model(1, nh, nl, xd, options={"bern_qw_force": 1} if force_qw else None)
     m.set_params(O.flatten_params(P))
     r0 = m.forward(x, k, 1.0, eps=eps, want=("lpxz",))
     assert np.max(np.abs(r0["lpxz"] - res_e["lpxz"])) < EMU_ROW_ATOL
@@ -193,6 +191,56 @@ def test_two_layer_large_row_count_matches_oracle(gpu, B, k, obj):
     r = m.forward_backward(x, k, 1.0, obj, eps=eps)
     assert abs(r[obj] - res_e[obj]) < EMU_SCALAR_ATOL, (r[obj], res_e[obj])
     assert max(_grad_rel_errors(m.get_grads(), g_e)) < EMU_GRAD_REL
+    m.close()
+
+
+@pytest.mark.parametrize("layers,B,k,obj", [(1, 120, 50, "iwae_elbo"), (1, 120, 50, "dreg"), (1, 90, 50, "iwae_eq14"), (1, 2000, 5, "iwae_elbo"),
+                                            (1, 2000, 5, "dreg"), (1, 1650, 5, "vae_elbo"), (2, 120, 50, "iwae_elbo"), (2, 2000, 5, "iwae_elbo")])
+def test_kernel_family_boundaries_match_oracle(gpu, layers, B, k, obj):
+    """Row counts and sample counts at which the host picks ANOTHER kernel family than the cases above: 4 097 - 8 191 rows
+    (6 000 = 120 x 50 and 4 500 = 90 x 50: beyond block_fwd_kernel's 4 096 rows, below the 8 192 of the one-launch decoder kernel:
+    sample_kernel + dense_kernel launches, per-pixel-group Bernoulli sums, dec_bwd_kernel in its small-row use), and >= 8 192
+    rows with FEW samples per image (B = 2 000 / 1 650, k = 5 -- the reference's default --n_samples, main.py:18 -- where a 128-row
+    block spans ~26 images: the pipelined Bernoulli kernel needs k >= ~32, so dense_kernel<EPI_BERN> runs at a large row count,
+    with the large-row weight gradients behind it).  1-layer iwae_elbo / iwae_eq14 / vae_elbo / DReG and the 2-layer model, every
+    gradient tensor and the per-row log-densities against the oracle with the same bf16 rounding points."""
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x, P, eps = MG.inputs(layers, nh, nl, 784, B, k, 9000 + B + k)
+    m = _model(layers, nh, nl)
+    m.set_params(O.flatten_params(P))
+    if layers == 1:
+        res_e, g_e = O.loss_grads_1layer(P, x, eps, 1.0, obj, rnd=O.bf16_round)
+        r = m.forward_backward(x, k, 1.0, obj, eps=eps, want=("lpxz", "lqzx", "lpz"))
+        for key in ("lpxz", "lqzx", "lpz"):
+            assert np.max(np.abs(r[key] - res_e[key])) < EMU_ROW_ATOL, key
+        if obj == "dreg":
+            assert abs(r["inference_loss"] - res_e["inference_loss"]) < 5e-3 * abs(res_e["inference_loss"]) + 0.05
+            assert abs(r["iwae_elbo"] - res_e["iwae_elbo"]) < EMU_SCALAR_ATOL
+        else:
+            for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+                assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    else:
+        res_e, g_e = O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, obj, rnd=O.bf16_round)
+        r = m.forward_backward(x, k, 1.0, obj, eps=eps, want=("lpxz",))
+        assert np.max(np.abs(r["lpxz"] - res_e["lpxz1"])) < EMU_ROW_ATOL
+        for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+            assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
+    g = m.get_grads()
+    errs = _grad_rel_errors(g, g_e)
+    assert max(errs) < EMU_GRAD_REL, errs
+    # the same step on the device's own noise agrees with the oracle on the same Philox draws (the decoder kernel / block kernels
+    # make z themselves on that path)
+    m.set_step(17, 3)
+    r2 = m.forward_backward(x, k, 1.0, obj)
+    if layers == 1:
+        e_dev = philox_np.device_eps(123, 17, B, k, nl, batch_offset=3)
+        res_d, g_d = O.loss_grads_1layer(P, x, e_dev, 1.0, obj, rnd=O.bf16_round)
+    else:
+        e1 = philox_np.device_eps(123, 17, B, k, nl[0], stream=0, batch_offset=3)
+        e2 = philox_np.device_eps(123, 17, B, k, nl[1], stream=1, batch_offset=3)
+        res_d, g_d = O.loss_grads_2layer(P, x, e1, e2, 1.0, obj, rnd=O.bf16_round)
+    assert abs(r2["iwae_elbo"] - res_d["iwae_elbo"]) < EMU_SCALAR_ATOL
+    assert max(_grad_rel_errors(m.get_grads(), g_d)) < EMU_GRAD_REL
     m.close()
 
 
@@ -224,7 +272,7 @@ def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl, o
 
 
 @pytest.mark.parametrize("B,k", [(170, 50), (24, 5)])
-def test_kernel_variants_agree(gpu, monkeypatch, B, k):
+def test_kernel_variants_agree(gpu, B, k):
     """The tuning switches select different kernels for the same mathematics: recomputing the logits in out_bwd
     instead of reading the stored s, the 4-wave x 32-row dense shape instead of 8 x 16, the separate sampling kernel
     instead of the first decoder layer making z itself, the Bernoulli forward on dense_kernel<EPI_BERN> instead of the
@@ -237,11 +285,7 @@ def test_kernel_variants_agree(gpu, monkeypatch, B, k):
     P = O.init_params(1, 200, 100, 7, x_mean=O.synthetic_pixel_means())
 
     def run(env):
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
-        m = _model(1, 200, 100)
-        for key in env:
-            monkeypatch.delenv(key)
+        m = _model(1, 200, 100, options=env)
         m.set_params(O.flatten_params(P))
         m.set_step(5, 0)
         r = m.forward_backward(x, k, 1.0, "iwae_elbo")
@@ -250,10 +294,10 @@ def test_kernel_variants_agree(gpu, monkeypatch, B, k):
         return r["iwae_elbo"], g
 
     e0, g0 = run({})
-    for env in ({"IWAE_OUT_RECOMPUTE": "1"}, {"IWAE_DENSE_G1": "0"}, {"IWAE_NO_ZIN": "1"}, {"IWAE_NO_BERN_PIPE": "1"},
-                {"IWAE_NO_DEC_FUSED": "1"}, {"IWAE_NO_BLOCK_FUSED": "1"}, {"IWAE_NO_EARLY_WOUT": "1"}, {"IWAE_BERN_QW_FORCE": "1"},
-                {"IWAE_NO_DEC_BWD": "1"}, {"IWAE_NO_WG7": "1"}, {"IWAE_WG9": "3"}, {"IWAE_NO_SIDE2": "1"}, {"IWAE_WG_GROUP": "1"}, {"IWAE_NO_LSE_DUP": "1"}, {"IWAE_DZ_F32": "1"}, {"IWAE_NO_SMALL_DEC_BWD": "1"},
-                {"IWAE_DEC_ROWS": "0"}, {"IWAE_DEC_ROWS": "16384"}, {"IWAE_NO_OUT_IN_BLOCK": "1"}):
+    for env in ({"out_recompute": 1}, {"dense_g1": 0}, {"no_zin": 1}, {"no_bern_pipe": 1},
+                {"no_dec_fused": 1}, {"no_block_fused": 1}, {"no_early_wout": 1}, {"bern_qw_force": 1},
+                {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
+                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
@@ -328,7 +372,7 @@ def test_split_backward_equals_joined_backward(gpu, B, k):
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
-def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
+def test_deferred_decoder_update_is_bitwise_equivalent(gpu):
     """iwae_train_step leaves the decoder's slab reduction + Adam on the side stream and joins it lazily (before the next
     sampling kernel / any parameter access): scheduling only -- 25 steps with device noise must land on exactly the
     parameters of the run that joins at the end of every step, and reads in between must see completed updates."""
@@ -337,11 +381,7 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
     P = O.init_params(1, 200, 100, 3, x_mean=O.synthetic_pixel_means())
 
     def run(env, poke):
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
-        m = _model(1, 200, 100)
-        for key in env:
-            monkeypatch.delenv(key)
+        m = _model(1, 200, 100, options=env)
         m.set_params(O.flatten_params(P))
         for t in range(25):
             m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=False)
@@ -351,7 +391,7 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu, monkeypatch):
         m.close()
         return out
 
-    p0, (m0, v0, t0) = run({"IWAE_NO_DEFER": "1"}, False)
+    p0, (m0, v0, t0) = run({"no_defer": 1}, False)
     p1, (m1, v1, t1) = run({}, False)
     p2, _ = run({}, True)
     np.testing.assert_array_equal(p0, p1)
@@ -448,7 +488,7 @@ def test_conditional_prior_model_matches_oracle(gpu, B, k, obj, beta):
 
 
 @pytest.mark.parametrize("layers,B,k,obj", [(1, 20, 1, "vae_elbo"), (1, 20, 5, "iwae_elbo"), (1, 32, 50, "dreg"), (2, 20, 5, "iwae_elbo")])
-def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, monkeypatch, layers, B, k, obj):
+def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, layers, B, k, obj):
     """BASELINE configs[0] regime (the reference's default B = 20, main.py:19-20): below 4 096 data rows iwae_train_step captures
     the step once (serial form: one stream, no events) and replays the hipGraph (IWAE_GRAPH=1), with the step counter, batch offset,
     Adam step size and dataset offset read from a device block.  30 steps through the resident-dataset path and through a device-resident
@@ -463,10 +503,7 @@ def test_graph_replayed_small_batch_step_is_bitwise_the_eager_step(gpu, monkeypa
     xdev = torch.tensor(O.synthetic_binarized(B, 3), device="cuda")
     outs = []
     for graph in (False, True):
-        if graph:
-            monkeypatch.setenv("IWAE_GRAPH", "1")          # opt-in: measured slower than the eager multi-stream step
-        m = _model(layers, nh, nl)
-        monkeypatch.delenv("IWAE_GRAPH", raising=False)
+        m = _model(layers, nh, nl, options={"graph": 1} if graph else None)      # opt-in
         m.set_params(O.flatten_params(P))
         m.dataset_upload(gray)
         m.dataset_begin_epoch(3, order)
@@ -709,7 +746,7 @@ def test_eval_llh_chunking_and_definition(big):
 
 
 @pytest.mark.parametrize("layers", [1, 2])
-def test_eval_llh_k_chunking_is_invisible(gpu, monkeypatch, layers):
+def test_eval_llh_k_chunking_is_invisible(gpu, layers):
     """iwae_eval_llh walks an image's k samples in chunks when k exceeds the rows-per-launch cap (IWAE_EVAL_ROWS) and merges the
     chunks' log-mean-exps with a running log-sum-exp (src/utils.py:6-8 in associative form); the Philox rows are those of the
     unchunked call, so the per-image estimates must not move -- k = 1500 in chunks of 256 (5 full + 1 ragged) against one launch,
@@ -719,16 +756,27 @@ def test_eval_llh_k_chunking_is_invisible(gpu, monkeypatch, layers):
     x = O.synthetic_binarized(6, 5)
     outs = {}
     for rows in (0, 256):
-        if rows:
-            monkeypatch.setenv("IWAE_EVAL_ROWS", str(rows))
-        m = _model(layers, nh, nl)
-        monkeypatch.delenv("IWAE_EVAL_ROWS", raising=False)
+        m = _model(layers, nh, nl, options={"eval_rows": rows} if rows else None)
         m.set_params(O.flatten_params(P))
         for prec in ("fp32", "bf16"):
             m.set_eval_precision(prec)
             m.set_step(31, 4)
             outs[(rows, prec)] = m.eval_llh(x, k=1500, per_image=True)
+            if rows:
+                # the chunked evaluator's last launch drew (step 31, image 4 + 5, the 220 samples 1280.. of 1500): a training step whose
+                # (step, offset, rows) happen to equal that launch's must NOT take those draws for its own (the ring slot's tag is
+                # invalidated by both arithmetics' chunked forwards)
+                m.set_step(31, 9)
+                outs[("after", prec)] = (m.forward_backward(x[5:6], 220, 1.0, "iwae_elbo")["iwae_elbo"], m.get_grads().copy())
         m.close()
+    fresh = _model(layers, nh, nl)
+    fresh.set_params(O.flatten_params(P))
+    fresh.set_step(31, 9)
+    e_ref, g_ref = fresh.forward_backward(x[5:6], 220, 1.0, "iwae_elbo")["iwae_elbo"], fresh.get_grads().copy()
+    fresh.close()
+    for prec in ("fp32", "bf16"):
+        assert outs[("after", prec)][0] == e_ref, prec
+        np.testing.assert_array_equal(outs[("after", prec)][1], g_ref)
     for prec in ("fp32", "bf16"):
         (a, pa), (b, pb) = outs[(0, prec)], outs[(256, prec)]
         np.testing.assert_allclose(pa, pb, atol=2e-3)
@@ -975,19 +1023,29 @@ def _jitter(X, rng):
     return out
 
 
-def test_trained_model_k5000_llh_within_north_star_tolerance(gpu):
+@pytest.mark.parametrize("kind", ["iwae1", "dreg", "iwae2"])
+def test_trained_model_k5000_llh_within_north_star_tolerance(gpu, kind):
     """north_star's stated tolerance: the test-set LLH at k = 5000 (main.py:170-184) within +-0.1 nat of the reference
     arithmetic.  A model is trained for 1 200 steps (B = 100, k = 50) on synthetic MNIST-like data with the device pipeline
     (resident dataset, per-epoch binarisation, fused step), then iwae_eval_llh(k = 5000) on 16 test images is compared with the
     exact float64 oracle evaluating the SAME weights on the SAME noise (the device's Philox stream restated in NumPy,
-    oracle/philox_np.py): |difference of the means| <= 0.1 nat, and per image <= 0.1 nat."""
-    from iwae_amd import iwae1, utils
+    oracle/philox_np.py; the 2-layer model draws z1 from stream 0 and z2 from stream 1): |difference of the means| <= 0.1 nat, and per
+    image <= 0.1 nat.  kind: the 1-layer model trained on iwae_elbo (README.md:14-16), the same model trained with the DReG estimator
+    (tasks/task02.py, README.md:44-46), the 2-layer model of src/iwae2.py (README.md:21-23) -- both evaluators each."""
+    from iwae_amd import iwae1, iwae2, task02, utils
     from iwae_amd.optimizers import Adam
     np.random.seed(123)
     rng = np.random.default_rng(0)
     Xtrain, Xtest = utils.synthetic_mnist(20000, 256)
     Xtrain, Xtest = _jitter(Xtrain, rng), _jitter(Xtest, rng)
-    model = iwae1.IWAE(200, 100, output_bias=utils.get_bias(Xtrain))
+    layers = 2 if kind == "iwae2" else 1
+    nh, nl = ([200, 100], [100, 50]) if layers == 2 else (200, 100)
+    if kind == "iwae2":
+        model = iwae2.IWAE(nh, nl, output_bias=utils.get_bias(Xtrain))
+    elif kind == "dreg":
+        model = task02.IWAEDReG(nh, nl, output_bias=utils.get_bias(Xtrain))
+    else:
+        model = iwae1.IWAE(nh, nl, output_bias=utils.get_bias(Xtrain))
     opt = Adam(1e-3, epsilon=1e-4)
     model.set_dataset(Xtrain)
     B, k = 100, 50
@@ -995,7 +1053,7 @@ def test_trained_model_k5000_llh_within_north_star_tolerance(gpu):
     for epoch in range(6):
         model.begin_epoch(epoch, np.random.permutation(Xtrain.shape[0]))
         for lo in range(0, Xtrain.shape[0], B):
-            res = model.train_step_dataset(lo, B, k, 1.0, opt, objective="iwae_elbo")
+            res = model.train_step_dataset(lo, B, k, 1.0, opt, objective="dreg" if kind == "dreg" else "iwae_elbo")
             first = float(res["iwae_elbo"]) if first is None else first
         last = float(res["iwae_elbo"])
     assert last > first + 20.0, (first, last)            # it did train
@@ -1008,12 +1066,16 @@ def test_trained_model_k5000_llh_within_north_star_tolerance(gpu):
     net.set_step(999, 0)
     _, per_bf = net.eval_llh(Xt[:n], 5000, chunk=n, per_image=True)            # the fast path (bf16 GEMM operands)
     net.set_eval_precision("fp32")
-    P = O.unflatten_params(net.get_params().astype(np.float64), 1, 200, 100)
-    per_o = np.array([float(O.forward_1layer(P, Xt[i:i + 1], philox_np.device_eps(123, 999, 1, 5000, 100, batch_offset=i))["iwae_elbo"])
-                      for i in range(n)])
+    P = O.unflatten_params(net.get_params().astype(np.float64), layers, nh, nl)
+    if layers == 1:
+        per_o = np.array([float(O.forward_1layer(P, Xt[i:i + 1], philox_np.device_eps(123, 999, 1, 5000, 100, batch_offset=i))["iwae_elbo"])
+                          for i in range(n)])
+    else:
+        per_o = np.array([float(O.forward_2layer(P, Xt[i:i + 1], philox_np.device_eps(123, 999, 1, 5000, 100, stream=0, batch_offset=i),
+                                                 philox_np.device_eps(123, 999, 1, 5000, 50, stream=1, batch_offset=i))["iwae_elbo"]) for i in range(n)])
     d_mean, d_max = abs(per.mean() - per_o.mean()), np.max(np.abs(per - per_o))
-    print("k=5000 LLH: device %.4f, exact fp64 oracle %.4f, |mean diff| %.4f, max per-image |diff| %.4f (trained %.2f -> %.2f)"
-          % (per.mean(), per_o.mean(), d_mean, d_max, first, last))
+    print("%s k=5000 LLH: device %.4f, exact fp64 oracle %.4f, |mean diff| %.4f, max per-image |diff| %.4f (trained %.2f -> %.2f)"
+          % (kind, per.mean(), per_o.mean(), d_mean, d_max, first, last))
     d_bf_mean, d_bf_max = abs(per_bf.mean() - per_o.mean()), np.max(np.abs(per_bf - per_o))
     print("          bf16 evaluator: |mean diff| %.4f, max per-image |diff| %.4f" % (d_bf_mean, d_bf_max))
     assert abs(llh_dev - per.mean()) < 1e-3

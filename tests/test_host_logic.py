@@ -144,6 +144,7 @@ def _dp_worker(rank, world, port, q):
     # the RCCL id blob of the in-library exchange (iwae_comm_init) travels the same way: rank 0 makes it, every rank gets it
     blob = parallel.share_comm_id(lambda: bytes(range(256)), rank)
     assert blob == bytes(range(256)), (rank, blob[:8])
+    assert parallel.all_ranks_ok(True) and not parallel.all_ranks_ok(rank == 0)
     dist.destroy_process_group()
 
 
@@ -159,6 +160,93 @@ def test_data_parallel_gradient_exchange_gloo_world2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert gerr < 1e-12 and perr < 1e-12
+
+
+class _FakeNet:
+    """Stands in for NativeModel in the host-logic tests of the exchange initialisation (no GPU, no RCCL)."""
+    fail_id = False
+
+    def __init__(self, fail_init):
+        self.fail_init, self.inited, self.destroyed = fail_init, False, False
+
+    @classmethod
+    def comm_unique_id(cls):
+        if cls.fail_id:
+            raise OSError("librccl.so: cannot open shared object file")
+        return bytes(range(256))
+
+    def comm_init(self, blob, world, rank):
+        assert blob == bytes(range(256))
+        if self.fail_init:
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+        self.inited = True
+
+    def comm_destroy(self):
+        self.destroyed = True
+
+
+class _FakeNetNoId(_FakeNet):
+    fail_id = True
+
+
+def _dp_init_worker(rank, world, port, scenario, q):
+    sys.path.insert(0, ROOT)
+    from iwae_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if scenario == "id_fails_on_rank0":          # ranks 1.. sit in the broadcast: rank 0 must ship its failure, everyone raises
+        net = _FakeNetNoId(False)
+    elif scenario == "init_fails_on_rank1":      # rank-asymmetric failure: rank 0's communicators are given back, everyone raises
+        net = _FakeNet(rank == 1)
+    else:
+        net = _FakeNet(False)
+    out = {"rank": rank}
+    try:
+        dp = parallel.DataParallelStep(net, rank, world)
+        out.update(raised=False, path=dp.path, in_library=dp.in_library)
+    except RuntimeError as e:
+        out.update(raised=True, msg=str(e))
+    out.update(inited=net.inited, destroyed=net.destroyed)
+    # whatever happened, the ranks are still in step: one more collective must complete
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    out["still_in_step"] = float(t.item()) == world
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["ok", "id_fails_on_rank0", "init_fails_on_rank1"])
+def test_exchange_initialisation_is_collective_and_never_falls_back_silently(scenario):
+    """world 2 over gloo.  A failing RCCL initialisation -- rank 0 cannot make the id, or comm_init fails on ONE rank -- must
+    raise on EVERY rank (no rank left behind in a broadcast, none on a different exchange path), with the communicators of
+    the ranks that did succeed destroyed again; the healthy case takes the in-library path on both."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_init_worker, args=(r, 2, port, scenario, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=120) for _ in procs), key=lambda o: o["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(o["still_in_step"] for o in outs)
+    if scenario == "ok":
+        assert all(not o["raised"] and o["in_library"] and o["path"] == "rccl_in_library" and o["inited"] and not o["destroyed"] for o in outs)
+    else:
+        assert all(o["raised"] for o in outs), outs
+        assert all("in-library RCCL exchange could not be initialised" in o["msg"] for o in outs)
+        if scenario == "id_fails_on_rank0":
+            assert all("librccl.so" in o["msg"] and not o["inited"] for o in outs)
+        else:
+            assert outs[0]["inited"] and outs[0]["destroyed"] and not outs[1]["inited"]      # rank 0 gave its communicators back
+
+
+def test_single_rank_needs_no_exchange():
+    from iwae_amd import parallel
+    dp = parallel.DataParallelStep(_FakeNet(True), 0, 1)
+    assert dp.path == "single" and not dp.in_library
 
 
 def test_shard_bounds():

@@ -1,14 +1,15 @@
 #!/bin/bash
-# Developer script (GPU box): bench.py ms/step under a list of environment variants, REPS interleaved rounds each (run-to-run
-# spread on a box is ~3 %: single runs cannot rank variants closer than that).  usage: tools/dev/ab.sh "VAR=1" "A=2 B=3" ...
+# Developer script (GPU box): bench.py ms/step under a list of option variants (iwae_set_option switches), REPS interleaved rounds each (run-to-run
+# spread on a box is ~3 %: single runs cannot rank variants closer than that).  usage: tools/dev/ab.sh "name=1" "a=2 b=3" ...
 # (the first line is the default build); env BENCH_ARGS adds bench.py arguments, REPS (default 3) the rounds
 R=${GRAFT_REPO_ROOT:-.}
 REPS=${REPS:-3}
-VARS=("IWAE_AB_DEFAULT=1" "$@")
+VARS=("-" "$@")
 declare -A RES
 for r in $(seq 1 $REPS); do
   for v in "${VARS[@]}"; do
-    ms=$(env $v python3 $R/bench.py --steps 150 --warmup 30 --no-cpu-baseline --no-llh-eval $BENCH_ARGS 2>/dev/null | python3 -c "
+    opts=""; if [ "$v" != "-" ]; then for o in $v; do opts="$opts --opt $o"; done; fi
+    ms=$(python3 $R/bench.py --steps 150 --warmup 30 --no-kernel-times --no-cpu-baseline --no-llh-eval $opts $BENCH_ARGS 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'): print(json.loads(l)['ms_per_step'])")

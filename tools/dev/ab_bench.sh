@@ -1,13 +1,16 @@
 #!/bin/bash
-# Developer script (GPU box): bench.py once per environment setting given as arguments ("-" = default build), one summary line each.
-# usage: tools/dev/ab_bench.sh - IWAE_NO_BERN_PIPE=1 ...
+# Developer script (GPU box): bench.py once per option setting given as arguments ("-" = defaults), one summary line each.
+# An argument is a space-separated list of iwae_set_option switches: tools/dev/ab_bench.sh - no_bern_pipe=1 "wg16=160 no_side2=1" ...
+# (BENCH_ARGS: extra bench.py arguments, e.g. "--config c2")
 cd $GRAFT_REPO_ROOT
 for e in "$@"; do
-  if [ "$e" = "-" ]; then envs=""; else envs="$e"; fi
-  env $envs python bench.py --no-cpu-baseline 2> gpurun_out/ab.err | python3 -c "
+  opts=""
+  if [ "$e" != "-" ]; then for o in $e; do opts="$opts --opt $o"; done; fi
+  python bench.py --no-cpu-baseline --no-llh-eval $opts $BENCH_ARGS 2> gpurun_out/ab.err | python3 -c "
 import sys, json
 for l in sys.stdin:
+    if not l.startswith('{'): continue
     d = json.loads(l); r = d['roofline']
-    print('%-28s ms/step %.4f  dominant %.2f us (%s)  other %s  elbo %s' % ('$e', d['ms_per_step'], r['avg_launch_us'], r['kernel'][:24], r['other'], d['config']['iwae_elbo_after']))
+    print('%-28s ms/step %.4f  dominant %.2f us (%s)  %s  elbo %s' % ('$e', d['ms_per_step'], r['avg_launch_us'], r['timed_as'], ' '.join('%s=%.1f' % (k, v['us']) for k, v in r.get('all_kernels', {}).items()), d['config']['iwae_elbo_after']))
 "
 done

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Developer script (GPU box): duration of kernels ALONE on the machine (a --pmc run serialises the dispatches) for a list of
-# environment variants.  usage: tools/dev/alone.sh "<kernel substrings, | separated>" "VAR=1" "A=2 B=3" ...
+# option variants (iwae_set_option switches).  usage: tools/dev/alone.sh "<kernel substrings, | separated>" "name=1" "a=2 b=3" ...
 PATS=$1; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/alone_tmp
 cd /tmp && export TMPDIR=/tmp
 run() {
   rm -rf $OUT; mkdir -p $OUT
-  env $1 IWAE_BENCH_TIMING=1000000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-llh-eval $BENCH_ARGS > $OUT/log.txt 2>&1 || echo "run failed: $1"
+  opts=""; for o in $1; do opts="$opts --opt $o"; done
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT -- python3 $R/bench.py --steps 30 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $opts $BENCH_ARGS > $OUT/log.txt 2>&1 || echo "run failed: $1"
   python3 - "$OUT" "$PATS" "$1" <<'PY'
 import csv, glob, sys, collections
 out, pats, tag = sys.argv[1], sys.argv[2].split("|"), sys.argv[3]
@@ -21,5 +22,5 @@ for k, d in dur.items():
 print("%-40s %s" % (tag, "  ".join(sorted(res))))
 PY
 }
-run "IWAE_AB_DEFAULT=1"
+run ""
 for v in "$@"; do run "$v"; done

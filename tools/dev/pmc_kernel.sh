@@ -5,13 +5,13 @@
 TAG=${1:-x}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pk_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-llh-eval $BENCH_ARGS"
+CMD="python3 $R/bench.py --steps 30 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS"
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE"; do
   i=$((i+1))
-  IWAE_BENCH_TIMING=1000000 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - "$OUT" "$@" <<'PY'
 import csv, glob, sys, collections

@@ -2,6 +2,6 @@
 # Developer script (GPU box): kernel timeline of one DATA-PARALLEL step rehearsed on one GPU (world size 1).
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_dp_${1:-x}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export IWAE_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 IWAE_BENCH_TIMING=1000000
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-llh-eval > $OUT/log.txt 2>&1 || echo failed
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --force-dist --steps 60 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval > $OUT/log.txt 2>&1 || echo failed
 python3 $R/tools/dev/timeline.py $OUT

@@ -2,5 +2,5 @@
 # Developer script (GPU box): kernel trace of the bench loop, then the timeline of one step.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_${1:-x}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-IWAE_BENCH_TIMING=1000000 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-llh-eval > $OUT/log.txt 2>&1 || echo failed
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 60 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS > $OUT/log.txt 2>&1 || echo failed
 python3 $R/tools/dev/timeline.py $OUT

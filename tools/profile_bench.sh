@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=60
 WARM=10
-CMD="python3 $R/bench.py --steps $STEPS --warmup $WARM --config $CONFIG --no-cpu-baseline --no-llh-eval"
+CMD="python3 $R/bench.py --steps $STEPS --warmup $WARM --settle 0 --no-kernel-times --config $CONFIG --no-cpu-baseline --no-llh-eval $BENCH_ARGS"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo "trace run failed"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || echo "pmc fetch failed"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || echo "pmc write failed"
