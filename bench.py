@@ -229,6 +229,9 @@ def run():
     dist = None
     if world > 1 or force_dist:      # --force-dist rehearses the RCCL path on one GPU
         import torch.distributed as dist
+        if world == 1:               # (a rehearsal outside torchrun: a one-rank rendezvous of its own)
+            for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29517"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+                os.environ.setdefault(key, val)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from iwae_amd.native import NativeModel

@@ -151,7 +151,8 @@ struct WgradPArgs {
     float* slabB;                           // [nsplit][JT*16]
     const char* zero;                       // >= 512 B of zeros (source of rows >= M and of unused slots)
     const float* rowscale;                  // optional [M]: G rows are multiplied by it (rounded to bf16) on the way in, else null
-    int dbg;                                // diagnostic ablations (IWAE_WG_DEBUG, timing only -- results are wrong): 1 no DMA in the loop, 2 no A reads / MFMAs, 4 no bias sums, 8 no row scaling
+    int dbg;                                // diagnostic ablations (DIAG build, option wg_debug; timing only -- results are wrong): 1 no DMA in the loop, 2 no A reads / MFMAs, 4 no bias sums, 8 no row scaling
+    unsigned long long* stamps;             // diagnostic build (STAMPS=1) only: wgradws_kernel's per-wave phase cycle sums [workgroups * waves][8], else null
 };
 
 struct WgradPGroup {                        // up to 3 independent 8-wave weight gradients in one launch

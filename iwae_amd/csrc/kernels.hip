@@ -2455,11 +2455,11 @@ __global__ __launch_bounds__(NW * 64, (AI * BJ > 16) ? 2 : NW / 4) void wgradp_k
 // waves that a barrier keeps in lockstep; the MFMA pipe idles 3/4 of the time.  Here:
 //   * 8 COMPUTE waves (2 x 4 grid, 7 x 4 accumulator tiles each = 224 x 256 features) only read fragments and multiply; the bias
 //     gradient (column sums of G) comes out of the matrix pipe too (one MFMA per G fragment against an all-ones A fragment);
-//   * 4 LOADER waves issue all LDS-DMA of the stage ring (3 stages ahead) and -- row-weighted variant -- scale the G rows THEY
-//     fetched in place (bf16, one rounding: dl = bf16(g_r * s)) once their own pieces have landed, one stage ahead of the
-//     compute waves; the row weights come by plain (asm) loads, two stages ahead, so nothing a loader waits for is young.
-// One barrier per stage: behind it the compute waves own stage c + 1 (landed, scaled) and the loaders own the buffer of
-// stage c (to refill) and stage c + 2 (to scale).
+//   * 4 LOADER waves issue all LDS-DMA of the stage ring (3 stages ahead); in the row-weighted variant (the output layer: G = the
+//     stored s, weight = dLoss/dlpxz of the row) the G strip travels through the loaders' REGISTERS instead and is multiplied by
+//     the row weight on the way into LDS (bf16, one rounding: dl = bf16(g_r * s)) -- see the loader branch below.
+// One barrier per stage: behind it the compute waves own stage c + 1 (landed, weighted) and the loaders own the buffer of
+// stage c (to refill).
 // ---------------------------------------------------------------------------------
 // counted wait for any count 0..24 (wave-uniform)
 __device__ __forceinline__ void wait_vmem_but_ws(int n) {
@@ -2477,29 +2477,185 @@ __device__ __forceinline__ void wait_vmem_but_ws(int n) {
 //   <.., 2, 8>: 224 x 128 features, 8 + 8 waves at <= 128 registers (four per SIMD): a third of the DMA issues and a quarter of the
 //               scaling per loader and stage -- the loaders' instruction stream is what a stage takes (see above) -- for 1.75x the
 //               X-tile traffic out of L2 (seven column blocks instead of four)
+#ifdef IWAE_DENSE_STAMPS      // diagnostic build: cycles per phase and wave -> a.stamps[workgroup * waves + wave][8]
+#define WS_STAMP(slot)                                                                 \
+    {                                                                                  \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        ws_sum[slot] += t_ - ws_prev;                                                  \
+        ws_prev = t_;                                                                  \
+    }
+#define WS_STAMP_OUT()                                                                                                         \
+    if (a.stamps && lane == 0) {                                                                                               \
+        for (int i_ = 0; i_ < 8; ++i_) a.stamps[((size_t)sid * (NCW + NLW) + wave) * 8 + i_] = ws_sum[i_];                     \
+    }
+#else
+#define WS_STAMP(slot)
+#define WS_STAMP_OUT()
+#endif
+// XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
+__device__ __forceinline__ void wgradws_block(int& bx, int& bz, const int gx, const int nz) {
+    const int nb = gx * nz;
+    if ((nb & 7) == 0) {
+        const int L = bx + gx * bz;
+        const int V = (L & 7) * (nb >> 3) + (L >> 3);
+        bx = V % gx; bz = V / gx;
+    }
+}
+// jt0: first j-tile (16 out-features) of the workgroup's G strip, bz: its row split, sid: its slot in the diagnostic stamp buffer
 template <bool SC, int BJ, int NLW>
-__device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz, const int gx, const int nz) {
+__device__ __forceinline__ void wgradws_body(const WgradPArgs& a, const int jt0, const int bz, const int sid) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+#ifdef IWAE_DENSE_STAMPS
+    unsigned long long ws_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ws_prev)::"memory");
+#endif
     constexpr int AI = 7, IGC = 2, NCW = 8, STRIP = 4 * BJ;
     constexpr int XT_BYTES = WG_SR * 512, GROW = STRIP * 32, GT_BYTES = WG_SR * GROW, BUF = XT_BYTES + GT_BYTES;
     constexpr int XP = XT_BYTES / 1024, GP = GT_BYTES / 1024, XPL = XP / NLW, GPL = GP / NLW, PPL = XPL + GPL;      // pieces per loader and stage
     constexpr int SPR = GROW / 16, RPP = 1024 / GROW;                   // G strip: 16-byte slots per row, rows per 1 KiB piece
     static_assert(XP % NLW == 0 && GP % NLW == 0 && GPL >= 1 && GPL <= 4, "loader split");
     typedef __attribute__((ext_vector_type(4))) short v4s;
-    {   // XCD-aware block order (see wgradp_kernel): the j-blocks of one row split share an XCD's L2
-        const int nb = gx * nz;
-        if ((nb & 7) == 0) {
-            const int L = bx + gx * bz;
-            const int V = (L & 7) * (nb >> 3) + (L >> 3);
-            bx = V % gx; bz = V / gx;
-        }
-    }
+    // G strip in LDS: 16-byte slot s of row r sits at slot s ^ gswz(r), so that the four rows a transposing read touches per quad fall
+    // into four different 64-byte bank windows (row pitch 512 / 256 B: rows are bank-aligned, the two low row bits pick the window;
+    // pitch 128 B -- the narrow strip -- : odd rows are half a bank cycle further by themselves, row bit 1 picks the other half)
+    auto gswz = [](int r) { return SPR >= 16 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); };
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rbeg = bz * a.rows_per_split;
     const int rend = min(a.M, rbeg + a.rows_per_split);
     const int nstage = (rend - rbeg + WG_SR - 1) / WG_SR;
-    const int gcol0 = bx * STRIP * 16;
+    const int gcol0 = jt0 * 16;
 
+    if (SC && wave >= NCW) {
+        // ------------------------------------------------------------------ loader waves, row-weighted variant (round 3)
+        // The G strip (the stored s of the output layer) does NOT go through LDS-DMA here: a loader fetches its pieces into REGISTERS
+        // (plain 16-byte loads, three stages ahead, four register sets), multiplies them by the row weight on the way -- one weight per
+        // lane and piece: a lane's 16 bytes are 8 features of ONE data row -- and stores them into the stage's buffer (ds_write_b128),
+        // one stage ahead of the compute waves.  Round 2 DMA'd the strip and then scaled it IN PLACE in LDS (ds_read, 20 vector
+        // instructions, ds_write, behind a wait for the DMA it had just issued around): that read-modify-write sat on the loaders'
+        // serial path, which is what a stage took (60 us alone against 31 for the unweighted kernel on the same shape).  Now the
+        // multiplies ride in the issue slots the compute waves' MFMAs leave free, nothing is read back from LDS, and a loader waits for
+        // nothing younger than two stages.  Same arithmetic as before: dl = bf16(g_r * s), one rounding.
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        // The loaders' stream (8 memory instructions, ~90 vector instructions of weighting, 4 LDS stores per stage) is what a stage waits
+        // for, and as the youngest waves of their SIMDs they lose every issue arbitration against the two compute waves beside them
+        // (phase stamps: 870 cycles for the weighting): issued first, they are out of the way instead.
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - NCW;
+        const char* zsrc = a.zero + (lane & 31) * 16;
+        const int xstride = WG_SR * a.ldX * 2, gstride = WG_SR * a.ldG * 2;
+        const char* xbase[XPL]; int xlim[XPL];
+#pragma unroll
+        for (int i = 0; i < XPL; ++i) {
+            const int pc = lw * XPL + i, rl = 2 * pc + (lane >> 5);
+            const int col = ((lane & 31) ^ ((rl & 3) << 2)) * 8;                 // source 16-byte chunk of this LDS slot
+            xbase[i] = (const char*)a.X + ((size_t)(rbeg + rl) * a.ldX + col) * 2;
+            xlim[i] = col < a.ldX ? rend - rbeg - rl : -(1 << 30);
+        }
+        const char* gbase[GPL]; int glim[GPL];
+#pragma unroll
+        for (int i = 0; i < GPL; ++i) {
+            const int pc = lw * GPL + i, rl = RPP * pc + lane / SPR;
+            const int col = gcol0 + ((lane % SPR) ^ gswz(rl)) * 8;
+            const bool ok = col < a.ldG;                                          // (a last column block narrower than its strip)
+            gbase[i] = (const char*)a.G + ((size_t)(rbeg + rl) * a.ldG + (ok ? col : 0)) * 2;
+            glim[i] = ok ? rend - rbeg - rl : -(1 << 30);
+        }
+        // What a stage costs a CU is the NUMBER of vector-memory wave-instructions, not their bytes (phase stamps of this kernel: 12
+        // instructions per loader and stage took 1 430 cycles, ~30 per instruction and CU whatever the width -- the "60-70 GB/s per CU"
+        // of DESIGN item 5 is 1 KiB per ~31 cycles).  So the row weights do NOT come by vector loads (4 dword loads per loader and stage
+        // = a third of all its instructions for 32 bytes): a loader's G pieces cover NR consecutive data rows, whose weights are ONE
+        // scalar load (s_load_dwordx8 through the scalar cache, no vector-memory slot), requested at the top of the iteration that
+        // uses them and waited for behind the stage's vector-memory wait.
+        constexpr int NR = RPP * GPL;           // data rows of a stage this loader's G pieces cover: rows NR*lw .. NR*lw + NR - 1
+        static_assert(NR == 8 || NR == 4, "row weights of a loader and stage are one s_load_dwordx8 / x4");
+        typedef __attribute__((ext_vector_type(NR))) float wvec_t;
+        auto load_w = [&](int st, wvec_t& w) {
+            const uint64_t ad = (uint64_t)(a.rowscale + (rbeg + st * WG_SR + NR * lw));      // (< Mp: the pad rows of gx are finite)
+            const uint64_t au = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ad >> 32)) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ad);
+            if constexpr (NR == 8) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(w) : "s"(au) : "memory");
+            else asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(w) : "s"(au) : "memory");
+        };
+        auto wsel = [&](const wvec_t& w, int i) {       // the weight of the lane's row in piece i: row RPP * i + lane / SPR of the loader's NR
+            float f = w[RPP * i];
+#pragma unroll
+            for (int r = 1; r < RPP; ++r) f = (lane / SPR == r) ? w[RPP * i + r] : f;
+            return f;
+        };
+        constexpr int PER = GPL + XPL;          // vector-memory operations per loader and stage: GPL strip pieces, XPL DMA pieces
+        u32x4 gq0[GPL], gq1[GPL], gq2[GPL], gq3[GPL];
+        // rows beyond the split (and the columns beyond the layer) read a valid address and are multiplied by zero in put_piece
+        auto issue_g = [&](int st, int i, u32x4& dst) {
+            const char* pg = (st * WG_SR < glim[i]) ? gbase[i] + (size_t)st * (size_t)gstride : (const char*)a.G;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(pg) : "memory");
+        };
+        auto issue_x = [&](int st, int i) {
+            if (WG_DBG(a, 1)) return;
+            const char* src = (st * WG_SR < xlim[i]) ? xbase[i] + (size_t)st * (size_t)xstride : zsrc;
+            glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)(lw * XPL + i) * 1024u)));
+        };
+        auto put_piece = [&](int st, int i, const u32x4& v, const wvec_t& w) {
+            const float f = (st * WG_SR < glim[i]) ? (WG_DBG(a, 8) ? 1.0f : wsel(w, i)) : 0.0f;
+            *(uint4*)(smem + (st % WG_NST) * BUF + (XP + lw * GPL + i) * 1024 + lane * 16) =
+                make_uint4(pack2(bflo(v.x) * f, bfhi(v.x) * f), pack2(bflo(v.y) * f, bfhi(v.y) * f),
+                           pack2(bflo(v.z) * f, bfhi(v.z) * f), pack2(bflo(v.w) * f, bfhi(v.w) * f));
+        };
+        constexpr int XDMA = XPL;
+        auto per_stage = [&](int st) { return (st < nstage) ? (WG_DBG(a, 1) ? PER - XDMA : PER) : 0; };
+        // prologue: stages 0, 1, 2 requested; stage 0 in its buffer behind the first barrier.  Stage st lives in register set st & 3.
+        wvec_t wcur;
+        load_w(0, wcur);
+        auto issue_all = [&](int st, u32x4 (&gs)[GPL]) {
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) issue_g(st, i, gs[i]);
+#pragma unroll
+            for (int i = 0; i < XPL; ++i) issue_x(st, i);
+        };
+        if (0 < nstage) issue_all(0, gq0);
+        if (1 < nstage) issue_all(1, gq1);
+        if (2 < nstage) issue_all(2, gq2);
+        wait_vmem_but_ws(per_stage(1) + per_stage(2));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wcur) : : "memory");
+        if (0 < nstage) {
+#pragma unroll
+            for (int i = 0; i < GPL; ++i) { asm volatile("" : "+v"(gq0[i])); put_piece(0, i, gq0[i], wcur); }
+        }
+        __syncthreads();
+        WS_STAMP(0)      // prologue
+        // Iteration c: the buffer stage c - 1 has left is requested again (stage c + 3), then stage c + 1 (requested two iterations ago) is
+        // weighted and stored into its buffer.  (Taking the two in turns, one memory instruction then one piece's weighting, was measured
+        // and is slower: 53 us alone against 51, the loaders' iteration 3 080 cycles against 2 030 in the stamped build.)
+        auto iter = [&](int c, u32x4 (&gn)[GPL], u32x4 (&gc)[GPL]) {      // n: register set of stage c + 3, c: of stage c + 1
+            const bool next = c + 1 < nstage;
+            if (next) load_w(c + 1, wcur);
+            if (c + 3 < nstage) issue_all(c + 3, gn);
+            WS_STAMP(1)      // requests of stage c + 3
+            if (next) {
+                wait_vmem_but_ws(per_stage(c + 2) + per_stage(c + 3));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wcur) : : "memory");
+            }
+            WS_STAMP(2)      // wait for stage c + 1
+            if (next) {
+#pragma unroll
+                for (int i = 0; i < GPL; ++i) { asm volatile("" : "+v"(gc[i])); put_piece(c + 1, i, gc[i], wcur); }
+            }
+            WS_STAMP(3)      // weighting + LDS stores of stage c + 1
+            __syncthreads();
+            WS_STAMP(4)      // barrier
+        };
+        for (int c = 0; c < nstage; c += 4) {
+            iter(c, gq3, gq1);
+            if (c + 1 < nstage) iter(c + 1, gq0, gq2);
+            if (c + 2 < nstage) iter(c + 2, gq1, gq3);
+            if (c + 3 < nstage) iter(c + 3, gq2, gq0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_STAMP_OUT()
+        return;
+    }
     if (wave >= NCW) {
         // ------------------------------------------------------------------ loader waves
         const int lw = wave - NCW;
@@ -2507,7 +2663,6 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
         const char* pbase[PPL];
         int plim[PPL];
         const int xstride = WG_SR * a.ldX * 2, gstride = WG_SR * a.ldG * 2;
-        int grow_l[GPL];                   // row (inside a stage) of the lane's 16 bytes in its G pieces
 #pragma unroll
         for (int i = 0; i < PPL; ++i) {
             const bool isx = i < XPL;
@@ -2520,9 +2675,8 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
             } else {
                 const int pc = lw * GPL + (i - XPL);
                 rl = RPP * pc + lane / SPR;
-                col = gcol0 + ((lane % SPR) ^ ((rl & 3) << 2)) * 8;
+                col = gcol0 + ((lane % SPR) ^ gswz(rl)) * 8;
                 ld = a.ldG;
-                grow_l[i - XPL] = rl;
             }
             pbase[i] = (const char*)(isx ? a.X : a.G) + ((size_t)(rbeg + rl) * ld + col) * 2;
             plim[i] = col < ld ? rend - rbeg - rl : -(1 << 30);
@@ -2536,58 +2690,18 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
                 glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (st % WG_NST) * BUF) + (uint32_t)pc * 1024u)));
             }
         };
-        // row weights of the lane's rows in this loader's G pieces of a stage (asm loads: the waits below count them by hand).
-        // Two register sets, alternating by stage parity: a set is overwritten (by loads issued two stages ahead) only after the
-        // stage it served has been scaled, and is read only behind the wait that covers its loads -- no copies of in-flight registers.
-        float s0[GPL], s1[GPL];
-#pragma unroll
-        for (int i = 0; i < GPL; ++i) { s0[i] = 0.0f; s1[i] = 0.0f; }
-        auto load_sc = [&](int st, float (&dst)[GPL]) {
-#pragma unroll
-            for (int i = 0; i < GPL; ++i) {
-                const int r = min(rbeg + st * WG_SR + grow_l[i], a.M - 1);
-                const float* pr = a.rowscale + r;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(dst[i]) : "v"(pr) : "memory");
-            }
-        };
-        auto scale_stage = [&](int st, float (&sc)[GPL]) {
-#pragma unroll
-            for (int i = 0; i < GPL; ++i) asm volatile("" : "+v"(sc[i]));      // (behind the wait: the loads are complete from here on)
-            if (WG_DBG(a, 8)) return;
-#pragma unroll
-            for (int i = 0; i < GPL; ++i) {
-                uint4* pz = (uint4*)(smem + (st % WG_NST) * BUF + (XP + lw * GPL + i) * 1024 + lane * 16);
-                const uint4 v = *pz;
-                const float f = sc[i];
-                *pz = make_uint4(pack2(bflo(v.x) * f, bfhi(v.x) * f), pack2(bflo(v.y) * f, bfhi(v.y) * f),
-                                 pack2(bflo(v.z) * f, bfhi(v.z) * f), pack2(bflo(v.w) * f, bfhi(v.w) * f));
-            }
-        };
-        constexpr int NSC = SC ? GPL : 0;
-        // prologue: sc(0) P(0) sc(1) P(1) P(2); stage 0 ready (scaled) behind the first barrier.  Stage st's weights live in set st & 1.
-        if (SC) load_sc(0, s0);
+        // prologue: P(0) P(1) P(2); stage 0 landed behind the first barrier
         if (0 < nstage) issue(0);
-        if (SC && 1 < nstage) load_sc(1, s1);
         if (1 < nstage) issue(1);
         if (2 < nstage) issue(2);
-        wait_vmem_but_ws((1 < nstage ? PPL + NSC : 0) + (2 < nstage ? PPL : 0));
-        if (SC) scale_stage(0, s0);
+        wait_vmem_but_ws((1 < nstage ? PPL : 0) + (2 < nstage ? PPL : 0));
         __syncthreads();
-        // iteration c: owned now are the buffer stage c - 1 has left (refill with stage c + 3) and stage c + 1 (scale it);
-        // issue order sc(c+2), P(c+3), so that the wait for stage c + 1 may leave P(c+2), sc(c+2), P(c+3) in flight
-        auto iter = [&](int c, float (&cur)[GPL], float (&nxt)[GPL]) {      // cur: weights of stage c + 1; nxt: receives those of stage c + 2
-            if (SC && c + 2 < nstage) load_sc(c + 2, nxt);
+        // iteration c: the buffer stage c - 1 has left is refilled with stage c + 3; the wait for stage c + 1 leaves P(c+2), P(c+3) in flight
+        for (int c = 0; c < nstage; ++c) {
             const bool refill = c + 3 < nstage && !WG_DBG(a, 1);
             if (refill) issue(c + 3);
-            if (c + 1 < nstage) {
-                wait_vmem_but_ws((c + 2 < nstage ? PPL + NSC : 0) + (refill ? PPL : 0));
-                if (SC) scale_stage(c + 1, cur);
-            }
+            if (c + 1 < nstage) wait_vmem_but_ws((c + 2 < nstage ? PPL : 0) + (refill ? PPL : 0));
             __syncthreads();
-        };
-        for (int c = 0; c < nstage; c += 2) {
-            iter(c, s1, s0);
-            if (c + 1 < nstage) iter(c + 1, s0, s1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -2607,6 +2721,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
     const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
     const bool do_bias = ig == 0 && !WG_DBG(a, 4);
     __syncthreads();
+    WS_STAMP(0)          // prologue
     for (int c = 0; c < nstage; ++c) {
         const int buf = c % WG_NST;
         const char* xb = smem + buf * BUF + xrow_off + p * 16;
@@ -2615,12 +2730,13 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
 #pragma unroll
         for (int u = 0; u < BJ; ++u) {
             const int jl = jg * BJ + u;
-            const char* gb = gbase + ((((4 * (jl >> 1)) ^ (qp << 2)) + p) * 16) + 8 * (jl & 1);
+            const char* gb = gbase + ((((4 * (jl >> 1)) ^ gswz(qp)) + p) * 16) + 8 * (jl & 1);
             const v4s g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)gb);
             const v4s g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(gb + 16 * GROW));
             const uint2 glo = __builtin_bit_cast(uint2, g0), ghi = __builtin_bit_cast(uint2, g1);
             g[u] = make_uint4(glo.x, glo.y, ghi.x, ghi.y);
         }
+        WS_STAMP(1)      // G fragments read
         if (!WG_DBG(a, 2)) {
             lds_pipeline<AI, 3>(
                 [&](int t) {       // A fragment of i-tile i: P chunk 4*(i>>1)+p (swizzled by the row), half i&1
@@ -2640,14 +2756,16 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
 #pragma unroll
             for (int u = 0; u < BJ; ++u) accb[u] = mfma16(ones, g[u], accb[u]);
         }
+        WS_STAMP(2)      // A fragments + MFMAs issued
         __syncthreads();
+        WS_STAMP(3)      // barrier
     }
     if (WG_DBG(a, 16)) return;
     // D: lane(col j = lane&15, quad q) reg ii -> out[i = 16*it + 4q + ii][j]
     float* slab = a.slabW + (size_t)bz * a.IT * 16 * a.JT * 16;
 #pragma unroll
     for (int u = 0; u < BJ; ++u) {
-        const int jt = bx * STRIP + jg * BJ + u;
+        const int jt = jt0 + jg * BJ + u;
         if (jt < a.JT) {
 #pragma unroll
             for (int t = 0; t < AI; ++t) {
@@ -2661,18 +2779,31 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, int bx, int bz
             if (ig == 0 && q == 0) a.slabB[(size_t)bz * a.JT * 16 + jt * 16 + l16] = accb[u][0];
         }
     }
+    WS_STAMP(4)          // slab stores issued
+    WS_STAMP_OUT()
 }
 
 template <bool SC, int BJ, int NLW>
 __global__ __launch_bounds__((8 + NLW) * 64, NLW == 8 ? 4 : 3) void wgradws_kernel(WgradPArgs a) {
-    wgradws_body<SC, BJ, NLW>(a, blockIdx.x, blockIdx.z, gridDim.x, gridDim.z);
+    int bx = blockIdx.x, bz = blockIdx.z;
+    wgradws_block(bx, bz, gridDim.x, gridDim.z);
+    const int sid = bz * (int)gridDim.x + bx;
+    if constexpr (SC && BJ == 4) {
+        // a last column block of <= 64 real out-features (the reference's 784 pixels = 3 x 256 + 64, padded to 832): its workgroups
+        // take the 64-wide strip shape -- 4 instead of 16 G pieces per stage, 7 instead of 28 MFMAs per wave -- instead of fetching and
+        // multiplying 192 columns of zeros (workgroup-uniform branch)
+        if (bx == (int)gridDim.x - 1 && a.JT - bx * 16 <= 4) { wgradws_body<SC, 1, NLW>(a, bx * 16, bz, sid); return; }
+    }
+    wgradws_body<SC, BJ, NLW>(a, bx * 4 * BJ, bz, sid);
 }
 // two (or three) of them in one launch: blockIdx.z runs over the concatenated row splits
 __global__ __launch_bounds__(768, 3) void wgradws_group_kernel(WgradPGroup g) {
     int l = 0;
     while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
     if ((int)blockIdx.x >= g.gx[l]) return;          // (uniform per workgroup: no barrier is skipped by part of a workgroup)
-    wgradws_body<false, 4, 4>(g.a[l], blockIdx.x, blockIdx.z - g.zbeg[l], g.gx[l], g.zbeg[l + 1] - g.zbeg[l]);
+    int bx = blockIdx.x, bz = blockIdx.z - g.zbeg[l];
+    wgradws_block(bx, bz, g.gx[l], g.zbeg[l + 1] - g.zbeg[l]);
+    wgradws_body<false, 4, 4>(g.a[l], bx * 16, bz, 0);
 }
 
 // Several small weight gradients in ONE launch (the three layers of an encoder block over B rows are ~30-130 blocks

@@ -572,6 +572,7 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     a.X = XP; a.ldX = L.Kp32; a.IT = L.IT; a.G = GP; a.ldG = L.Np32; a.JT = L.JT; a.M = rows; a.rows_per_split = cps * 64;
     a.slabW = ptr<float>(L.slabW); a.slabB = ptr<float>(L.slabB); a.zero = m->d_zero; a.rowscale = nullptr;
     a.dbg = m->wg_debug;
+    a.stamps = nullptr;
     return IWAE_OK;
 }
 
@@ -581,6 +582,13 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
     int nsplit = 1, nw = 8;
     CHK(wgradp_plan(m, L, XP, GP, rows, a, nsplit, nw));
     a.rowscale = rowscale;
+#ifdef IWAE_DENSE_STAMPS
+    if (m->dstamp_epi == 10 && rowscale && nw == 7) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 10): phase stamps of the output layer's weight gradient
+        m->dstamp_waves = ((L.JT + 15) / 16) * nsplit * 12;
+        CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, m->stream));
+        a.stamps = ptr<unsigned long long>(m->dstamps);
+    }
+#endif
     launch_wgradp(a, nsplit, nw, st ? st : m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
