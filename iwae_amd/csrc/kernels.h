@@ -162,6 +162,23 @@ struct WgradPGroup {                        // up to 3 independent 8-wave weight
     int zbeg[4];                            // first blockIdx.z of each (zbeg[n] = total)
 };
 
+struct Chain2FwdArgs {                // chain2_fwd_kernel: the 2-layer model's per-sample blocks (q(z2|z1) and p(z1|z2)) on M rows, one launch
+    const uint16_t* Z1P;              // z1 rows, bf16 P-layout [M][32*KT0] (made by sample_kernel)
+    const char *e_img1, *e_img2, *e_imgh;     // MG-major forward images of encode_z1_to_z2: l1 (KT0 k-steps), l2, head (KTH k-steps each)
+    const char *d_img1, *d_img2, *d_imgh;     // ... of decode_z2_to_z1: l1 (KT1 k-steps), l2, head (KTH k-steps each)
+    int M, k, B, D0, D1;              // data rows, samples per image, images; latent widths of z1 and z2
+    uint16_t *EH1, *EH2;              // encode block's tanh activations, P-layout [M][32*KTH], kept for the backward pass (null: forward only)
+    float* EHEAD;                     // its head, fp32 [M][64*KT1] (mu2 | sigma2), or null
+    uint16_t* Z2P;                    // z2 rows, P-layout [M][32*KT1], or null
+    uint16_t *DH1, *DH2;              // decode block's tanh activations, or null
+    float* DHEAD;                     // its head, fp32 [M][64*KT0] (mu_p | sigma_p), or null
+    const float* head1; int ldH1;     // head of q(z1|x) per image [B][ldH1] (mu1 | sigma1 at 32*KT0): z1 in float32 for log p(z1|z2)
+    EpsSrc eps1, eps2;                // the draws of z1 and z2
+    float *lpz1z2, *lpz2, *lqz2z1;    // per-row log-densities (iwae2.py:122-124)
+};
+bool chain2_fwd_ok(int KT0, int KTH, int KT1, int M);
+void launch_chain2_fwd(const Chain2FwdArgs& a, hipStream_t st);
+
 struct GaussLpArgs {
     const float* zhead; int ldZH; int Dzp;   // head that generated z (per image)
     const float* phead; int ldPH; int Dpp;   // head that scores z (per row)

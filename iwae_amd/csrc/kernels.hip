@@ -1427,6 +1427,200 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
 }
 
 // ---------------------------------------------------------------------------------
+// chain2_fwd_kernel (round 3): the per-sample blocks of the 2-layer model's forward pass in ONE launch at large row counts --
+//   q(z2|z1) = BasicBlock(z1) (iwae2.py:63-64), z2 = mu2 + sigma2*eps2 with log q(z2|z1) and log p(z2) (:65, :119, :124),
+//   p(z1|z2) = BasicBlock(z2) (iwae2.py:90) and log p(z1|z2) (:122).
+// As dense_kernel launches these were six GEMM launches + sample_kernel + gauss_lp_kernel with every activation and both float32
+// heads (1.5 KB per row) making a round trip through HBM between them (~130 us of kernel time at 51 200 rows).  Here a wave owns
+// 16 rows through all six layers: a layer's converted accumulators ARE the next layer's B operand (layout.h), the mu accumulators
+// wait in registers for their sigma group, z2 and the three log-densities are made in the epilogue that already holds their
+// operands.  The weights stream through two LDS buffers one 64-out-feature group at a time (units 0..: l1, l2, head of the encode
+// block, then of the decode block), each unit's DMA issued behind the previous unit's barrier.  The hidden activations (and, for
+// the unfused backward kernels, the heads) are stored once for the backward pass; a forward-only call stores nothing but z2.
+// Shapes: latent widths padded to 64-feature groups (KT0, KT1 even), one hidden width KTH for both blocks.
+// ---------------------------------------------------------------------------------
+template <int KT0, int KTH, int KT1>
+__global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
+    static_assert(KT0 % 2 == 0 && KT1 % 2 == 0 && KT0 <= 4 && KTH <= 4 && KT1 <= 4, "64-feature latent groups, <= 128 features everywhere");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NWV = 8;
+    constexpr int KTMAX = KT0 > KTH ? (KT0 > KT1 ? KT0 : KT1) : (KTH > KT1 ? KTH : KT1);
+    constexpr int UNIT = KTMAX * 4096 + 1024, NIDX = (4 * KTMAX + 1 + NWV - 1) / NWV;
+    constexpr int MGH = (KTH + 1) / 2;                       // 64-feature groups of a hidden layer
+    constexpr int U_E2 = MGH, U_EH = 2 * MGH, U_D1 = U_EH + KT1, U_D2 = U_D1 + MGH, U_DH = U_D2 + MGH, NUNITS = U_DH + KT0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * NWV + wave) * 16 + rho;
+    const bool valid = row < a.M;
+    const int rowc = min(row, a.M - 1);
+    const int b = rowc / a.k, sidx = rowc - b * a.k;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+
+    auto dma_unit = [&](int uu, int buf) {                 // uu wave-uniform
+        const char* src; int kt;
+        if (uu < U_E2) { src = a.e_img1 + (size_t)uu * img_mg_group_bytes(KT0); kt = KT0; }
+        else if (uu < U_EH) { src = a.e_img2 + (size_t)(uu - U_E2) * img_mg_group_bytes(KTH); kt = KTH; }
+        else if (uu < U_D1) { src = a.e_imgh + (size_t)(uu - U_EH) * img_mg_group_bytes(KTH); kt = KTH; }
+        else if (uu < U_D2) { src = a.d_img1 + (size_t)(uu - U_D1) * img_mg_group_bytes(KT1); kt = KT1; }
+        else if (uu < U_DH) { src = a.d_img2 + (size_t)(uu - U_D2) * img_mg_group_bytes(KTH); kt = KTH; }
+        else { src = a.d_imgh + (size_t)(uu - U_DH) * img_mg_group_bytes(KTH); kt = KTH; }
+        const int npc = 4 * kt + 1;
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) {
+            const int p = wave + NWV * idx;
+            if (p < npc)
+                glds16(src + (size_t)p * 1024 + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
+        }
+    };
+    dma_unit(0, 0);
+    uint4 zf[KT0];
+#pragma unroll
+    for (int ks = 0; ks < KT0; ++ks) {
+        const uint4 v = *(const uint4*)(a.Z1P + (size_t)rowc * (32 * KT0) + ks * 32 + q * 8);
+        zf[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+    }
+    int u = 0;
+    // one unit: the 4 accumulator tiles (64 out-features x 16 rows) of a weight group, started from the group's bias block
+    auto unit_mfma = [&](auto kt_tag, const uint4* bin, f32x4 (&acc)[4]) {
+        constexpr int KTin = decltype(kt_tag)::value;
+        const int buf = u & 1;
+        wait_all_vmem();
+        __syncthreads();
+        if (u + 1 < NUNITS) dma_unit(u + 1, buf ^ 1);
+        const char* lb = smem + buf * UNIT + a_off;
+        const char* lbias = smem + buf * UNIT + KTin * 4096 + q * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 c = *(const float4*)(lbias + 64 * t);
+            acc[t] = (f32x4){c.x, c.y, c.z, c.w};
+        }
+        lds_pipeline<KTin * 4, 4>([&](int i) { return *(const uint4*)(lb + i * 1024); },
+                                  [&](int i, const uint4& av) { acc[i & 3] = mfma16(av, bin[i >> 2], acc[i & 3]); });
+        ++u;
+    };
+    // a tanh layer: MGH units; tile pair (2p, 2p+1) of group mg is k-step 2mg + p of the next layer's operand (and of the stored rows)
+    auto tanh_layer = [&](auto kt_tag, const uint4* bin, uint4 (&bout)[KTH], uint16_t* Hout) {
+#pragma unroll
+        for (int mg = 0; mg < MGH; ++mg) {
+            f32x4 acc[4];
+            unit_mfma(kt_tag, bin, acc);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int kso = 2 * mg + p2;
+                if (kso < KTH) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
+                    const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                    bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
+                    if (valid && Hout) *(uint4*)(Hout + (size_t)row * (32 * KTH) + kso * 32 + q * 8) = frag;
+                }
+            }
+        }
+    };
+    auto quad_sum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+
+    // ---- q(z2|z1): encode_z1_to_z2 (iwae2.py:63-64)
+    uint4 h1f[KTH], h2f[KTH];
+    tanh_layer(std::integral_constant<int, KT0>{}, zf, h1f, a.EH1);
+    tanh_layer(std::integral_constant<int, KTH>{}, h1f, h2f, a.EH2);
+    // head: the mu groups first (their accumulators wait), then the sigma groups; z2 = mu2 + sigma2 * eps2 (iwae2.py:65)
+    uint4 z2f[KT1];
+    {
+        constexpr int NG = KT1 / 2;               // 64-feature groups of mu2 (and of sigma2)
+        f32x4 mu2[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) unit_mfma(std::integral_constant<int, KTH>{}, h2f, mu2[g]);
+        float lp = 0.0f, lq = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 sa[4];
+            unit_mfma(std::integral_constant<int, KTH>{}, h2f, sa);
+            float zt[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f0 = 64 * g + 16 * t + 4 * q;
+                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (f0 < a.D1) eps4(a.eps2, b, sidx, rowc, f0 >> 2, a.D1, e);
+                float sg4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sg = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;          // iwae2.py:43 (exp activation), :45 (+ 1e-6)
+                    sg4[i] = sg;
+                    float z = 0.0f;
+                    if (f0 + i < a.D1) {
+                        const float mu = mu2[g][t][i];
+                        z = fmaf(sg, e[i], mu);
+                        lp += -0.5f * z * z - 0.5f * LOG2PI_F;                      // log p(z2), iwae2.py:119
+                        const float uu = (z - mu) * __builtin_amdgcn_rcpf(sg);
+                        lq += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sg);       // log q(z2|z1), iwae2.py:124
+                    }
+                    zt[t][i] = z;
+                }
+                if (valid && a.EHEAD) {
+                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + f0) = make_float4(mu2[g][t][0], mu2[g][t][1], mu2[g][t][2], mu2[g][t][3]);
+                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + 32 * KT1 + f0) = make_float4(sg4[0], sg4[1], sg4[2], sg4[3]);
+                }
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const uint4 frag = make_uint4(pack2(zt[2 * p2][0], zt[2 * p2][1]), pack2(zt[2 * p2][2], zt[2 * p2][3]),
+                                              pack2(zt[2 * p2 + 1][0], zt[2 * p2 + 1][1]), pack2(zt[2 * p2 + 1][2], zt[2 * p2 + 1][3]));
+                z2f[2 * g + p2] = valid ? frag : make_uint4(0, 0, 0, 0);
+                if (valid && a.Z2P) *(uint4*)(a.Z2P + (size_t)row * (32 * KT1) + (2 * g + p2) * 32 + q * 8) = frag;
+            }
+        }
+        lp = quad_sum(lp); lq = quad_sum(lq);
+        if (q == 0 && valid) { a.lpz2[row] = lp; a.lqz2z1[row] = lq; }
+    }
+    // ---- p(z1|z2): decode_z2_to_z1 (iwae2.py:90) and log p(z1|z2) (iwae2.py:122), z1 = mu1 + sigma1 * eps1 in float32
+    uint4 g1f[KTH], g2f[KTH];
+    tanh_layer(std::integral_constant<int, KT1>{}, z2f, g1f, a.DH1);
+    tanh_layer(std::integral_constant<int, KTH>{}, g1f, g2f, a.DH2);
+    {
+        constexpr int NG = KT0 / 2;
+        f32x4 mup[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) unit_mfma(std::integral_constant<int, KTH>{}, g2f, mup[g]);
+        float lp = 0.0f;
+        const float* hz = a.head1 + (size_t)b * a.ldH1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 sa[4];
+            unit_mfma(std::integral_constant<int, KTH>{}, g2f, sa);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f0 = 64 * g + 16 * t + 4 * q;
+                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float4 zm = make_float4(0.f, 0.f, 0.f, 0.f), zs = zm;
+                if (f0 < a.D0) {
+                    eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e);
+                    zm = *(const float4*)(hz + f0); zs = *(const float4*)(hz + 32 * KT0 + f0);
+                }
+                const float zmv[4] = {zm.x, zm.y, zm.z, zm.w}, zsv[4] = {zs.x, zs.y, zs.z, zs.w};
+                float sg4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sg = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;
+                    sg4[i] = sg;
+                    if (f0 + i < a.D0) {
+                        const float z = zmv[i] + zsv[i] * e[i];
+                        const float uu = (z - mup[g][t][i]) * __builtin_amdgcn_rcpf(sg);
+                        lp += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sg);
+                    }
+                }
+                if (valid && a.DHEAD) {
+                    *(float4*)(a.DHEAD + (size_t)row * (64 * KT0) + f0) = make_float4(mup[g][t][0], mup[g][t][1], mup[g][t][2], mup[g][t][3]);
+                    *(float4*)(a.DHEAD + (size_t)row * (64 * KT0) + 32 * KT0 + f0) = make_float4(sg4[0], sg4[1], sg4[2], sg4[3]);
+                }
+            }
+        }
+        lp = quad_sum(lp);
+        if (q == 0 && valid) a.lpz1z2[row] = lp;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // out_bwd_kernel: backward of the Bernoulli output layer for one block of rows, logits
 // recomputed on the fly (never stored): per 64-pixel group
 //   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also stored, P-layout, for dV3)
@@ -3634,6 +3828,10 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
         case 8: launch_dense_k<8>(epi, a, grid, lds, st); break;
         default: launch_dense_k<0>(epi, a, grid, a.stage_all ? 4 * DENSE_UNIT : lds, st); break;
     }
+}
+bool chain2_fwd_ok(int KT0, int KTH, int KT1, int M) { return KT0 == 4 && KTH == 4 && KT1 == 2 && M >= 8192; }
+void launch_chain2_fwd(const Chain2FwdArgs& a, hipStream_t st) {
+    LAUNCH_EV((chain2_fwd_kernel<4, 4, 2>), dim3((a.M + 127) / 128), dim3(512), 2 * (4 * 4096 + 1024), st, a);
 }
 bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
 void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st) {

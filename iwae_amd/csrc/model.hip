@@ -238,6 +238,7 @@ struct iwae_model {
     bool small_dec_bwd = true; int small_rows = 8191;   // the one-launch dX chain also below 8 192 rows (IWAE_NO_SMALL_DEC_BWD=1: the per-pixel-group out_bwd + finish + two dX launches
                                                         // there).  Measured: B=20,k=1 0.1417 -> 0.1383 ms/step, B=100,k=5 150.7 -> 144.6 us, B=160,k=50 189.1 -> 165.7 us
     bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
+    bool allow_chain2 = true;   // option no_chain2: the 2-layer model's per-sample blocks as dense_kernel launches + sample_kernel + gauss_lp_kernel (A/B measurements, variant tests)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
     bool allow_out_in_block = true;  // IWAE_NO_OUT_IN_BLOCK=1: the output layer of a few-row decoder stays a dense_kernel<EPI_BERN> launch (A/B measurements)
@@ -815,8 +816,32 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (two) {
         // ---- q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
         CHK(block_alloc(m, m->enc2, m->wenc2, M, Mp, bwd, true));
-        CHK(block_fwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M));
         CHK(ensure(m->zP[1], (size_t)Mp * m->Dp[1] * 2, st));
+        CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
+        // large row counts, the reference's dims: both per-sample blocks, the z2 sampling and the three log-densities in ONE launch
+        const Linear *e2 = m->enc2, *d2 = m->dec2;
+        const bool chain = m->allow_chain2 && chain2_fwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].Kp32 == m->Dp[0] && e2[0].Np32 == 32 * e2[1].KT &&
+                           e2[1].Np32 == e2[0].Np32 && e2[2].KT == e2[1].KT && e2[2].Np32 == 2 * m->Dp[1] && d2[0].Kp32 == m->Dp[1] && d2[0].Np32 == e2[0].Np32 &&
+                           d2[1].KT == e2[1].KT && d2[1].Np32 == d2[0].Np32 && d2[2].KT == e2[1].KT && d2[2].Np32 == 2 * m->Dp[0];
+        if (chain) {
+            Chain2FwdArgs c;
+            memset(&c, 0, sizeof(c));
+            c.Z1P = ptr<uint16_t>(m->zP[0]);
+            c.e_img1 = e2[0].imgF; c.e_img2 = e2[1].imgF; c.e_imgh = e2[2].imgF;
+            c.d_img1 = d2[0].imgF; c.d_img2 = d2[1].imgF; c.d_imgh = d2[2].imgF;
+            c.M = M; c.k = k; c.B = B; c.D0 = m->D[0]; c.D1 = m->D[1];
+            const bool keep = bwd || want != nullptr;      // the backward pass (and the z2 / snis exports) read the blocks' activations and heads
+            c.EH1 = keep ? ptr<uint16_t>(m->wenc2.h1P) : nullptr; c.EH2 = keep ? ptr<uint16_t>(m->wenc2.h2P) : nullptr;
+            c.EHEAD = keep ? ptr<float>(m->wenc2.head) : nullptr;
+            c.Z2P = ptr<uint16_t>(m->zP[1]);
+            c.DH1 = keep ? ptr<uint16_t>(m->wdec2.h1P) : nullptr; c.DH2 = keep ? ptr<uint16_t>(m->wdec2.h2P) : nullptr;
+            c.DHEAD = keep ? ptr<float>(m->wdec2.head) : nullptr;
+            c.head1 = ptr<float>(m->wenc1.head); c.ldH1 = 2 * m->Dp[0];
+            c.eps1 = eps_src(m, 0); c.eps2 = eps_src(m, 1);
+            c.lpz1z2 = t1; c.lpz2 = t2; c.lqz2z1 = t4;
+            launch_chain2_fwd(c, st);
+        } else {
+        CHK(block_fwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M));
         SampleArgs s;
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc2.head); s.ldH = 2 * m->Dp[1]; s.Dp = m->Dp[1]; s.D = m->D[1]; s.head_per_row = 1;
@@ -824,7 +849,6 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.ZP = ptr<uint16_t>(m->zP[1]);
         s.lp_prior = t2; s.lq = t4; s.lq_dreg = nullptr;
         launch_sample(s, st);
-        CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
         CHK(block_fwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M));
         GaussLpArgs g;
         memset(&g, 0, sizeof(g));
@@ -832,6 +856,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         g.phead = ptr<float>(m->wdec2.head); g.ldPH = 2 * m->Dp[0]; g.Dpp = m->Dp[0];
         g.D = m->D[0]; g.M = M; g.k = k; g.eps = eps_src(m, 0); g.out = t1;
         launch_gauss_lp(g, st);
+        }
     }
 
     // ---- decoder + Bernoulli log-likelihood (iwae1.py:81-83,111)
@@ -2043,6 +2068,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     if (n == "out_recompute") m->allow_s_mode = !on;                  // recompute the logits in out_bwd instead of keeping s
     else if (n == "no_defer") m->allow_defer = !on;                   // join the decoder update at the end of every step
     else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
+    else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32
