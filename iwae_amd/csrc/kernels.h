@@ -179,6 +179,26 @@ struct Chain2FwdArgs {                // chain2_fwd_kernel: the 2-layer model's 
 bool chain2_fwd_ok(int KT0, int KTH, int KT1, int M);
 void launch_chain2_fwd(const Chain2FwdArgs& a, hipStream_t st);
 
+struct GBlockBwdArgs {                // gblock_bwd_kernel: backward of a per-sample BasicBlock of the 2-layer model from its Gaussian head, one launch
+    const char* imgH;                 // FORWARD image of the head (KTH k-steps, KTL groups: mu groups then sigma groups): the head is recomputed
+    const char *imgBh, *imgB2, *imgB1;   // backward images (MG-major) of the head (2*KTL k-steps), l2 and l1 (KTH k-steps each)
+    const uint16_t *H2, *H1;          // the block's stored tanh activations, P-layout [M][32*KTH]
+    const float* gx;                  // [M] dLoss/dlog_w of the row
+    int M, k, B, D;                   // D: real width of the head's latent
+    EpsSrc eps;                       // MODE 0: the draws of z1; MODE 1: the draws of z2
+    const float* head1; int ldH1;     // MODE 0: head of q(z1|x) per image (z1 = mu1 + sigma1*eps1 in float32)
+    const float* DZIN;                // MODE 1: dz2 from the decode block, float32 [M][32*KTL]
+    uint16_t* DHP;                    // dhead, P-layout [M][64*KTL] (for the head's weight gradient)
+    uint16_t *D2P, *D1P;              // dpre of l2 / l1, P-layout [M][32*KTH]
+    float* DZ2;                       // MODE 0: dz2 out, float32 [M][32*KTIN]
+    uint16_t* DZD;                    // MODE 0: out, MODE 1: in -- the direct term of dz1 (-dm), bf16 [M][128] natural feature order
+    const float* DZDEC;               // MODE 1: dz1 from the z1 -> x decoder, float32 [M][ldDZDEC]
+    int ldDZDEC;
+    uint16_t* DZOUT;                  // MODE 1: the three terms of dz1 summed, bf16 [M][32*KTIN] natural feature order (latent_bwd_kernel's input)
+};
+bool gblock_bwd_ok(int KT0, int KTH, int KT1, int M);
+void launch_gblock_bwd(int mode, const GBlockBwdArgs& a, hipStream_t st);
+
 struct GaussLpArgs {
     const float* zhead; int ldZH; int Dzp;   // head that generated z (per image)
     const float* phead; int ldPH; int Dpp;   // head that scores z (per row)

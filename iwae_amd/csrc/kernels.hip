@@ -1621,6 +1621,191 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// gblock_bwd_kernel (round 3): the backward pass of one per-sample BasicBlock of the 2-layer model, FROM its Gaussian head, in one launch
+// at large row counts.  As separate launches this was gauss_bwd_kernel (reading the stored float32 head, 0.5-1 KB per row) + three
+// dense_kernel<EPI_DX / EPI_F32> launches with dhead / dpre2 / dpre1 / dz making round trips through HBM.  Here a wave owns 16 rows:
+//   A. the head is RECOMPUTED from the stored h2 (KTL weight groups through the matrix pipe: cheaper than storing and re-reading it --
+//      the forward pass no longer writes the heads at all), and its gradient made in that epilogue:
+//        MODE 0, decode_z2_to_z1 (iwae2.py:90,122): u = (z1 - mu_p)/sigma_p,  dhead = G [ u/sigma_p | (u^2 - 1)/sigma_p * (sigma_p - 1e-6) ],
+//                the direct term of dz1, -G u/sigma_p, kept as bf16 for MODE 1's launch;
+//        MODE 1, encode_z1_to_z2 (iwae2.py:63-65,119,124): dz2 = dz2_dec - G z2,  dhead = [ dz2 | (dz2 eps2 + G/sigma2)(sigma2 - 1e-6) ];
+//   B-D. the dX chain d2 = (dhead Wh^T)(1 - h2^2), d1 = (d2 W2^T)(1 - h1^2), dz_in = d1 W1^T with every converted accumulator the next
+//      product's B operand (layout.h); dhead, d2, d1 are stored once (bf16) for the weight gradients.  MODE 1 adds the other two terms of
+//      dz1 (the decoder's, float32, and MODE 0's) to its own and stores the sum as bf16 -- latent_bwd_kernel then reads one tensor, not three.
+// Weights: the forward head image, then the three backward images, one 64-feature group per unit through two LDS buffers.
+// ---------------------------------------------------------------------------------
+template <int MODE, int KTIN, int KTH, int KTL>
+__global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
+    static_assert(KTIN % 2 == 0 && KTL % 2 == 0 && KTIN <= 4 && KTH <= 4 && KTL <= 4, "64-feature latent groups, <= 128 features");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int NWV = 8, KTD = 2 * KTL;                    // k-steps of dhead
+    constexpr int KTMAX = KTD > KTH ? KTD : KTH;
+    constexpr int UNIT = KTMAX * 4096 + 1024, NIDX = (4 * KTMAX + 1 + NWV - 1) / NWV;
+    constexpr int MGH = (KTH + 1) / 2, NGL = KTL / 2, NGI = KTIN / 2;
+    constexpr int U_B = KTL, U_C = U_B + MGH, U_D = U_C + MGH, NUNITS = U_D + NGI;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int row = (blockIdx.x * NWV + wave) * 16 + rho;
+    const bool valid = row < a.M;
+    const int rowc = min(row, a.M - 1);
+    const int b = rowc / a.k, sidx = rowc - b * a.k;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+
+    auto dma_unit = [&](int uu, int buf) {                 // uu wave-uniform
+        const char* src; int kt;
+        if (uu < U_B) { src = a.imgH + (size_t)uu * img_mg_group_bytes(KTH); kt = KTH; }
+        else if (uu < U_C) { src = a.imgBh + (size_t)(uu - U_B) * img_mg_group_bytes(KTD); kt = KTD; }
+        else if (uu < U_D) { src = a.imgB2 + (size_t)(uu - U_C) * img_mg_group_bytes(KTH); kt = KTH; }
+        else { src = a.imgB1 + (size_t)(uu - U_D) * img_mg_group_bytes(KTH); kt = KTH; }
+        const int npc = 4 * kt + 1;
+#pragma unroll
+        for (int idx = 0; idx < NIDX; ++idx) {
+            const int p = wave + NWV * idx;
+            if (p < npc)
+                glds16(src + (size_t)p * 1024 + lane * 16, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + buf * UNIT) + (uint32_t)p * 1024u)));
+        }
+    };
+    dma_unit(0, 0);
+    const float G = valid ? a.gx[rowc] : 0.0f;
+    uint4 hf2[KTH];
+#pragma unroll
+    for (int ks = 0; ks < KTH; ++ks) {
+        const uint4 v = *(const uint4*)(a.H2 + (size_t)rowc * (32 * KTH) + ks * 32 + q * 8);
+        hf2[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+    }
+    int u = 0;
+    auto unit_mfma = [&](auto kt_tag, auto bias_tag, const uint4* bin, f32x4 (&acc)[4]) {
+        constexpr int KTin = decltype(kt_tag)::value;
+        const int buf = u & 1;
+        wait_all_vmem();
+        __syncthreads();
+        if (u + 1 < NUNITS) dma_unit(u + 1, buf ^ 1);
+        const char* lb = smem + buf * UNIT + a_off;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (decltype(bias_tag)::value) {
+                const float4 c = *(const float4*)(smem + buf * UNIT + KTin * 4096 + q * 16 + 64 * t);
+                acc[t] = (f32x4){c.x, c.y, c.z, c.w};
+            } else acc[t] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        lds_pipeline<KTin * 4, 4>([&](int i) { return *(const uint4*)(lb + i * 1024); },
+                                  [&](int i, const uint4& av) { acc[i & 3] = mfma16(av, bin[i >> 2], acc[i & 3]); });
+        ++u;
+    };
+    // ---- A. the head again (mu groups, then sigma groups) and its gradient
+    uint4 dhf[KTD];
+    {
+        f32x4 muh[NGL][4];
+#pragma unroll
+        for (int g = 0; g < NGL; ++g) unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, muh[g]);
+        const float* hz = MODE == 0 ? a.head1 + (size_t)b * a.ldH1 : nullptr;
+#pragma unroll
+        for (int g = 0; g < NGL; ++g) {
+            f32x4 sa[4];
+            unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, sa);
+            float dmv[4][4], dsv[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f0 = 64 * g + 16 * t + 4 * q;
+                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), y4 = x4;
+                if (f0 < a.D) {
+                    eps4(a.eps, b, sidx, rowc, f0 >> 2, a.D, e);
+                    if (MODE == 0) { x4 = *(const float4*)(hz + f0); y4 = *(const float4*)(hz + 32 * KTL + f0); }     // mu1, sigma1 of the image
+                    else x4 = *(const float4*)(a.DZIN + (size_t)rowc * (32 * KTL) + f0);                               // dz2 from the decode block
+                }
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
+                float dzd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float dm = 0.0f, ds = 0.0f;
+                    if (f0 + i < a.D) {
+                        const float mu = muh[g][t][i], sg = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f, rs = __builtin_amdgcn_rcpf(sg);
+                        if (MODE == 0) {
+                            const float z = xv[i] + yv[i] * e[i];
+                            const float uu = (z - mu) * rs;
+                            dm = G * uu * rs;
+                            ds = G * (uu * uu - 1.0f) * rs * (sg - 1e-6f);
+                            dzd[i] = -dm;
+                        } else {
+                            const float z = mu + sg * e[i];
+                            const float d = xv[i] - G * z;
+                            dm = d;
+                            ds = (d * e[i] + G * rs) * (sg - 1e-6f);
+                        }
+                    }
+                    dmv[t][i] = dm; dsv[t][i] = ds;
+                }
+                if (MODE == 0 && valid) *(uint2*)(a.DZD + (size_t)row * (32 * KTL) + f0) = make_uint2(pack2(dzd[0], dzd[1]), pack2(dzd[2], dzd[3]));
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const uint4 fm = make_uint4(pack2(dmv[2 * p2][0], dmv[2 * p2][1]), pack2(dmv[2 * p2][2], dmv[2 * p2][3]),
+                                            pack2(dmv[2 * p2 + 1][0], dmv[2 * p2 + 1][1]), pack2(dmv[2 * p2 + 1][2], dmv[2 * p2 + 1][3]));
+                const uint4 fs = make_uint4(pack2(dsv[2 * p2][0], dsv[2 * p2][1]), pack2(dsv[2 * p2][2], dsv[2 * p2][3]),
+                                            pack2(dsv[2 * p2 + 1][0], dsv[2 * p2 + 1][1]), pack2(dsv[2 * p2 + 1][2], dsv[2 * p2 + 1][3]));
+                dhf[2 * g + p2] = valid ? fm : make_uint4(0, 0, 0, 0);
+                dhf[KTL + 2 * g + p2] = valid ? fs : make_uint4(0, 0, 0, 0);
+                if (valid) {
+                    *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (2 * g + p2) * 32 + q * 8) = fm;
+                    *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (KTL + 2 * g + p2) * 32 + q * 8) = fs;
+                }
+            }
+        }
+    }
+    // a dX product with the tanh' of the stored activation: dout = (din W^T) * (1 - act^2)
+    auto dx_layer = [&](auto kt_tag, const uint4* din, const uint4* act, uint4 (&dout)[KTH], uint16_t* Dst) {
+#pragma unroll
+        for (int mg = 0; mg < MGH; ++mg) {
+            f32x4 acc[4];
+            unit_mfma(kt_tag, std::false_type{}, din, acc);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int kso = 2 * mg + p2;
+                if (kso < KTH) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float y = bf_at(act[kso], j); v[j] = acc[2 * p2 + (j >> 2)][j & 3] * (1.0f - y * y); }
+                    const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+                    dout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
+                    if (valid) *(uint4*)(Dst + (size_t)row * (32 * KTH) + kso * 32 + q * 8) = frag;
+                }
+            }
+        }
+    };
+    // ---- B. d2 = (dhead Wh^T)(1 - h2^2)
+    uint4 d2f[KTH];
+    dx_layer(std::integral_constant<int, KTD>{}, dhf, hf2, d2f, a.D2P);
+    // ---- C. d1 = (d2 W2^T)(1 - h1^2)
+    uint4 hf1[KTH], d1f[KTH];
+#pragma unroll
+    for (int ks = 0; ks < KTH; ++ks) {
+        const uint4 v = *(const uint4*)(a.H1 + (size_t)rowc * (32 * KTH) + ks * 32 + q * 8);
+        hf1[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+    }
+    dx_layer(std::integral_constant<int, KTH>{}, d2f, hf1, d1f, a.D1P);
+    // ---- D. gradient of the block's input: dz = d1 W1^T
+#pragma unroll
+    for (int g = 0; g < NGI; ++g) {
+        f32x4 acc[4];
+        unit_mfma(std::integral_constant<int, KTH>{}, std::false_type{}, d1f, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f0 = 64 * g + 16 * t + 4 * q;
+            if (!valid) continue;
+            if (MODE == 0) {
+                *(float4*)(a.DZ2 + (size_t)row * (32 * KTIN) + f0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            } else {       // dz1 = decoder term + direct p(z1|z2) term + this path through q(z2|z1)
+                const float4 dd = *(const float4*)(a.DZDEC + (size_t)row * a.ldDZDEC + f0);
+                const uint2 dr = *(const uint2*)(a.DZD + (size_t)row * (32 * KTIN) + f0);
+                *(uint2*)(a.DZOUT + (size_t)row * (32 * KTIN) + f0) =
+                    make_uint2(pack2(acc[t][0] + dd.x + bflo(dr.x), acc[t][1] + dd.y + bfhi(dr.x)), pack2(acc[t][2] + dd.z + bflo(dr.y), acc[t][3] + dd.w + bfhi(dr.y)));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // out_bwd_kernel: backward of the Bernoulli output layer for one block of rows, logits
 // recomputed on the fly (never stored): per 64-pixel group
 //   l = g2 V3 + c3 ; dl = gx[row] * (x - sigmoid(l))  -> bf16 (also stored, P-layout, for dV3)
@@ -3832,6 +4017,12 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
 bool chain2_fwd_ok(int KT0, int KTH, int KT1, int M) { return KT0 == 4 && KTH == 4 && KT1 == 2 && M >= 8192; }
 void launch_chain2_fwd(const Chain2FwdArgs& a, hipStream_t st) {
     LAUNCH_EV((chain2_fwd_kernel<4, 4, 2>), dim3((a.M + 127) / 128), dim3(512), 2 * (4 * 4096 + 1024), st, a);
+}
+bool gblock_bwd_ok(int KT0, int KTH, int KT1, int M) { return KT0 == 4 && KTH == 4 && KT1 == 2 && M >= 8192; }
+void launch_gblock_bwd(int mode, const GBlockBwdArgs& a, hipStream_t st) {
+    dim3 grid((a.M + 127) / 128);
+    if (mode == 0) LAUNCH_EV((gblock_bwd_kernel<0, 2, 4, 4>), grid, dim3(512), 2 * (8 * 4096 + 1024), st, a);      // decode_z2_to_z1: head over z1 (KTL = 4), input z2
+    else LAUNCH_EV((gblock_bwd_kernel<1, 4, 4, 2>), grid, dim3(512), 2 * (4 * 4096 + 1024), st, a);                // encode_z1_to_z2: head over z2 (KTL = 2), input z1
 }
 bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
 void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st) {

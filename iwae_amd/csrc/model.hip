@@ -238,6 +238,7 @@ struct iwae_model {
     bool small_dec_bwd = true; int small_rows = 8191;   // the one-launch dX chain also below 8 192 rows (IWAE_NO_SMALL_DEC_BWD=1: the per-pixel-group out_bwd + finish + two dX launches
                                                         // there).  Measured: B=20,k=1 0.1417 -> 0.1383 ms/step, B=100,k=5 150.7 -> 144.6 us, B=160,k=50 189.1 -> 165.7 us
     bool allow_dz_half = true;  // IWAE_DZ_F32=1: dec_bwd_kernel leaves dz as float32 (A/B measurements)
+    bool allow_chain2_bwd = true, chain2_bwd = false;      // option no_chain2_bwd: the per-sample blocks' backward as gauss_bwd_kernel + dense_kernel launches; chain2_bwd: this step takes gblock_bwd_kernel
     bool allow_chain2 = true;   // option no_chain2: the 2-layer model's per-sample blocks as dense_kernel launches + sample_kernel + gauss_lp_kernel (A/B measurements, variant tests)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
@@ -612,9 +613,11 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side) {
-    bool chain_fused = false;
-    if (m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
+// dx_done: the dX chain (dhead -> d2 -> d1 -> dx) has been computed already (gblock_bwd_kernel): only the weight gradients are left
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false) {
+    bool chain_fused = dx_done;
+    if (dx_done) need_dx = false;
+    if (!dx_done && m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
         BlockBwdArgs b;      // few rows (the encoder on the batch's images): both dX products in one launch
         memset(&b, 0, sizeof(b));
         b.DH = ptr<uint16_t>(w.dheadP); b.ldDH = blk[2].Np32; b.imgH = blk[2].imgB; b.imgL2 = blk[1].imgB;
@@ -636,7 +639,7 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
     // wait for them; the small encoder block (R = B) stays on the main stream (it is the tail of the step anyway).
     hipStream_t ws = m->stream;
     if (wgrad_on_side) {
-        HIPCHK(hipEventRecord(m->ev_blk, m->stream));
+        if (!dx_done) HIPCHK(hipEventRecord(m->ev_blk, m->stream));      // (dx_done: the event rode on gblock_bwd_kernel's dispatch packet)
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0));
         ws = m->side;
     }
@@ -820,6 +823,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
         // large row counts, the reference's dims: both per-sample blocks, the z2 sampling and the three log-densities in ONE launch
         const Linear *e2 = m->enc2, *d2 = m->dec2;
+        m->chain2_bwd = false;
         const bool chain = m->allow_chain2 && chain2_fwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].Kp32 == m->Dp[0] && e2[0].Np32 == 32 * e2[1].KT &&
                            e2[1].Np32 == e2[0].Np32 && e2[2].KT == e2[1].KT && e2[2].Np32 == 2 * m->Dp[1] && d2[0].Kp32 == m->Dp[1] && d2[0].Np32 == e2[0].Np32 &&
                            d2[1].KT == e2[1].KT && d2[1].Np32 == d2[0].Np32 && d2[2].KT == e2[1].KT && d2[2].Np32 == 2 * m->Dp[0];
@@ -830,12 +834,15 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             c.e_img1 = e2[0].imgF; c.e_img2 = e2[1].imgF; c.e_imgh = e2[2].imgF;
             c.d_img1 = d2[0].imgF; c.d_img2 = d2[1].imgF; c.d_imgh = d2[2].imgF;
             c.M = M; c.k = k; c.B = B; c.D0 = m->D[0]; c.D1 = m->D[1];
-            const bool keep = bwd || want != nullptr;      // the backward pass (and the z2 / snis exports) read the blocks' activations and heads
-            c.EH1 = keep ? ptr<uint16_t>(m->wenc2.h1P) : nullptr; c.EH2 = keep ? ptr<uint16_t>(m->wenc2.h2P) : nullptr;
-            c.EHEAD = keep ? ptr<float>(m->wenc2.head) : nullptr;
+            // the backward pass reads the blocks' tanh activations; the float32 heads only where something still reads THEM: the unfused
+            // backward kernels (gauss_bwd_kernel) and the z2 / snis exports -- gblock_bwd_kernel recomputes them from h2
+            m->chain2_bwd = bwd && m->allow_chain2_bwd && gblock_bwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].imgB && d2[0].imgB && !m->serial;
+            const bool heads = want != nullptr || (bwd && !m->chain2_bwd);
+            c.EH1 = bwd ? ptr<uint16_t>(m->wenc2.h1P) : nullptr; c.EH2 = bwd ? ptr<uint16_t>(m->wenc2.h2P) : nullptr;
+            c.EHEAD = heads ? ptr<float>(m->wenc2.head) : nullptr;
             c.Z2P = ptr<uint16_t>(m->zP[1]);
-            c.DH1 = keep ? ptr<uint16_t>(m->wdec2.h1P) : nullptr; c.DH2 = keep ? ptr<uint16_t>(m->wdec2.h2P) : nullptr;
-            c.DHEAD = keep ? ptr<float>(m->wdec2.head) : nullptr;
+            c.DH1 = bwd ? ptr<uint16_t>(m->wdec2.h1P) : nullptr; c.DH2 = bwd ? ptr<uint16_t>(m->wdec2.h2P) : nullptr;
+            c.DHEAD = heads ? ptr<float>(m->wdec2.head) : nullptr;
             c.head1 = ptr<float>(m->wenc1.head); c.ldH1 = 2 * m->Dp[0];
             c.eps1 = eps_src(m, 0); c.eps2 = eps_src(m, 1);
             c.lpz1z2 = t1; c.lpz2 = t2; c.lqz2z1 = t4;
@@ -1183,9 +1190,37 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
 
     const float* dz1 = ptr<float>(w.dz);
     const float *dz1_b = nullptr, *dz1_c = nullptr;
+    bool dz_sum_half = false;      // 2-layer model, fused block backward: the three terms of dz1 arrive summed, as bf16, in dzdir
     if (two) {
         // ---- p(z1|z2) head, dec2, q(z2|z1) head, enc2
         CHK(ensure(m->dzdir, (size_t)Mp * m->Dp[0] * 4, st));
+        if (m->chain2_bwd) {
+            // one launch per block: the head recomputed from h2, its gradient, the block's dX chain (gblock_bwd_kernel); the second one
+            // also sums the three terms of dz1 (bf16, in dzdir) -- latent_bwd_kernel reads that like the 1-layer step's dz
+            GBlockBwdArgs gb;
+            memset(&gb, 0, sizeof(gb));
+            gb.imgH = m->dec2[2].imgF; gb.imgBh = m->dec2[2].imgB; gb.imgB2 = m->dec2[1].imgB; gb.imgB1 = m->dec2[0].imgB;
+            gb.H2 = ptr<uint16_t>(m->wdec2.h2P); gb.H1 = ptr<uint16_t>(m->wdec2.h1P); gb.gx = ptr<float>(m->gx);
+            gb.M = M; gb.k = k; gb.B = B; gb.D = m->D[0]; gb.eps = eps_src(m, 0);
+            gb.head1 = ptr<float>(m->wenc1.head); gb.ldH1 = 2 * m->Dp[0];
+            gb.DHP = ptr<uint16_t>(m->wdec2.dheadP); gb.D2P = ptr<uint16_t>(m->wdec2.d2P); gb.D1P = ptr<uint16_t>(m->wdec2.d1P);
+            gb.DZ2 = ptr<float>(m->wdec2.dx); gb.DZD = (uint16_t*)m->wenc2.dx.p;
+            set_launch_stop_event(m->ev_blk);
+            launch_gblock_bwd(0, gb, st);
+            CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, false, true, true));
+            memset(&gb, 0, sizeof(gb));
+            gb.imgH = m->enc2[2].imgF; gb.imgBh = m->enc2[2].imgB; gb.imgB2 = m->enc2[1].imgB; gb.imgB1 = m->enc2[0].imgB;
+            gb.H2 = ptr<uint16_t>(m->wenc2.h2P); gb.H1 = ptr<uint16_t>(m->wenc2.h1P); gb.gx = ptr<float>(m->gx);
+            gb.M = M; gb.k = k; gb.B = B; gb.D = m->D[1]; gb.eps = eps_src(m, 1);
+            gb.DZIN = ptr<float>(m->wdec2.dx);
+            gb.DHP = ptr<uint16_t>(m->wenc2.dheadP); gb.D2P = ptr<uint16_t>(m->wenc2.d2P); gb.D1P = ptr<uint16_t>(m->wenc2.d1P);
+            gb.DZD = (uint16_t*)m->wenc2.dx.p; gb.DZDEC = ptr<float>(w.dz); gb.ldDZDEC = m->dec1[0].Kp32; gb.DZOUT = (uint16_t*)m->dzdir.p;
+            set_launch_stop_event(m->ev_blk);
+            launch_gblock_bwd(1, gb, st);
+            CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, false, true, true));
+            HIPCHK(hipGetLastError());
+            dz1 = nullptr; dz_sum_half = true;
+        } else {
         GaussBwdArgs g;
         memset(&g, 0, sizeof(g));
         g.mode = 0; g.G = ptr<float>(m->gx);
@@ -1205,12 +1240,14 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         launch_gauss_bwd(g, st);
         CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, !m->serial));
         dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
+        }
     }
     {
         LatentBwdArgs a;
         memset(&a, 0, sizeof(a));
         a.dz = dz1; a.dz2 = dz1_b; a.dz3 = dz1_c; a.ldDZ = m->Dp[0];
         if (dz_half) a.dzh = (const uint16_t*)w.dz.p;
+        if (dz_sum_half) a.dzh = (const uint16_t*)m->dzdir.p;
         a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
         a.cf = ptr<float4>(m->cf); a.eps = eps_src(m, 0);
         a.B = B; a.Bp = Bp; a.k = k;
@@ -2068,6 +2105,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     if (n == "out_recompute") m->allow_s_mode = !on;                  // recompute the logits in out_bwd instead of keeping s
     else if (n == "no_defer") m->allow_defer = !on;                   // join the decoder update at the end of every step
     else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
+    else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
     else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it

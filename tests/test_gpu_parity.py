@@ -212,8 +212,8 @@ def test_two_layer_kernel_variants_agree(gpu, B, k):
         m.close()
         return r, g
 
-    for e in (eps, None):
-        r0, g0 = run({"no_chain2": 1}, e)
+    for e, ref_opts in ((eps, {"no_chain2": 1}), (None, {"no_chain2": 1}), (eps, {"no_chain2_bwd": 1})):
+        r0, g0 = run(ref_opts, e)
         r1, g1 = run({}, e)
         # the fused kernels start their accumulators from the bias, the separate launches add it at the end: float32 sums in another
         # order, so a bf16 activation flips by an ulp here and there and moves the densities of THAT row (log p(z1|z2) of a row with a small
