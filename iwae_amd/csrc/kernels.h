@@ -163,7 +163,8 @@ struct WgradPGroup {                        // up to 3 independent 8-wave weight
 };
 
 struct Chain2FwdArgs {                // chain2_fwd_kernel: the 2-layer model's per-sample blocks (q(z2|z1) and p(z1|z2)) on M rows, one launch
-    const uint16_t* Z1P;              // z1 rows, bf16 P-layout [M][32*KT0] (made by sample_kernel)
+    uint16_t* Z1P;                    // z1 rows, bf16 P-layout [M][32*KT0]: MADE here (z1 = mu1 + sigma1*eps1, iwae2.py:61) and kept for the decoder and the weight gradient
+    float* lqz1x;                     // log q(z1|x) per row (iwae2.py:123)
     const char *e_img1, *e_img2, *e_imgh;     // MG-major forward images of encode_z1_to_z2: l1 (KT0 k-steps), l2, head (KTH k-steps each)
     const char *d_img1, *d_img2, *d_imgh;     // ... of decode_z2_to_z1: l1 (KT1 k-steps), l2, head (KTH k-steps each)
     int M, k, B, D0, D1;              // data rows, samples per image, images; latent widths of z1 and z2

@@ -1428,6 +1428,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
 
 // ---------------------------------------------------------------------------------
 // chain2_fwd_kernel (round 3): the per-sample blocks of the 2-layer model's forward pass in ONE launch at large row counts --
+//   z1 = mu1 + sigma1*eps1 with log q(z1|x) (iwae2.py:61, :123),
 //   q(z2|z1) = BasicBlock(z1) (iwae2.py:63-64), z2 = mu2 + sigma2*eps2 with log q(z2|z1) and log p(z2) (:65, :119, :124),
 //   p(z1|z2) = BasicBlock(z2) (iwae2.py:90) and log p(z1|z2) (:122).
 // As dense_kernel launches these were six GEMM launches + sample_kernel + gauss_lp_kernel with every activation and both float32
@@ -1473,11 +1474,43 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
         }
     };
     dma_unit(0, 0);
+    auto quad_sum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+    // ---- z1 = mu1 + sigma1 * eps1 of this row (iwae2.py:61) and log q(z1|x) (:123): sample_kernel's arithmetic, without its launch and
+    // without reading z1 back -- the fragments are this kernel's first operand; the rows are kept for the decoder and the weight gradient
     uint4 zf[KT0];
+    {
+        const float* hz = a.head1 + (size_t)b * a.ldH1;
+        float lq = 0.0f;
 #pragma unroll
-    for (int ks = 0; ks < KT0; ++ks) {
-        const uint4 v = *(const uint4*)(a.Z1P + (size_t)rowc * (32 * KT0) + ks * 32 + q * 8);
-        zf[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < KT0; ++ks) {
+            float z8[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f0 = 32 * ks + 16 * h + 4 * q;
+                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), sg4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (f0 < a.D0) {
+                    eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e);
+                    mu4 = *(const float4*)(hz + f0); sg4 = *(const float4*)(hz + 32 * KT0 + f0);
+                }
+                const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float z = 0.0f;
+                    if (f0 + i < a.D0) {
+                        z = muv[i] + sgv[i] * e[i];
+                        const float uu = (z - muv[i]) * __builtin_amdgcn_rcpf(sgv[i]);
+                        lq += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sgv[i]);
+                    }
+                    z8[4 * h + i] = z;
+                }
+            }
+            const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
+            zf[ks] = valid ? frag : make_uint4(0, 0, 0, 0);
+            if (valid) *(uint4*)(a.Z1P + (size_t)row * (32 * KT0) + ks * 32 + q * 8) = frag;
+        }
+        lq = quad_sum(lq);
+        if (q == 0 && valid) a.lqz1x[row] = lq;
     }
     int u = 0;
     // one unit: the 4 accumulator tiles (64 out-features x 16 rows) of a weight group, started from the group's bias block
@@ -1518,7 +1551,6 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
             }
         }
     };
-    auto quad_sum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
 
     // ---- q(z2|z1): encode_z1_to_z2 (iwae2.py:63-64)
     uint4 h1f[KTH], h2f[KTH];

@@ -176,7 +176,7 @@ struct iwae_model {
     int ds_N = 0;
     int wg_target16_1 = 64;    // same, for layers that are a single block wide (IWAE_WG16_1): the hidden layers' gradients -- with the specialised-wave kernel 64 row splits (12.8 MB of slabs each) beat 128 (0.259 -> 0.249-0.254 ms/step); 48 and 32 are slower again
     int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
-    int wg_target8 = 256;      // same for the 8-wave launches on many rows (narrow layers of the 2-layer model) (IWAE_WG8)
+    int wg_target8 = 128;      // same for the 8-wave launches on many rows (narrow layers of the 2-layer model; option wg8): 128 row splits halve the 109 MB of fp32 slabs 256 wrote per step (c2: 0.4193 -> 0.4176 ms; 64: 0.462)
     int wg_target8_few = 32;   // 8-wave launches on < 8 192 rows (the encoder's layers on the batch's images; IWAE_WG8_FEW): the 784-wide first layer in 4 row
                                // splits instead of 16 (10.6 -> 2.7 MB of slabs each way): 0.2439 -> 0.2351 ms/step at B = 1 024; 8 / 16 / 48: 0.2374 / 0.2374 / 0.2360
     int wg_target16 = 128;     // workgroups aimed at per 16-wave weight-gradient launch (IWAE_WG16 overrides, tuning aid): these are one-per-CU
@@ -224,7 +224,7 @@ struct iwae_model {
     bool use_side2 = true;
     hipEvent_t ev_lse = nullptr;
     bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
-    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_dec = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_dec = nullptr;
     // Single-GPU train step: the decoder's slab reduction + Adam (90 % of the slab bytes) stays on the side stream and is
     // NOT joined at the end of the step -- nothing needs the decoder's new weights before the next step's d1 layer, so it
     // runs beside the next encoder forward.  dec_pending: ev_dec (recorded behind it) has not been waited for yet;
@@ -614,7 +614,7 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
 // dx_done: the dX chain (dhead -> d2 -> d1 -> dx) has been computed already (gblock_bwd_kernel): only the weight gradients are left
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false) {
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false, hipStream_t side_st = nullptr) {
     bool chain_fused = dx_done;
     if (dx_done) need_dx = false;
     if (!dx_done && m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
@@ -639,9 +639,9 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
     // wait for them; the small encoder block (R = B) stays on the main stream (it is the tail of the step anyway).
     hipStream_t ws = m->stream;
     if (wgrad_on_side) {
+        ws = side_st ? side_st : m->side;
         if (!dx_done) HIPCHK(hipEventRecord(m->ev_blk, m->stream));      // (dx_done: the event rode on gblock_bwd_kernel's dispatch packet)
-        HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0));
-        ws = m->side;
+        HIPCHK(hipStreamWaitEvent(ws, m->ev_blk, 0));
     }
     WgradPGroup g;
     memset(&g, 0, sizeof(g));
@@ -785,7 +785,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     // the draws are kept when later kernels of this call need them again (backward, 2-layer densities)
     CHK(ensure(m->zP[0], (size_t)Mp * m->Dp[0] * 2, st));
     CHK(join_side(m));      // from here on: the prefetched noise, then the decoder's weights
-    bool fuse_z = false, sample_in_block = false;
+    bool fuse_z = false, sample_in_block = false, chain = false;
     SampleArgs zin;
     memset(&zin, 0, sizeof(zin));
     if (m->has_prior) {     // p(z|y) = N(mu_p(y), sigma_p(y)) (tasks/task04.py:124): the prior block on the B condition rows
@@ -813,24 +813,28 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                  (m->dec1[0].KT == 4 || m->dec1[0].KT == 2) && m->dec1[0].Kp32 == m->Dp[0];
         // few rows: block_fwd_kernel (the decoder's two tanh layers in one launch, below) makes z itself -- one latency-bound launch less
         sample_in_block = m->allow_block_fused && m->allow_zin && !two && !fuse_z && M <= 4096 && !s.ZF && m->dec1[0].Kp32 == m->Dp[0];
+        // 2-layer model at large row counts, the reference's dims: chain2_fwd_kernel (below) makes z1 itself, as its first layer's operand
+        if (two) {
+            const Linear *e2 = m->enc2, *d2 = m->dec2;
+            chain = m->allow_chain2 && chain2_fwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].Kp32 == m->Dp[0] && e2[0].Np32 == 32 * e2[1].KT &&
+                    e2[1].Np32 == e2[0].Np32 && e2[2].KT == e2[1].KT && e2[2].Np32 == 2 * m->Dp[1] && d2[0].Kp32 == m->Dp[1] && d2[0].Np32 == e2[0].Np32 &&
+                    d2[1].KT == e2[1].KT && d2[1].Np32 == d2[0].Np32 && d2[2].KT == e2[1].KT && d2[2].Np32 == 2 * m->Dp[0];
+        }
         if (fuse_z || sample_in_block) zin = s;
-        else launch_sample(s, st);
+        else if (!chain) launch_sample(s, st);
     }
     if (two) {
         // ---- q(z2|z1), z2, p(z1|z2)  (iwae2.py:63-65, :90, :118-124)
         CHK(block_alloc(m, m->enc2, m->wenc2, M, Mp, bwd, true));
         CHK(ensure(m->zP[1], (size_t)Mp * m->Dp[1] * 2, st));
         CHK(block_alloc(m, m->dec2, m->wdec2, M, Mp, bwd, true));
-        // large row counts, the reference's dims: both per-sample blocks, the z2 sampling and the three log-densities in ONE launch
+        // large row counts, the reference's dims: the z1 sampling, both per-sample blocks, the z2 sampling and the four log-densities in ONE launch
         const Linear *e2 = m->enc2, *d2 = m->dec2;
         m->chain2_bwd = false;
-        const bool chain = m->allow_chain2 && chain2_fwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].Kp32 == m->Dp[0] && e2[0].Np32 == 32 * e2[1].KT &&
-                           e2[1].Np32 == e2[0].Np32 && e2[2].KT == e2[1].KT && e2[2].Np32 == 2 * m->Dp[1] && d2[0].Kp32 == m->Dp[1] && d2[0].Np32 == e2[0].Np32 &&
-                           d2[1].KT == e2[1].KT && d2[1].Np32 == d2[0].Np32 && d2[2].KT == e2[1].KT && d2[2].Np32 == 2 * m->Dp[0];
         if (chain) {
             Chain2FwdArgs c;
             memset(&c, 0, sizeof(c));
-            c.Z1P = ptr<uint16_t>(m->zP[0]);
+            c.Z1P = ptr<uint16_t>(m->zP[0]); c.lqz1x = t3;
             c.e_img1 = e2[0].imgF; c.e_img2 = e2[1].imgF; c.e_imgh = e2[2].imgF;
             c.d_img1 = d2[0].imgF; c.d_img2 = d2[1].imgF; c.d_imgh = d2[2].imgF;
             c.M = M; c.k = k; c.B = B; c.D0 = m->D[0]; c.D1 = m->D[1];
@@ -964,7 +968,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             // side stream forks early.  Round 2: it forks behind THIS kernel (event on its dispatch packet) and runs its own copy of
             // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
             // a cross-stream hand-off takes now pass beside the main stream's lse_kernel, not behind it.
-            m->early_wout = bwd && m->s_mode && m->allow_early_wout && !two && !m->serial;
+            m->early_wout = bwd && m->s_mode && m->allow_early_wout && !m->serial;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
             m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1 && !out_done;
             if (!out_done) { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
             if (m->lse_dup && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
@@ -1217,7 +1221,8 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             gb.DZD = (uint16_t*)m->wenc2.dx.p; gb.DZDEC = ptr<float>(w.dz); gb.ldDZDEC = m->dec1[0].Kp32; gb.DZOUT = (uint16_t*)m->dzdir.p;
             set_launch_stop_event(m->ev_blk);
             launch_gblock_bwd(1, gb, st);
-            CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, false, true, true));
+            // (the encode block's weight gradients on the second side stream, free by now: beside the decode block's, not behind them)
+            CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, false, true, true, (m->early_wout && m->use_side2) ? m->side2 : nullptr));
             HIPCHK(hipGetLastError());
             dz1 = nullptr; dz_sum_half = true;
         } else {
@@ -1275,6 +1280,10 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     } else if (!defer && !m->serial) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+        if (two && m->tail != m->side) {      // the per-sample blocks' weight gradients went to `side` behind the output layer's: both side streams join
+            HIPCHK(hipEventRecord(m->ev_join2, m->side));
+            HIPCHK(hipStreamWaitEvent(st, m->ev_join2, 0));
+        }
     }
     {
         ScopedTimer tm_red(m, T_REDUCE);
@@ -1832,6 +1841,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_fork2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_dec, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_blk, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
@@ -1926,6 +1936,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_fork2) (void)hipEventDestroy(m->ev_fork2);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
     if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
     if (m->ev_lse) (void)hipEventDestroy(m->ev_lse);
     if (m->ev_blk) (void)hipEventDestroy(m->ev_blk);
