@@ -67,7 +67,7 @@ typedef struct {
                                   (one-hot labels there, C = 10); needs n_latent + C <= round_up(n_latent, 32) */
     int32_t cond_prior;        /* with cond_dim > 0: 1 = the learned conditional prior p(z|y) of tasks/task04.py:101-173 (a BasicBlock on y,
                                   created after the decoder) replaces N(0,1) in lpz; sample(z, y) maps z through it (:190-196) */
-    int32_t precision;         /* iwae_precision of forward / train calls (iwae_eval_llh: iwae_set_eval_precision); IWAE_PREC_FP32 needs cond_dim = 0 */
+    int32_t precision;         /* iwae_precision of forward / train calls (iwae_eval_llh: iwae_set_eval_precision) */
     int32_t reserved;          /* 0 */
 } iwae_config;
 
@@ -185,8 +185,7 @@ int iwae_comm_info(iwae_handle h, int32_t* world_size, int32_t* rank);
  * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
 int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);
 /* arithmetic of iwae_eval_llh, independent of iwae_config.precision: IWAE_PREC_FP32 by default (the reference evaluates in
- * float32, main.py:176; 10 000 images x k = 5000 take well under a second either way), IWAE_PREC_BF16 for the fast path.
- * The conditional models (cond_dim > 0) always evaluate on the bf16 path. */
+ * float32, main.py:176; 10 000 images x k = 5000 take well under a second either way), IWAE_PREC_BF16 for the fast path. */
 int iwae_set_eval_precision(iwae_handle h, int32_t precision);
 
 /* IWAE.sample(z): decoder only -> probs [n, x_dim].  1-layer: src/iwae1.py:168-178, z [n,D1].  2-layer:

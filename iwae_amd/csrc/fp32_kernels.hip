@@ -177,6 +177,18 @@ void launch_export_mat(const float* in, int B, int k, int X, float* out, hipStre
     hipLaunchKernelGGL(export_mat_kernel, dim3((unsigned)(((size_t)B * k * X + 255) / 256)), dim3(256), 0, st, in, B, k, X, out);
 }
 
+// out[r] = concat(a[r] (na floats), b[r] (nb floats)): the conditional models' inputs (tasks/task05.py:113, :185: concat(x, y), concat(z, y))
+__global__ __launch_bounds__(256) void concat_f32_kernel(const float* a, int na, const float* b, int nb, int rows, float* out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int w = na + nb;
+    if (idx >= (size_t)rows * w) return;
+    const int r = (int)(idx / w), j = (int)(idx - (size_t)r * w);
+    out[idx] = j < na ? a[(size_t)r * na + j] : b[(size_t)r * nb + (j - na)];
+}
+void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(concat_f32_kernel, dim3((unsigned)(((size_t)rows * (na + nb) + 255) / 256)), dim3(256), 0, st, a, na, b, nb, rows, out);
+}
+
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;
     // float4 fetches where every quad is 16-byte aligned: base pointer, the non-unit stride and the k-chunk offsets

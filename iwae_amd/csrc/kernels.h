@@ -13,11 +13,6 @@ enum { PB_LME = 0, PB_MEAN, PB_EQ14, PB_KL, PB_PX, PB_T1, PB_T2, PB_DREG, PB_COU
 // scalar outputs (device float[16]); must match iwae_scalars in include/iwae_amd.h
 enum { SC_VAE_ELBO = 0, SC_VAE_ELBO_KL, SC_IWAE_ELBO, SC_IWAE_EQ14, SC_INFERENCE_LOSS, SC_MEAN_LPXZ, SC_MEAN_T1, SC_MEAN_T2, SC_KL, SC_COUNT = 16 };
 
-// Per-step values of a CAPTURED train step (hipGraph replay of the small-batch regime): the graph's kernels read them from this
-// device block, which a one-thread kernel in front of every replay fills (stream-ordered, so any number of steps may be in flight).
-struct StepDyn { uint32_t step; uint32_t batch_offset; float alpha; int32_t ds_start; };
-void launch_set_dyn(StepDyn* dyn, uint32_t step, uint32_t batch_offset, float alpha, int ds_start, hipStream_t st);
-
 struct EpsSrc {
     const float* user = nullptr;     // [k][B][D] host-supplied draws (reference order) or null -> Philox
     const float* cache = nullptr;    // [rows][ldC] draws eps_gen_kernel made ahead of the step (Philox costs ~40 quarter-rate
@@ -30,8 +25,6 @@ struct EpsSrc {
     // k-chunked calls (iwae_eval_llh at large k): this call holds samples [s_off, s_off + kc) of k_total per image; the Philox row
     // index is that of the unchunked call, (image)*k_total + sample, so chunking does not change the draws.  k_total = 0: off.
     int k_total = 0, s_off = 0, kc = 0;
-    const StepDyn* dyn = nullptr;   // graph replay: step / batch offset are read from this device block instead (eps_gen_kernel)
-    int dyn_k = 0;             // samples per image (row_offset = dyn->batch_offset * dyn_k)
 };
 
 struct DenseArgs {
@@ -271,7 +264,7 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_wgradws_group(const WgradPGroup& g, hipStream_t st);     // shape-7 (specialised waves) gradients, non-row-weighted, in one launch
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st, const StepDyn* dyn = nullptr);      // dyn != null: start = dyn->ds_start
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks = 0);   // max_blocks > 0: grid-stride over at most that many blocks
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
@@ -282,8 +275,7 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
 // per_b != null: one extra block turns the per-image values into the batch means (scalars) of the step.
 // fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread.
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st,
-                         const StepDyn* dyn = nullptr);      // dyn != null: the Adam step size alpha is read from dyn->alpha
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
                  float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block = 0);   // blocks [first_block, first_block + nblocks) of the elementwise grid
@@ -314,5 +306,6 @@ void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int 
 void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st);
 void launch_sigmoid_f32(float* v, size_t n, hipStream_t st);
 void launch_export_mat(const float* in, int B, int k, int X, float* out, hipStream_t st);
+void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows, float* out, hipStream_t st);
 
 }  // namespace iwae

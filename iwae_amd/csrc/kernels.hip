@@ -3263,8 +3263,7 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, const fl
 // (epoch, image): one binarisation per image per epoch, as in the reference.  Same block shape and
 // output as prep_rows_kernel (P-layout) + optional float32 copy.
 __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp,
-                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, float* xf, const StepDyn* dyn) {
-    if (dyn) start = dyn->ds_start;
+                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, float* xf) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 64 + lane;
     const int nchunk = Xp / 8;
@@ -3301,7 +3300,6 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
 // take their time in a corner of every CU; as 5 000 blocks it filled the machine for 11 us and the forward's large
 // workgroups queued behind it.
 __global__ __launch_bounds__(256) void eps_gen_kernel(EpsSrc e, int M, int nd4, int ld, float* out) {
-    if (e.dyn) { e.step = e.dyn->step; e.row_offset = (uint64_t)e.dyn->batch_offset * (uint64_t)e.dyn_k; }      // captured step: this replay's counters
     const size_t total = (size_t)M * nd4;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int row = (int)(idx / nd4), d4 = (int)(idx - (size_t)row * nd4);
@@ -3794,8 +3792,7 @@ struct MeansArgs { const float* per_b; int B; float beta; float* out; };     // 
 // The grid covers reduce blocks [first_block, first_block + n) of the layer table: the whole table, or -- single-GPU
 // train step -- the decoder's layers on the side stream and the rest on the main stream (see backward_impl).
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad, float* param, float* mom,
-                                                           float* vel, AdamCoef c, MeansArgs mn, int first_block, const StepDyn* dyn) {
-    if (dyn) c.alpha = dyn->alpha;
+                                                           float* vel, AdamCoef c, MeansArgs mn, int first_block) {
     if (mn.per_b && blockIdx.x == gridDim.x - 1) {      // the one extra block of the grid: batch means of this step
         batch_means_block(mn.per_b, mn.B, mn.beta, mn.out);
         return;
@@ -4147,15 +4144,10 @@ void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, in
     hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, cond, B, X, cond ? C : 0, Xp, Bp, XP);
 }
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st, const StepDyn* dyn) {
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st) {
     const int nchunk = Xp / 8;
     hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
-                       Bp, seed, epoch, XP, xf, dyn);
-}
-__global__ void set_dyn_kernel(StepDyn* dyn, StepDyn v) { if (threadIdx.x == 0) *dyn = v; }
-void launch_set_dyn(StepDyn* dyn, uint32_t step, uint32_t batch_offset, float alpha, int ds_start, hipStream_t st) {
-    const StepDyn v = {step, batch_offset, alpha, ds_start};
-    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(64), 0, st, dyn, v);
+                       Bp, seed, epoch, XP, xf);
 }
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks) {
     const int nd4 = (D + 3) / 4;
@@ -4175,11 +4167,10 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
 }
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st,
-                         const StepDyn* dyn) {
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
     const AdamCoef c = {alpha, 1.0f, beta1, beta2, eps, fuse_adam};
     const MeansArgs mn = {per_b, B, beta, scalars};
-    LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block, dyn);
+    LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
 }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);

@@ -134,7 +134,7 @@ struct iwae_model {
     int64_t adam_t = 0;
     // float32 mode (iwae_config.precision / iwae_set_eval_precision): row-major float32 activations, GEMMs on v_mfma_f32_16x16x4_f32
     struct F32Block { DevBuf h1, h2, dhead, d2, d1, dx; };
-    struct F32State { F32Block enc1, enc2, dec2; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart; } f32;
+    struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat; } f32;
     int eval_tag_kill = -1;
     int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
     int eval_rows = 1 << 19;                  // data rows per evaluator launch (IWAE_EVAL_ROWS): images x samples, k chunked beyond it
@@ -201,19 +201,6 @@ struct iwae_model {
     // optional HIP-event timing of the dominant kernels (iwae_enable_timing): pairs recorded on m->stream
     // fork/join of the decoder weight-gradient GEMMs (independent of the dz -> encoder chain) onto a side stream
     hipStream_t side = nullptr;
-    // hipGraph replay of the small-batch train step (the reference's default regime, B = 20: ~20 dependent launches of a few
-    // microseconds each): the step is captured ONCE per (shape, objective, input) in serial form -- every kernel on the main stream,
-    // no events -- and replayed; step counter, batch offset, Adam step size and dataset offset travel through d_dyn (StepDyn).
-    struct GraphEntry { int B, k, objective; float beta; const void* x; int from_ds; uint64_t gen; int seen; hipGraphExec_t exec; LayerDesc* d_descs; };
-    bool capturing = false;            // inside hipStreamBeginCapture: the (synchronous) rebuild of the shared layer table is skipped
-    LayerDesc* cur_descs = nullptr;    // the layer table the slab reductions of THIS call read (a captured step owns a copy: its row splits are part of the capture)
-    std::vector<GraphEntry> graphs;
-    StepDyn* d_dyn = nullptr;
-    bool serial = false;               // this call runs in serial form (capture / its warm-up step)
-    bool allow_graph = false;          // IWAE_GRAPH=1 switches the captured step on.  Measured at B = 20, k = 1 (bench.py --config c0): replay 0.163 ms/step, eager 0.142 --
-                                       // the eager step overlaps its weight gradients on the side streams and is not host-bound, the serial capture gives that up
-                                       // and pays the graph launch; kept as an option (bit-identical to the eager step: test_graph_replayed_...)
-    int graph_max_rows = 4096;         // capture only below this many data rows (IWAE_GRAPH_ROWS): beyond it the step is not launch-bound
     hipStream_t tail = nullptr;        // this step's side stream that finishes last (carries the decoder's reduction / exchange / update)
     bool allow_wg_group = false;       // IWAE_WG_GROUP=1: the hidden layers' gradients as ONE grouped launch (measured: 0.2450 vs 0.2384 ms/step as two launches --
                                        // both at once take more of the machine from the output layer's gradient, which is what the step waits for)
@@ -263,10 +250,8 @@ struct iwae_model {
 
 namespace {
 
-static thread_local uint64_t g_alloc_gen = 0;      // bumped whenever a work buffer moves: captured graphs hold the old addresses
 int ensure(DevBuf& b, size_t bytes, hipStream_t st) {
     if (bytes <= b.cap) return IWAE_OK;
-    g_alloc_gen += 1;
     if (b.p) {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipFree(b.p));
@@ -464,7 +449,6 @@ EpsSrc eps_src(iwae_model* m, int layer) {
     e.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k;
     e.step = m->noise_step;
     e.stream = (uint32_t)layer;
-    if (m->serial) { e.dyn = m->d_dyn; e.dyn_k = m->k; }
     if (m->eval_k_total > 0) {      // k-chunked evaluation: the unchunked call's Philox rows
         e.k_total = m->eval_k_total; e.s_off = m->eval_s_off; e.kc = m->k;
         e.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->eval_k_total;
@@ -706,7 +690,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
-    m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0 && !m->serial;
+    m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32, Xinp = m->Xinp;
     hipStream_t st = m->stream;
@@ -724,12 +708,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         const int np = (m->epsc_par + 1) % 3;
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
         iwae_model::EpsTag& tg = m->eps_tag[np];
-        if (m->serial) {            // captured step: the draws are always made in the graph, from the replay's own counters
-            for (int p3 = 0; p3 < 3; ++p3)       // (every ring slot sized by the warm-up step: no allocation may happen inside a capture)
-                for (int l = 0; l < m->cfg.n_layers; ++l) CHK(ensure(m->epsc[p3][l], (size_t)Mp * m->Dp[l] * 4, st));
-            CHK(draw_eps(m, np, m->noise_step, M, st));
-            m->eps_tag[np].valid = false;
-        } else if (m->eval_k_total > 0 || !(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
+        if (m->eval_k_total > 0 || !(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
             CHK(join_side(m));          // a speculative draw into this slot may still be on the side stream
             if (m->side) HIPCHK(hipStreamSynchronize(m->side));
             CHK(draw_eps(m, np, m->noise_step, M, st));
@@ -745,7 +724,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xinp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st, m->serial ? m->d_dyn : nullptr);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
         m->ds_start = -1;
     } else {
         const float* xd = x;
@@ -840,7 +819,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             c.M = M; c.k = k; c.B = B; c.D0 = m->D[0]; c.D1 = m->D[1];
             // the backward pass reads the blocks' tanh activations; the float32 heads only where something still reads THEM: the unfused
             // backward kernels (gauss_bwd_kernel) and the z2 / snis exports -- gblock_bwd_kernel recomputes them from h2
-            m->chain2_bwd = bwd && m->allow_chain2_bwd && gblock_bwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].imgB && d2[0].imgB && !m->serial;
+            m->chain2_bwd = bwd && m->allow_chain2_bwd && gblock_bwd_ok(e2[0].KT, e2[1].KT, d2[0].KT, M) && e2[0].imgB && d2[0].imgB;
             const bool heads = want != nullptr || (bwd && !m->chain2_bwd);
             c.EH1 = bwd ? ptr<uint16_t>(m->wenc2.h1P) : nullptr; c.EH2 = bwd ? ptr<uint16_t>(m->wenc2.h2P) : nullptr;
             c.EHEAD = heads ? ptr<float>(m->wenc2.head) : nullptr;
@@ -968,14 +947,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             // side stream forks early.  Round 2: it forks behind THIS kernel (event on its dispatch packet) and runs its own copy of
             // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
             // a cross-stream hand-off takes now pass beside the main stream's lse_kernel, not behind it.
-            m->early_wout = bwd && m->s_mode && m->allow_early_wout && !m->serial;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
+            m->early_wout = bwd && m->s_mode && m->allow_early_wout;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
             m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1 && !out_done;
             if (!out_done) { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
             if (m->lse_dup && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
         HIPCHK(hipGetLastError());
         // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
         // stream, idle until the backward pass forks -- enqueued behind the decoder kernel so that its dispatch does not delay that one
-        if (bwd && keep_eps && m->side && !m->serial) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
+        if (bwd && keep_eps && m->side) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
 
@@ -1101,7 +1080,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 r.DZ = ptr<float>(w.dz); r.DZH = dz_half ? (uint16_t*)w.dz.p : nullptr;
                 if (dec_bwd_rows_ok(r)) {
                     ScopedTimer tm(m, T_DEC_BWD);
-                    if (!m->serial) set_launch_stop_event(m->ev_fork2);
+                    set_launch_stop_event(m->ev_fork2);
                     launch_dec_bwd_rows(r, st);
                     rows_kernel = true;
                 }
@@ -1123,20 +1102,19 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                     d.o.stamps = ptr<unsigned long long>(m->dstamps);
                 }
                 ScopedTimer tm(m, T_DEC_BWD);
-                if (!m->serial) set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
+                set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
                 launch_dec_bwd(d, st);
             } else {
             // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
-            { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout && !m->serial) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
+            { ScopedTimer tm(m, T_OUT_BWD); if (!m->early_wout) set_launch_stop_event(m->ev_fork); launch_out_bwd(a, st); }
             }
         HIPCHK(hipGetLastError());
     }
     // fork: the decoder weight gradients only need what out_bwd produced (dl, dpre2) plus forward activations, so
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
-    hipStream_t sd = m->serial ? st : m->side;       // serial form (graph capture): everything on the main stream, no events
-    if (m->serial) {}
-    else if (m->early_wout && m->lse_dup) {}                                              // forked behind the decoder kernel already (forward_impl)
+    hipStream_t sd = m->side;
+    if (m->early_wout && m->lse_dup) {}                                              // forked behind the decoder kernel already (forward_impl)
     else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
@@ -1146,7 +1124,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     if (!fused_dx) {
         { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
-        { ScopedTimer tm(m, T_DX_LAT); if (!m->serial) set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
+        { ScopedTimer tm(m, T_DX_LAT); set_launch_stop_event(m->ev_fork2); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
     }
     // ONE event (ev_fork2) behind the whole dX chain -- the last of its kernels carries it on its dispatch packet (every separate
     // record costs the main stream a ~6 us bubble): the hidden layers' weight gradients need dpre2 and dpre1, and the deferred
@@ -1160,8 +1138,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // layer's gradient, long complete by then) instead of `side` picking up the later of the two.
     hipStream_t ws = sd;
     m->tail = sd;
-    if (m->serial) {}
-    else if (m->early_wout && m->use_side2) {
+    if (m->early_wout && m->use_side2) {
         HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
         ws = m->side2;
         m->tail = m->side2;
@@ -1181,16 +1158,16 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             launch_wgradws_group(g, ws);
         } else {
             { ScopedTimer tm(m, T_WGRAD_HID, ws); launch_wgradp(ah, nsh, shh, ws); }
-            if (!m->early_wout && !fused_dx && !m->serial) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+            if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
             { ScopedTimer tm(m, T_WGRAD_LAT, ws); launch_wgradp(al, nsl, shl, ws); }
         }
         HIPCHK(hipGetLastError());
     }
-    if (ws == m->side2 && !m->serial) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
+    if (ws == m->side2) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
-    if (m->descs_dirty && !m->capturing) CHK(build_descs(m));
-    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two && !m->serial;      // (2-layer: the main stream needs the side-stream block gradients anyway)
+    if (m->descs_dirty) CHK(build_descs(m));
+    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two;      // (2-layer: the main stream needs the side-stream block gradients anyway)
 
     const float* dz1 = ptr<float>(w.dz);
     const float *dz1_b = nullptr, *dz1_c = nullptr;
@@ -1235,7 +1212,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         g.eps = eps_src(m, 0); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wdec2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true, !m->serial));
+        CHK(block_bwd(m, m->dec2, m->wdec2, ptr<uint16_t>(m->zP[1]), M, true, true));
         memset(&g, 0, sizeof(g));
         g.mode = 1; g.G = ptr<float>(m->gx);
         g.head = ptr<float>(m->wenc2.head); g.ldH = 2 * m->Dp[1]; g.D = m->D[1]; g.Dp = m->Dp[1];
@@ -1243,7 +1220,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         g.eps = eps_src(m, 1); g.M = M; g.Mp = Mp; g.k = k;
         g.DHP = ptr<uint16_t>(m->wenc2.dheadP);
         launch_gauss_bwd(g, st);
-        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, !m->serial));
+        CHK(block_bwd(m, m->enc2, m->wenc2, ptr<uint16_t>(m->zP[0]), M, true, true));
         dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
         }
     }
@@ -1263,21 +1240,21 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
-    if (m->descs_dirty && !m->capturing) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
+    if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
     // split (data-parallel step, iwae_forward_backward_split): the decoder's layers are summed into the flat gradient on the
     // side stream, right behind their weight gradients, and NOT joined here -- the caller's all-reduce of that segment is
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
     // Without split (iwae_forward_backward: gradient only, e.g. the one-message data-parallel step) the same early decoder
     // reduction runs on the side stream and the main stream joins it behind its own, shorter, encoder reduction.
-    const bool early = !fuse && m->early_first > 0 && !two && !m->serial;
+    const bool early = !fuse && m->early_first > 0 && !two;
     m->split_offset = m->nparam;
     if (early) {
         set_launch_stop_event(m->ev_dec);
-        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
-    } else if (!defer && !m->serial) {       // join: every weight gradient launched on the side stream is in its slabs
+    } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
         if (two && m->tail != m->side) {      // the per-sample blocks' weight gradients went to `side` behind the output layer's: both side streams join
@@ -1287,9 +1264,8 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     {
         ScopedTimer tm_red(m, T_REDUCE);
-        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st,
-                            (m->serial && fuse) ? m->d_dyn : nullptr);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     }
     if (early && !split) CHK(join_side(m));
     if (defer) {
@@ -1298,7 +1274,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         // the trajectory test caught a stale-image race), joined by the next user of the decoder (join_side): it runs beside
         // the encoder's backward pass / update and the next step's encoder forward.
         set_launch_stop_event(m->ev_dec);
-        launch_reduce_grads(m->cur_descs ? m->cur_descs : m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
     }
@@ -1464,7 +1440,12 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     const bool from_ds = m->ds_start >= 0;
     if ((!x && !from_ds) || B <= 0 || k <= 0) return fail(IWAE_ERR_ARG, "forward: need x, B > 0, k > 0");
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
-    if (m->C > 0) return fail(IWAE_ERR_ARG, "float32 mode covers the unconditional 1- and 2-layer models");
+    const float* cond = nullptr;      // conditional models (tasks/task05.py, tasks/task04.py): y of these images
+    if (m->C > 0) {
+        if (from_ds) return fail(IWAE_ERR_ARG, "the conditional model takes (x, y) batches, not the resident dataset");
+        if (m->cond_row0 + B > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these images first");
+        cond = ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C;
+    }
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
@@ -1494,10 +1475,20 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         xd = ptr<float>(m->xin);
     } else if (!is_device_ptr(x, m->cfg.device)) { CHK(copy_in(m, m->xin, x, (size_t)B * X * 4)); xd = ptr<float>(m->xin); }
     m->f32_x = xd;
-    // ---- encoder on the images
+    // ---- encoder on the images (conditional models: on concat(x, y), tasks/task05.py:113-118)
     const int b_enc1 = m->enc1[0].sub[0];
     CHK(ensure(m->wenc1.head, (size_t)Bp * 2 * m->Dp[0] * 4, st));
-    CHK(f32_block_fwd(m, b_enc1, m->f32.enc1, xd, X, B, ptr<float>(m->wenc1.head), m->Dp[0], bwd));
+    const float* xenc = xd;
+    if (m->C > 0) {
+        CHK(ensure(m->f32.xcat, (size_t)B * (X + m->C) * 4, st));
+        launch_concat_f32(xd, X, cond, m->C, B, ptr<float>(m->f32.xcat), st);
+        xenc = ptr<float>(m->f32.xcat);
+    }
+    CHK(f32_block_fwd(m, b_enc1, m->f32.enc1, xenc, X + m->C, B, ptr<float>(m->wenc1.head), m->Dp[0], bwd));
+    if (m->has_prior) {     // p(z|y) = N(mu_p(y), sigma_p(y)): the prior block on the B condition rows (tasks/task04.py:108,124)
+        CHK(ensure(m->wprior.head, (size_t)Bp * 2 * m->Dp[0] * 4, st));
+        CHK(f32_block_fwd(m, m->prior[0].sub[0], m->f32.prior, cond, m->C, B, ptr<float>(m->wprior.head), m->Dp[0], bwd));
+    }
     for (int i = 0; i < 6; ++i) CHK(ensure(m->rows[i], (size_t)Mp * 4, st));
     float* lpxz = ptr<float>(m->rows[0]);
     float* t1 = ptr<float>(m->rows[1]);
@@ -1506,13 +1497,16 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     float* t4 = ptr<float>(m->rows[4]);
     float* lqd = ptr<float>(m->rows[5]);
     // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
-    CHK(ensure(m->f32.z[0], (size_t)Mp * m->D[0] * 4, st));
+    const int Dz = m->D[0] + m->C;      // row width of the decoder's input: z, or concat(z, y) (tasks/task05.py:185)
+    CHK(ensure(m->f32.z[0], (size_t)Mp * Dz * 4, st));
     {
         SampleArgs s;
         memset(&s, 0, sizeof(s));
         s.head = ptr<float>(m->wenc1.head); s.ldH = 2 * m->Dp[0]; s.Dp = m->Dp[0]; s.D = m->D[0]; s.head_per_row = 0;
         s.M = M; s.Mp = Mp; s.k = k; s.B = B; s.eps = eps_src(m, 0);
-        s.ZP = nullptr; s.ZF = ptr<float>(m->f32.z[0]); s.ldZF = m->D[0];
+        s.ZP = nullptr; s.ZF = ptr<float>(m->f32.z[0]); s.ldZF = Dz;
+        s.cond = cond; s.C = m->C;      // (the sampling kernel writes y into features D .. D + C - 1 of every row)
+        s.prior_head = m->has_prior ? ptr<float>(m->wprior.head) : nullptr;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
         const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);
@@ -1547,7 +1541,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
     CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
     CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
-    CHK(f32_fwd(m, *d1, ptr<float>(m->f32.z[0]), m->D[0], M, ptr<float>(m->f32.g1), H, GEMM_EPI_TANH));
+    CHK(f32_fwd(m, *d1, ptr<float>(m->f32.z[0]), Dz, M, ptr<float>(m->f32.g1), H, GEMM_EPI_TANH));
     CHK(f32_fwd(m, *d2, ptr<float>(m->f32.g1), H, M, ptr<float>(m->f32.g2), H, GEMM_EPI_TANH));
     CHK(f32_fwd(m, *d3, ptr<float>(m->f32.g2), H, M, ptr<float>(m->f32.logits), X, GEMM_EPI_NONE));
     launch_bern_f32(ptr<float>(m->f32.logits), X, xd, X, M, k, lpxz, st);
@@ -1605,7 +1599,7 @@ int backward_f32(iwae_model* m, int objective) {
     CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false));
     CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M));
     CHK(f32_dx(m, *d2, ptr<float>(m->f32.d2), H, M, ptr<float>(m->f32.d1), H, ptr<float>(m->f32.g1), H, false));
-    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0, ptr<float>(m->f32.d1), H, M));
+    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M));
     CHK(f32_dx(m, *d1, ptr<float>(m->f32.d1), H, M, ptr<float>(m->wdec1.dz), Dp0, nullptr, 0, false));
     const float *dz1_b = nullptr, *dz1_c = nullptr;
     if (two) {
@@ -1649,94 +1643,18 @@ int backward_f32(iwae_model* m, int objective) {
         a.B = B; a.Bp = m->Bp; a.k = k;
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
         a.DHP = nullptr; a.DHF = ptr<float>(m->f32.enc1.dhead);
+        if (m->has_prior) {      // gradient of the conditional prior's head, summed over the image's samples (tasks/task04.py:124-130)
+            CHK(ensure(m->f32.prior.dhead, (size_t)m->Bp * 2 * Dp0 * 4, st));
+            HIPCHK(hipMemsetAsync(m->f32.prior.dhead.p, 0, (size_t)m->Bp * 2 * Dp0 * 4, st));
+            a.prior_head = ptr<float>(m->wprior.head); a.DHF2 = ptr<float>(m->f32.prior.dhead);
+        }
         launch_latent_bwd(a, st);
     }
-    CHK(f32_block_bwd(m, m->enc1[0].sub[0], m->f32.enc1, m->f32_x, X, B, Dp0, nullptr, 0));
+    if (m->has_prior)
+        CHK(f32_block_bwd(m, m->prior[0].sub[0], m->f32.prior, ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C, m->C, B, Dp0, nullptr, 0));
+    CHK(f32_block_bwd(m, m->enc1[0].sub[0], m->f32.enc1, m->C > 0 ? ptr<float>(m->f32.xcat) : m->f32_x, X + m->C, B, Dp0, nullptr, 0));
     HIPCHK(hipGetLastError());
     m->split_offset = m->nparam;       // (data-parallel step: one all-reduce of the whole gradient)
-    return IWAE_OK;
-}
-
-// Small-batch train step through a captured hipGraph (see iwae_model::GraphEntry).  *handled = false: not eligible, the caller
-// runs the ordinary step.  First sight of a key: one eager step in serial form (sizes every buffer); second: capture + first
-// replay; from then on: a one-thread kernel writes this step's counters into d_dyn, then hipGraphLaunch.
-int train_step_graph(iwae_model* m, const float* x, int B, int k, float beta, float lr, int objective, bool* handled) {
-    *handled = false;
-    const bool from_ds = m->ds_start >= 0;
-    if (!m->allow_graph || m->cfg.precision != IWAE_PREC_BF16 || m->comm_main || m->C > 0 || (int64_t)B * k >= m->graph_max_rows) return IWAE_OK;
-    if (!from_ds && (!x || !is_device_ptr(x, m->cfg.device))) return IWAE_OK;        // a host batch is staged by a pageable copy: not capturable
-    if (m->timing > 0 && (m->timing_calls % m->timing) == 0) return IWAE_OK;          // a sampled step of iwae_enable_timing runs eagerly, with its events
-    CHK(join_side(m));
-    iwae_model::GraphEntry* ge = nullptr;
-    for (auto& g : m->graphs)
-        if (g.B == B && g.k == k && g.objective == objective && g.beta == beta && g.x == (from_ds ? nullptr : (const void*)x) && g.from_ds == (int)from_ds) ge = &g;
-    if (!ge) {
-        if (m->graphs.size() >= 16) {
-            HIPCHK(hipStreamSynchronize(m->stream));
-            for (auto& g : m->graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.d_descs) (void)hipFree(g.d_descs); }
-            m->graphs.clear();
-        }
-        m->graphs.push_back({B, k, objective, beta, from_ds ? nullptr : (const void*)x, (int)from_ds, 0, 0, nullptr, nullptr});
-        ge = &m->graphs.back();
-        HIPCHK(hipMalloc((void**)&ge->d_descs, sizeof(LayerDesc) * m->klayers.size()));
-    }
-    if (ge->seen < 0) return IWAE_OK;               // a shape whose capture failed once: eager
-    const float alpha = adam_alpha(m, lr);          // advances the Adam step count: exactly once per train step, whichever branch runs it
-    const int ds_start = m->ds_start;
-    launch_set_dyn(m->d_dyn, m->noise_step, m->batch_offset, alpha, ds_start, m->stream);
-    HIPCHK(hipGetLastError());
-    if (ge->exec && ge->gen == g_alloc_gen) {
-        HIPCHK(hipGraphLaunch(ge->exec, m->stream));
-        m->timing_calls += 1;
-        m->ds_start = -1;
-        m->B = B; m->k = k; m->M = B * k; m->beta = beta; m->have_forward = false;
-        *handled = true;
-        return IWAE_OK;
-    }
-    if (ge->exec) { (void)hipGraphExecDestroy(ge->exec); ge->exec = nullptr; ge->seen = 0; }        // buffers moved since the capture
-    m->adam_t -= 1;                                  // (the serial step below computes alpha itself through backward_impl)
-    m->serial = true;
-    int rc = IWAE_OK;
-    if (ge->seen == 0) {                             // warm-up: the same serial step, eagerly -- allocates and plans everything the capture will reference
-        rc = forward_impl(m, x, B, k, beta, nullptr, objective, true, nullptr);
-        if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
-        m->serial = false;
-        if (rc != IWAE_OK) return rc;
-        // this shape's layer table (row splits, slab addresses) as the step just planned it: the capture's slab reductions read this copy
-        HIPCHK(hipMemcpy(ge->d_descs, m->descs.data(), sizeof(LayerDesc) * m->descs.size(), hipMemcpyHostToDevice));
-        ge->seen = 1;
-        *handled = true;
-        return IWAE_OK;
-    }
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { m->serial = false; (void)hipGetLastError(); m->allow_graph = false; return IWAE_OK; }      // capture unavailable: eager from now on
-    const uint64_t gen0 = g_alloc_gen;
-    m->ds_start = ds_start;
-    m->cur_descs = ge->d_descs;
-    m->capturing = true;
-    rc = forward_impl(m, x, B, k, beta, nullptr, objective, true, nullptr);
-    if (rc == IWAE_OK) rc = backward_impl(m, objective, lr);
-    m->serial = false;
-    m->cur_descs = nullptr;
-    m->capturing = false;
-    e = hipStreamEndCapture(m->stream, &graph);
-    if (rc != IWAE_OK || e != hipSuccess || !graph || gen0 != g_alloc_gen) {
-        // something moved or could not be captured: drop the capture and run this step eagerly (nothing has executed yet)
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        if (rc == IWAE_OK) m->adam_t -= 1;           // (backward_impl advanced the step count; the eager step will do it again)
-        ge->seen = (rc != IWAE_OK || e != hipSuccess) ? -1 : 0;      // -1: this shape is never captured again (the eager step reports a real error)
-        m->ds_start = ds_start;
-        return IWAE_OK;                              // *handled = false
-    }
-    e = hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) { ge->exec = nullptr; (void)hipGetLastError(); m->adam_t -= 1; m->ds_start = ds_start; m->allow_graph = false; return IWAE_OK; }
-    ge->gen = g_alloc_gen;
-    HIPCHK(hipGraphLaunch(ge->exec, m->stream));     // the capture recorded the step; this runs it (d_dyn already holds its counters)
-    m->have_forward = false;
-    *handled = true;
     return IWAE_OK;
 }
 
@@ -1787,7 +1705,6 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
                                       std::to_string(sizeof(iwae_config)) + " bytes (binding built against another include/iwae_amd.h?)");
     if (cfg->reserved != 0) return fail(IWAE_ERR_ARG, "iwae_config.reserved must be 0");
     if (cfg->precision != IWAE_PREC_BF16 && cfg->precision != IWAE_PREC_FP32) return fail(IWAE_ERR_ARG, "precision must be IWAE_PREC_BF16 or IWAE_PREC_FP32");
-    if (cfg->precision == IWAE_PREC_FP32 && cfg->cond_dim > 0) return fail(IWAE_ERR_ARG, "float32 mode covers the unconditional 1- and 2-layer models (cond_dim = 0)");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(IWAE_ERR_ARG, "need world_size >= 1 and 0 <= rank < world_size");
     if (cfg->n_layers != 1 && cfg->n_layers != 2) return fail(IWAE_ERR_ARG, "n_layers must be 1 or 2 (main.py:17)");
     for (int i = 0; i < cfg->n_layers; ++i) {
@@ -1866,8 +1783,6 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipMemset(m->vel, 0, nb));
     HIPCHK(hipMalloc((void**)&m->d_zero, 1024));
     HIPCHK(hipMemset(m->d_zero, 0, 1024));
-    HIPCHK(hipMalloc((void**)&m->d_dyn, sizeof(StepDyn)));
-    HIPCHK(hipMemset(m->d_dyn, 0, sizeof(StepDyn)));
     HIPCHK(hipMalloc((void**)&m->d_scalars, SC_COUNT * 4));
     HIPCHK(hipMemset(m->d_scalars, 0, SC_COUNT * 4));
     HIPCHK(hipHostMalloc((void**)&m->h_scalars, SC_COUNT * 4));
@@ -1910,9 +1825,9 @@ void iwae_destroy(iwae_handle m) {
         for (DevBuf* b : bb) free_buf(*b);
     }
     {
-        iwae_model::F32Block* fb[] = {&m->f32.enc1, &m->f32.enc2, &m->f32.dec2};
+        iwae_model::F32Block* fb[] = {&m->f32.enc1, &m->f32.enc2, &m->f32.dec2, &m->f32.prior};
         for (auto* w : fb) { DevBuf* bb[] = {&w->h1, &w->h2, &w->dhead, &w->d2, &w->d1, &w->dx}; for (DevBuf* b : bb) free_buf(*b); }
-        DevBuf* bb[] = {&m->f32.z[0], &m->f32.z[1], &m->f32.g1, &m->f32.g2, &m->f32.logits, &m->f32.d2, &m->f32.d1, &m->f32.slab, &m->f32.bpart};
+        DevBuf* bb[] = {&m->f32.z[0], &m->f32.z[1], &m->f32.g1, &m->f32.g2, &m->f32.logits, &m->f32.d2, &m->f32.d1, &m->f32.slab, &m->f32.bpart, &m->f32.xcat};
         for (DevBuf* b : bb) free_buf(*b);
     }
     if (m->param) (void)hipFree(m->param);
@@ -1921,8 +1836,6 @@ void iwae_destroy(iwae_handle m) {
     if (m->vel) (void)hipFree(m->vel);
     if (m->d_descs) (void)hipFree(m->d_descs);
     if (m->d_zero) (void)hipFree(m->d_zero);
-    for (auto& ge : m->graphs) { if (ge.exec) (void)hipGraphExecDestroy(ge.exec); if (ge.d_descs) (void)hipFree(ge.d_descs); }
-    if (m->d_dyn) (void)hipFree(m->d_dyn);
     if (m->d_scalars) (void)hipFree(m->d_scalars);
     if (m->h_scalars) (void)hipHostFree(m->h_scalars);
     for (int i = 0; i < T_COUNT; ++i) {
@@ -2101,14 +2014,11 @@ int iwae_adam_step(iwae_handle m, float lr, float grad_scale) {
 int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     if (!m || !name) return fail(IWAE_ERR_ARG, "set_option: null argument");
     HIPCHK(hipSetDevice(m->cfg.device));
-    // a switch changes which kernels the next call launches: nothing of the previous calls may still be in flight, and
-    // captured steps (which hold the old choice) are dropped
+    // a switch changes which kernels the next call launches: nothing of the previous calls may still be in flight
     CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->side) HIPCHK(hipStreamSynchronize(m->side));
     if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
-    for (auto& ge : m->graphs) { if (ge.exec) (void)hipGraphExecDestroy(ge.exec); if (ge.d_descs) (void)hipFree(ge.d_descs); }
-    m->graphs.clear();
     m->have_forward = false;
     const bool on = value != 0;
     const int iv = (int)value;
@@ -2143,8 +2053,6 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "wg_group") m->allow_wg_group = on;                 // ... as one grouped launch
     else if (n == "no_early_wout") m->allow_early_wout = !on;         // the output layer's weight gradient forks behind out_bwd
     else if (n == "dp_concurrent") m->dp_concurrent = on;             // data-parallel step: no device-side order between its two all-reduces
-    else if (n == "graph") m->allow_graph = on;                       // captured small-batch step (hipGraph replay)
-    else if (n == "graph_rows") m->graph_max_rows = iv;
 #ifdef IWAE_DIAG
     // diagnostic builds only (DIAG=1 ./build.sh): in-kernel phase stamps and the weight-gradient ablations -- results are wrong or slower
     else if (n == "stamps") { m->want_stamps = on; if (on) { m->allow_s_mode = false; m->allow_bern_pipe = false; m->allow_block_fused = false; m->allow_dec_fused = false; } }
@@ -2184,15 +2092,6 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
         CHK(fetch_outputs(m, scalars, nullptr));
         m->noise_step += 1;
         return IWAE_OK;
-    }
-    if (!eps && !want) {                        // small batches: the captured step (hipGraph replay), where eligible
-        bool handled = false;
-        CHK(train_step_graph(m, x, B, k, beta, lr, objective, &handled));
-        if (handled) {
-            CHK(fetch_outputs(m, scalars, nullptr));
-            m->noise_step += 1;
-            return IWAE_OK;
-        }
     }
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
     if (m->comm_main) {                         // data-parallel step: exchange between gradient and update (iwae_comm_init)
@@ -2313,7 +2212,7 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
             const int kn = std::min(kc, k - s0);
             m->eval_k_total = (kc < k) ? k : 0;
             m->eval_s_off = s0;
-            const bool f32 = m->eval_precision == IWAE_PREC_FP32 && m->C == 0;      // (the conditional models evaluate on the bf16 path)
+            const bool f32 = m->eval_precision == IWAE_PREC_FP32;
             rc = f32 ? forward_f32(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
                      : forward_impl(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
             m->eval_k_total = 0; m->eval_s_off = 0;
