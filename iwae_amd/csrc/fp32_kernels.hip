@@ -111,6 +111,118 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
         }
 }
 
+// The same product on 128 x 128 tiles (round 3), for every GEMM that has more than one 64-tile in both directions: wave (wm, wn)
+// owns 64 x 64 = 4 x 4 MFMA tiles, so a k-step of 4 costs it 8 LDS reads for 16 MFMAs (the 64 x 64 kernel: 4 for 4 -- its MFMA pipe
+// was 39 % busy) and the activations of the 784-wide layer are fetched 7 times instead of 13; the k-steps of 16 are double
+// buffered in LDS (one barrier per step), the next step's quads are in flight under this step's 64 MFMAs.  Same operand addressing
+// (element strides), same K split, same epilogues; bit-for-bit the same k-ordered fmaf chain per element.
+__global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {      // <= 128 registers: four workgroups per CU (1 024 slots: the 800 workgroups of a 51 200 x 200 product are one round, not two)
+    __shared__ float sA[2][128][17];
+    __shared__ float sB[2][16][144];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
+    // two quads per thread and operand: quad u of the A tile is (m, k..k+3) with m = (tid >> 2) + 64u (k-fast) or (m..m+3, k) with
+    // k = (tid >> 5) + 8u (m-fast); the B tile likewise
+    auto fetch_a = [&](int k0, int u) -> float4 {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int gm = m0 + (a_kfast ? (tid >> 2) + 64 * u : (tid & 31) * 4), gk = k0 + (a_kfast ? (tid & 3) * 4 : (tid >> 5) + 8 * u);
+        const float* p = a.A + (size_t)gm * a.sam + (size_t)gk * a.sak;
+        const int lim = a_kfast ? k_end - gk : a.M - gm;
+        const bool outer_ok = a_kfast ? gm < a.M : gk < k_end;
+        if (outer_ok && lim >= 4 && a.avec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e * (a_kfast ? a.sak : a.sam)];
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto fetch_b = [&](int k0, int u) -> float4 {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int gn = n0 + (b_nfast ? (tid & 31) * 4 : (tid >> 2) + 64 * u), gk = k0 + (b_nfast ? (tid >> 5) + 8 * u : (tid & 3) * 4);
+        const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
+        const int lim = b_nfast ? a.N - gn : k_end - gk;
+        const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
+        if (outer_ok && lim >= 4 && a.bvec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e * (b_nfast ? a.sbn : a.sbk)];
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto stash = [&](int buf, const float4 (&ra)[2], const float4 (&rb)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float av4[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w}, bv4[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a_kfast) sA[buf][(tid >> 2) + 64 * u][(tid & 3) * 4 + e] = av4[e]; else sA[buf][(tid & 31) * 4 + e][(tid >> 5) + 8 * u] = av4[e];
+                if (b_nfast) sB[buf][(tid >> 5) + 8 * u][(tid & 31) * 4 + e] = bv4[e]; else sB[buf][(tid & 3) * 4 + e][(tid >> 2) + 64 * u] = bv4[e];
+            }
+        }
+    };
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { ra[u] = make_float4(0.f, 0.f, 0.f, 0.f); rb[u] = ra[u]; }
+    if (k_beg < k_end) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ra[u] = fetch_a(k_beg, u); rb[u] = fetch_b(k_beg, u); }
+    }
+    stash(0, ra, rb);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+        const bool more = k0 + 16 < k_end;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { ra[u] = fetch_a(k0 + 16, u); rb[u] = fetch_b(k0 + 16, u); }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = sA[buf][64 * wm + 16 * i + r16][4 * kk + q];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = sB[buf][4 * kk + q][64 * wn + 16 * j + r16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1, ra, rb);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wn + 16 * j + r16;
+            if (n >= a.N) continue;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (a.epi == GEMM_EPI_TANH) v = tanhf(v);
+                else if (a.epi == GEMM_EPI_EXP) v = expf(v) + 1e-6f;
+                else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n]; v *= 1.0f - y * y; }
+                float* dst = C + (size_t)m * a.ldc + n;
+                *dst = a.accumulate ? *dst + v : v;
+            }
+        }
+}
+
 // out[i] = sum over z of slabs[z*stride + i] (fixed order), i < n
 __global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slabs, size_t stride, int nsplit, size_t n, float* out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -195,7 +307,12 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     const long a_str = a.sak == 1 ? a.sam : a.sak, b_str = a.sbn == 1 ? a.sbk : a.sbn;
     a.avec = (((uintptr_t)a.A & 15) == 0 && a_str % 4 == 0 && (a.sak == 1 || a.sam == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
     a.bvec = (((uintptr_t)a.B & 15) == 0 && b_str % 4 == 0 && (a.sbn == 1 || a.sbk == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
+    // 128 x 128 tiles wherever both extents exceed one 64-tile (the per-sample layers, the weight gradients); the small kernel for the
+    // rest (few images, narrow heads: a 128-tile would be mostly padding)
+    // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
+    const long big_wgs = (long)((a.N + 127) / 128) * ((a.M + 127) / 128) * nsplit;
+    if (a.M > 64 && a.N > 64 && big_wgs >= 512) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128, nsplit), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, stride, nsplit, n, out);

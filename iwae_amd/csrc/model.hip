@@ -1385,7 +1385,9 @@ int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int ro
 }
 // grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
 int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows) {
-    const int nsplit = std::max(1, std::min(64, rows / 1024));
+    // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
+    const int tiles = (kl.Kin > 64 && kl.Nout > 64) ? ((kl.Kin + 127) / 128) * ((kl.Nout + 127) / 128) : ((kl.Kin + 63) / 64) * ((kl.Nout + 63) / 64);
+    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (1024 + tiles - 1) / tiles));
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     CHK(ensure(m->f32.slab, nsplit * nW * 4, m->stream));
     CHK(ensure(m->f32.bpart, (size_t)nsplit * kl.Nout * 4, m->stream));

@@ -11,6 +11,37 @@ __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
 __global__ void copy_kernel(const uint4* a, uint4* b, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
 }
+// tuned copies (the yardstick for "what a streaming kernel can reach"): UN independent 16-byte loads in flight per thread, then
+// the stores; NT: non-temporal loads and stores (streamed data that is not read again)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int UN, bool NT>
+__global__ __launch_bounds__(256) void copy_tuned_kernel(const uint4* __restrict__ a4, uint4* __restrict__ b4, size_t n) {
+    const u32x4* a = (const u32x4*)a4; u32x4* b = (u32x4*)b4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += UN * stride) {
+        u32x4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) if (i + u * stride < n) v[u] = NT ? __builtin_nontemporal_load(a + i + u * stride) : a[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) if (i + u * stride < n) { if (NT) __builtin_nontemporal_store(v[u], b + i + u * stride); else b[i + u * stride] = v[u]; }
+    }
+}
+template <int UN>
+__global__ __launch_bounds__(256) void read_kernel(const uint4* __restrict__ a, unsigned* out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += UN * stride) {
+        uint4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = (i + u * stride < n) ? a[i + u * stride] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ __launch_bounds__(256) void write_kernel(uint4* b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = make_uint4(1, 2, 3, 4);
+}
 __global__ void clock_kernel(unsigned long long* out, int iters) {
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     float x = threadIdx.x;
@@ -67,6 +98,26 @@ int main() {
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("copy 1 GiB: %.3f ms -> %.2f TB/s (read+write)\n", ms, 2.0 * bytes / ms / 1e9);
+    }
+    // tuned copies, read-only and write-only streams (best of 3 each)
+    {
+        auto timeit = [&](const char* name, double moved, auto launch) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                (void)hipEventRecord(e0, st); launch(); (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (rep && ms < best) best = ms;
+            }
+            printf("%-44s %.3f ms -> %.2f TB/s\n", name, best, moved / best / 1e9);
+        };
+        const size_t n = bytes / 16;
+        unsigned* dout; CK(hipMalloc(&dout, 4));
+        timeit("copy 1 GiB, 4 loads in flight, 2048 blocks", 2.0 * bytes, [&] { hipLaunchKernelGGL((copy_tuned_kernel<4, false>), dim3(2048), dim3(256), 0, st, a, b, n); });
+        timeit("copy 1 GiB, 8 loads in flight, 2048 blocks", 2.0 * bytes, [&] { hipLaunchKernelGGL((copy_tuned_kernel<8, false>), dim3(2048), dim3(256), 0, st, a, b, n); });
+        timeit("copy 1 GiB, 8 loads in flight, 4096 blocks", 2.0 * bytes, [&] { hipLaunchKernelGGL((copy_tuned_kernel<8, false>), dim3(4096), dim3(256), 0, st, a, b, n); });
+        timeit("copy 1 GiB, 8 in flight, non-temporal, 2048", 2.0 * bytes, [&] { hipLaunchKernelGGL((copy_tuned_kernel<8, true>), dim3(2048), dim3(256), 0, st, a, b, n); });
+        timeit("copy 128 MiB (a step's worth), 8 in flight", 2.0 * (bytes / 8), [&] { hipLaunchKernelGGL((copy_tuned_kernel<8, false>), dim3(2048), dim3(256), 0, st, a, b, n / 8); });
+        timeit("read 1 GiB, 8 loads in flight", 1.0 * bytes, [&] { hipLaunchKernelGGL((read_kernel<8>), dim3(2048), dim3(256), 0, st, a, dout, n); });
+        timeit("write 1 GiB", 1.0 * bytes, [&] { hipLaunchKernelGGL(write_kernel, dim3(2048), dim3(256), 0, st, b, n); });
     }
     // MFMA
     float* mo; CK(hipMalloc(&mo, 2048 * 256 * 4));
