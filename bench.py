@@ -28,7 +28,7 @@ TIMING_STEPS = 48            # steps of that pass (>= 16 launches per kernel; an
                              # so none of it happens inside the timed region)
 SETTLE_STEPS = 100           # untimed steps run in any case before the timed region (--warmup if that is larger): clocks ramped, the noise
                              # ring primed, every buffer at its final size.  A fixed COUNT: every rank must issue the same collectives
-PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain device copy reaches ~4.8 TB/s on this box
+PEAK_HBM_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md); a plain 1 GiB device copy reaches 4.8 TB/s on these boxes (profiles/r03_copy_yardstick.txt)
 PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (same guide)
 PEAK_FP32_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32 (precision fp32)
 RIDGE = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)      # 312 FLOP/B
@@ -90,7 +90,7 @@ def kernel_models(cfg):
                                  " (decoder dX chain in one launch: dg2 = s W3^T -> dpre2 -> dpre1 -> dz; s, g2, g1 in, dpre2, dpre1, dz out)",
                             bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + (2 if cfg["layers"] == 1 else 4) * D), flop=2 * M * (H * X + H * H + H * D),
                             match="dec_bwd_rows_kernel" if M <= 1024 else "dec_bwd_kernel"),
-        "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, side stream)" if big else
+        "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, s weighted on its way through the loaders' registers, side stream)" if big else
                                "wgradp_kernel<8,4,4,4,true> (output-layer weight gradient, side stream)",
                           bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true"),
         "dx_hidden": dict(name="dense_kernel<EPI_DX,7> (dpre1 = (dpre2 V2^T) * (1 - g1^2))", bytes=M * 6 * H, flop=2 * M * H * H, match="dense_kernel<2, 7"),
@@ -155,7 +155,7 @@ def load_profile_traffic(kernel_match, config):
     """HBM bytes per launch of the kernel whose device-side name contains `kernel_match`, from the PMC passes of
     tools/profile_bench.sh kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: MI355X_MICROARCH.md, HBM).  Returned WITH its
     source, or None when no kept profile holds that instantiation (the number is a profile artefact, not a live measurement)."""
-    for tag in ("r02",):
+    for tag in ("r03", "r03_c2"):
         path = os.path.join(ROOT, "profiles", "%s_kernel_traffic.json" % tag)
         if not os.path.exists(path):
             continue
