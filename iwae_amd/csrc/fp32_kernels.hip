@@ -201,6 +201,35 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
         __syncthreads();
         buf ^= 1;
     }
+    if (a.epi == GEMM_EPI_BERN) {       // the output layer of a forward-only call: log p(x|z) of this half tile's 64 columns per row, no logits in HBM
+        float bias4[4];
+        bool nok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wn + 16 * j + r16;
+            nok[j] = n < a.N;
+            bias4[j] = (nok[j] && a.bias) ? a.bias[n] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                const int mc = min(m, a.M - 1);
+                const float* xr = a.XB + (size_t)(mc / a.bern_k) * a.bern_X;
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (nok[j]) {
+                        const float l = acc[i][j][r] + bias4[j];
+                        sum += xr[n0 + 64 * wn + 16 * j + r16] * l - (fmaxf(l, 0.0f) + log1pf(expf(-fabsf(l))));      // iwae1.py:111
+                    }
+                }
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);      // the 16 columns of a tile sit on lanes r16
+                if (r16 == 0 && m < a.M) a.part[(size_t)(2 * blockIdx.x + wn) * a.part_stride + m] = sum;
+            }
+        return;
+    }
     float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -301,6 +330,9 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
     hipLaunchKernelGGL(concat_f32_kernel, dim3((unsigned)(((size_t)rows * (na + nb) + 255) / 256)), dim3(256), 0, st, a, na, b, nb, rows, out);
 }
 
+bool gemm_f32_takes_big(int M, int N, int nsplit) {
+    return M > 64 && N > 64 && (long)((N + 127) / 128) * ((M + 127) / 128) * nsplit >= 512;
+}
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;
     // float4 fetches where every quad is 16-byte aligned: base pointer, the non-unit stride and the k-chunk offsets
@@ -310,8 +342,7 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     // 128 x 128 tiles wherever both extents exceed one 64-tile (the per-sample layers, the weight gradients); the small kernel for the
     // rest (few images, narrow heads: a 128-tile would be mostly padding)
     // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
-    const long big_wgs = (long)((a.N + 127) / 128) * ((a.M + 127) / 128) * nsplit;
-    if (a.M > 64 && a.N > 64 && big_wgs >= 512) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128, nsplit), dim3(256), 0, st, a);
+    if (gemm_f32_takes_big(a.M, a.N, nsplit)) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128, nsplit), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {

@@ -286,7 +286,7 @@ void launch_unpack_p(const uint16_t* P, int rows, int F, int Fp, float* out, hip
 void launch_eps_dump(const EpsSrc& e, int B, int k, int D, float* out, hipStream_t st);
 
 // ---- float32 mode (fp32_kernels.hip)
-enum { GEMM_EPI_NONE = 0, GEMM_EPI_TANH = 1, GEMM_EPI_EXP = 2, GEMM_EPI_DTANH = 3 };
+enum { GEMM_EPI_NONE = 0, GEMM_EPI_TANH = 1, GEMM_EPI_EXP = 2, GEMM_EPI_DTANH = 3, GEMM_EPI_BERN = 4 };
 struct GemmF32Args {
     const float* A; long sam, sak;        // element (m,k) of op(A) at A[m*sam + k*sak]
     const float* B; long sbk, sbn;        // element (k,n) of op(B) at B[k*sbk + n*sbn]
@@ -298,7 +298,12 @@ struct GemmF32Args {
     int accumulate;                       // C += instead of C =
     int kchunk; size_t slab_stride;       // K split over blockIdx.z: split z covers kchunk k's and writes C + z*slab_stride
     int avec, bvec;                       // set by launch_gemm_f32: the operand's quads may be fetched as float4
+    // GEMM_EPI_BERN (128-tile kernel only, forward-only calls): the logits are not stored; every 64-column half tile leaves its partial
+    // log p(x|z) = sum_n x_n l_n - softplus(l_n) per row in part[(2 * column tile + half) * part_stride + m]; lse_kernel adds them in fixed order
+    const float* XB; int bern_k, bern_X;  // x [B][bern_X] float32 in {0,1}; row m belongs to image m / bern_k
+    float* part; size_t part_stride;
 };
+bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
 void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st);      // part [nsplit][N]

@@ -1542,11 +1542,26 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     const int H = d1->Nout;
     CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
     CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
-    CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
     CHK(f32_fwd(m, *d1, ptr<float>(m->f32.z[0]), Dz, M, ptr<float>(m->f32.g1), H, GEMM_EPI_TANH));
     CHK(f32_fwd(m, *d2, ptr<float>(m->f32.g1), H, M, ptr<float>(m->f32.g2), H, GEMM_EPI_TANH));
+    // forward-only calls at large row counts (the k = 5000 evaluator): log p(x|z) in the epilogue of the output layer's GEMM -- the float32
+    // logits (1.6 GB per launch of 2^19 rows) are neither written nor read back; per 64-column half tile a partial sum that lse_kernel adds
+    const bool fuse_bern = !bwd && !(want && want->logits) && gemm_f32_takes_big(M, X, 1);
+    m->px_parts = 1;
+    if (fuse_bern) {
+        m->px_parts = 2 * ((X + 127) / 128);
+        CHK(ensure(m->px_part, (size_t)m->px_parts * Mp * 4, st));
+        GemmF32Args ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.A = ptr<float>(m->f32.g2); ga.sam = H; ga.sak = 1; ga.B = m->param + d3->offW; ga.sbk = d3->Nout; ga.sbn = 1; ga.M = M; ga.N = X; ga.K = H;
+        ga.bias = m->param + d3->offb; ga.epi = GEMM_EPI_BERN; ga.kchunk = H;
+        ga.XB = xd; ga.bern_k = k; ga.bern_X = X; ga.part = ptr<float>(m->px_part); ga.part_stride = (size_t)Mp;
+        launch_gemm_f32(ga, 1, st);
+    } else {
+    CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
     CHK(f32_fwd(m, *d3, ptr<float>(m->f32.g2), H, M, ptr<float>(m->f32.logits), X, GEMM_EPI_NONE));
     launch_bern_f32(ptr<float>(m->f32.logits), X, xd, X, M, k, lpxz, st);
+    }
     if (want && want->logits) {      // reference [k,B,X] order
         CHK(ensure(m->scratch, (size_t)M * X * 4, st));
         launch_export_mat(ptr<float>(m->f32.logits), B, k, X, ptr<float>(m->scratch), st);
@@ -1572,14 +1587,14 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
-        a.n_px_part = 1; a.px_stride = 0; a.term0_out = lpxz;
+        a.n_px_part = m->px_parts; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
+        if (m->px_parts > 1) a.term[0] = ptr<float>(m->px_part);      // (the fused Bernoulli epilogue's per-half-tile partial sums)
         launch_lse(a, st);
         launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
     }
     HIPCHK(hipGetLastError());
     m->have_forward = true;
     m->fwd_was_f32 = true;
-    m->px_parts = 1;
     return IWAE_OK;
 }
 
