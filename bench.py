@@ -244,8 +244,10 @@ def run():
     net = NativeModel(cfg["layers"], cfg["nh"], cfg["nl"], x_dim=X_DIM, device=local_rank, seed=123, world_size=world, rank=rank,
                       precision=args.precision, options=options)
     net.set_output_bias(utils.bias_from_mean(p))                       # identical init on every rank (same seed)
-    # world > 1: the in-library RCCL exchange, or an exception on every rank -- never a silent fallback (iwae_amd/parallel.py)
-    dp = DataParallelStep(net, rank, world, in_library=not args.dp_torch, force_dist=force_dist)
+    # world > 1: the in-library RCCL exchange.  If it cannot be brought up on EVERY rank, all ranks together take the torch.distributed
+    # path (a collective decision, printed, and recorded in config.dp_path -- never a silent or rank-asymmetric fallback); the library's
+    # own default (DataParallelStep without allow_fallback) raises instead
+    dp = DataParallelStep(net, rank, world, in_library=not args.dp_torch, force_dist=force_dist, allow_fallback=True)
     rccl_ranks = net.comm_info()[0] if dp.in_library else (dist.get_world_size() if dist and dp.path == "torch_fallback" else 0)
     lr = 1e-3
     obj_id = OBJ_ID[cfg["obj"]]
