@@ -206,7 +206,7 @@ struct iwae_model {
                                        // both at once take more of the machine from the output layer's gradient, which is what the step waits for)
     hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
     hipEvent_t ev_s2 = nullptr;
-    hipEvent_t ev_ar = nullptr;        // data-parallel step: recorded behind the decoder segment's all-reduce (dp_finish)
+    hipEvent_t ev_ar = nullptr;        // data-parallel step: recorded behind the encoder segment's all-reduce (dp_finish)
     bool dp_concurrent = false;        // option dp_concurrent: the two all-reduces of a step may run at the same time (see dp_finish)
     bool use_side2 = true;
     hipEvent_t ev_lse = nullptr;
@@ -1686,17 +1686,20 @@ int dp_finish(iwae_model* m, float lr) {
     const size_t n = m->nparam, off = m->split_offset;
     if (off < n && m->dec_pending) {
         const int b0 = m->descs[m->dec1[0].sub[0]].block_begin;
+        // Two communicators, one per stream.  Until an N > 1 run has shown that the two collectives may be co-resident, they are ORDERED
+        // on the device, and in the order in which their inputs become ready: the encoder's segment first (main stream: its gradient is
+        // complete ~30 us before the decoder's, whose reduction waits for the hidden layers' weight gradients), the decoder's behind an
+        // event recorded after it -- a wait that is normally already satisfied.  (Round 3 first had them the other way round: the main
+        // stream's update and the next encoder forward then waited for the decoder's reduction, +22 us per step in the one-rank
+        // rehearsal.)  Every rank enqueues them in this order.  Option dp_concurrent = 1 drops the wait.
+        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
+        if (!m->dp_concurrent) HIPCHK(hipEventRecord(m->ev_ar, m->stream));
+        launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
+        if (!m->dp_concurrent) HIPCHK(hipStreamWaitEvent(m->tail, m->ev_ar, 0));
         NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail));
         set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
-        // Two communicators, one per stream.  Until an N > 1 run has shown that the two collectives may be co-resident, they are ORDERED
-        // on the device: the main stream's all-reduce waits for an event behind the side stream's (issued long before -- the wait is
-        // normally already satisfied).  Every rank enqueues them in this order.  Option dp_concurrent = 1 drops the wait.
-        if (!m->dp_concurrent) HIPCHK(hipEventRecord(m->ev_ar, m->tail));
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
                     m->tail, b0);
-        if (!m->dp_concurrent) HIPCHK(hipStreamWaitEvent(m->stream, m->ev_ar, 0));
-        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
-        launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
     } else {
         CHK(join_side(m));
         NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, n, ncclFloat32, ncclSum, m->comm_main, m->stream));
