@@ -27,6 +27,17 @@ struct EpsSrc {
     int k_total = 0, s_off = 0, kc = 0;
 };
 
+struct LseArgs {
+    const float* term[5]; float coef[5];
+    const float* lq_dreg;
+    int B, k; float beta; int objective;
+    float cz_on;                         // 1: prior term -z reaches dz (1-layer); 0: 2-layer (handled per row)
+    const float* head; int ldH, D, Dp;   // for KL (1-layer) or null
+    float* logw; float* wn; float* gx; float4* cf; float* per_b;
+    int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
+    float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
+};
+
 struct DenseArgs {
     const uint16_t* X; int ldX;       // P-layout rows [M][ldX], ldX = 32*KT
     const char* img;                  // MG-major A-image of the weight
@@ -55,6 +66,11 @@ struct DenseArgs {
     const uint16_t* pre_Z;               // z rows, P-layout [M][32*pre_KT1] (when zhead == null; else z is made in the kernel, see ZIN fields)
     uint16_t *pre_G1, *pre_G2;           // the layers' activations, P-layout [M][32*KT], kept for the backward pass (null: forward only, not stored)
     unsigned long long* stamps;       // diagnostic build (IWAE_DENSE_STAMPS) only: [blocks*4 waves][8] phase cycle sums, else null
+    // bern_pipe_kernel<.., PRE, QW>, k a divisor of its 200 rows: the workgroup's rows are whole images, so what lse_kernel would do for
+    // them (log_w, log-mean-exp, row weights, per-image values: `lse`) runs at the end of the workgroup -- no launch between the decoder
+    // forward and the backward pass (lse.term[0] is ignored: log p(x|z) comes from the kernel's own sums)
+    int lse_on;
+    LseArgs lse;
 };
 
 struct SampleArgs {
@@ -201,16 +217,6 @@ struct GaussLpArgs {
     float* out;
 };
 
-struct LseArgs {
-    const float* term[5]; float coef[5];
-    const float* lq_dreg;
-    int B, k; float beta; int objective;
-    float cz_on;                         // 1: prior term -z reaches dz (1-layer); 0: 2-layer (handled per row)
-    const float* head; int ldH, D, Dp;   // for KL (1-layer) or null
-    float* logw; float* wn; float* gx; float4* cf; float* per_b;
-    int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
-    float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
-};
 
 struct LatentBwdArgs {
     const float* dz; int ldDZ;
@@ -255,6 +261,7 @@ struct LayerDesc {
 void set_launch_stop_event(hipEvent_t e);
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st);
 void launch_out_bwd(const OutBwdArgs& a, hipStream_t st);
+bool bern_lse_ok(const DenseArgs& a);   // ... and can take lse_kernel's work for its rows (DenseArgs.lse_on)
 bool bern_pipe_ok(const DenseArgs& a);  // shapes bern_pipe_kernel covers (launch_dense falls back to dense_kernel<EPI_BERN> otherwise)
 bool out_bwd_has_s_mode(int KT);      // hidden widths with a compiled out_bwd_s_kernel / dec_bwd_kernel
 void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st);

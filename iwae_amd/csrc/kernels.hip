@@ -978,6 +978,143 @@ __global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(De
     }
 }
 
+// Wave-wide sum / max through the DPP path (row_shr 1, 2, 4, 8, then row_bcast 15 and 31: the total arrives in lane 63 and is handed to
+// every lane through an SGPR): six vector instructions of ~10 cycles each, where the ds_bpermute butterfly of __shfl_xor is six LDS
+// round trips of ~100 -- lse_image is four such reductions deep, on the tail of the decoder kernel.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_or(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_or<0x111, 0xf>(0.0f, v); v += dpp_or<0x112, 0xf>(0.0f, v); v += dpp_or<0x114, 0xf>(0.0f, v); v += dpp_or<0x118, 0xf>(0.0f, v);
+    v += dpp_or<0x142, 0xa>(0.0f, v);
+    v += dpp_or<0x143, 0xc>(0.0f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_or<0x111, 0xf>(-INFINITY, v)); v = fmaxf(v, dpp_or<0x112, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_or<0x114, 0xf>(-INFINITY, v)); v = fmaxf(v, dpp_or<0x118, 0xf>(-INFINITY, v));
+    v = fmaxf(v, dpp_or<0x142, 0xa>(-INFINITY, v));
+    v = fmaxf(v, dpp_or<0x143, 0xc>(-INFINITY, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// What one wave does for image b: log_w over its k samples, logmeanexp / softmax / objective gradients (iwae1.py:113-139).  `src` says where
+// the rows' terms come from: LseGlobalSrc (lse_kernel: the arrays of LseArgs) or the LDS copies bern_pipe_kernel keeps of what it made itself.
+struct LseGlobalSrc {
+    __device__ __forceinline__ float px(const LseArgs& a, int, int r) const {
+        float px = a.term[0][r];
+        if (a.n_px_part > 1) {      // log p(x|z) as partial sums over pixel groups (small row counts): fixed order
+            // (all partials requested at once: as a loop of dependent adds each load waited for the one before it -- 13 L2 round
+            // trips, most of this kernel's 10 us at B = 20)
+            float part[16];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) part[i] = (i < a.n_px_part) ? a.term[0][(size_t)i * a.px_stride + r] : 0.0f;
+#pragma unroll
+            for (int i = 1; i < 16; ++i) px += part[i];
+            for (int i = 16; i < a.n_px_part; ++i) px += a.term[0][(size_t)i * a.px_stride + r];
+            a.term0_out[r] = px;
+        }
+        return px;
+    }
+    __device__ __forceinline__ float px_total(const LseArgs& a, int, int r) const { return a.term0_out[r]; }      // (total log p(x|z), written by px() above)
+    __device__ __forceinline__ float term(const LseArgs& a, int t, int, int r) const { return a.term[t][r]; }
+    __device__ __forceinline__ float lq_dreg(const LseArgs& a, int, int r) const { return a.lq_dreg[r]; }
+};
+
+template <class SRC>
+__device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const int lane, const SRC& src) {
+    const int k = a.k;
+    const bool single = k <= 64;          // one sample per lane: log_w stays in a register between the passes
+    // the image's head (for the KL term at the end): requested first, so that its round trip runs beside the log_w terms' instead of
+    // behind the whole kernel
+    float kmu[2] = {0.0f, 0.0f}, ksg[2] = {1.0f, 1.0f};
+    if (a.head) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = lane + 64 * i;
+            if (f < a.D) { kmu[i] = a.head[(size_t)b * a.ldH + f]; ksg[i] = a.head[(size_t)b * a.ldH + a.Dp + f]; }
+        }
+    }
+    float lw_reg = 0.0f;
+    float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
+    for (int s = lane; s < k; s += 64) {
+        const int r = b * k + s;
+        const float px = src.px(a, s, r);
+        float lw = a.coef[0] * px;
+#pragma unroll
+        for (int t = 1; t < 5; ++t)
+            if (a.term[t]) lw += a.coef[t] * src.term(a, t, s, r);
+        a.logw[r] = lw;
+        lw_reg = lw;
+        m = fmaxf(m, lw);
+        sum_lw += lw;
+        sum_px += px;
+        if (a.term[1]) sum_t1 += src.term(a, 1, s, r);
+        if (a.term[2]) sum_t2 += src.term(a, 2, s, r);
+    }
+    m = wave_max(m); sum_lw = wave_sum(sum_lw); sum_px = wave_sum(sum_px); sum_t1 = wave_sum(sum_t1); sum_t2 = wave_sum(sum_t2);
+    float se = 0.0f;
+    for (int s = lane; s < k; s += 64) se += __expf((single ? lw_reg : a.logw[b * k + s]) - m);
+    se = wave_sum(se);
+    const float inv_se = 1.0f / se;
+    const float invB = 1.0f / (float)a.B, invkB = invB / (float)k;
+    float eq14 = 0.0f, dreg = 0.0f;
+    for (int s = lane; s < k; s += 64) {
+        const int r = b * k + s;
+        const float lw = single ? lw_reg : a.logw[r];
+        const float wn = __expf(lw - m) * inv_se;       // iwae1.py:128-131 == softmax over k (:137)
+        eq14 += wn * lw;
+        a.wn[r] = wn;
+        float G;                                         // dLoss/dlog_w, loss = -objective (iwae1.py:157)
+        float4 cf = make_float4(1.0f, 0.0f, 0.0f, 0.0f); // (ca, cz, cq, cs) for latent_bwd_kernel
+        if (a.objective == OBJ_VAE_ELBO) {
+            G = -invkB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
+        } else if (a.objective == OBJ_VAE_ELBO_KL) {
+            G = -invkB;
+        } else if (a.objective == OBJ_DREG) {            // tasks/task02.py:61-76,95-96
+            G = -wn * invB;
+            const float c2 = wn * wn * invB;
+            cf.x = wn; cf.y = c2; cf.z = -c2;
+        } else {                                         // iwae_elbo, iwae_eq14 (same gradient, SURVEY 3.3)
+            G = -wn * invB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
+        }
+        if (a.lq_dreg) dreg += wn * wn * (src.term(a, 1, s, r) + src.px_total(a, s, r) - src.lq_dreg(a, s, r));   // tasks/task02.py:70-73
+        a.gx[r] = G;
+        a.cf[r] = cf;
+    }
+    eq14 = wave_sum(eq14); dreg = wave_sum(dreg);
+    // KL(q(z|x) || N(0,1)) per image (iwae1.py:116), TFP closed form
+    float kl = 0.0f;
+    if (a.head) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (lane + 64 * i < a.D) {
+                const float ls = __logf(ksg[i]);
+                kl += 0.5f * kmu[i] * kmu[i] + 0.5f * expm1f(2.0f * ls) - ls;
+            }
+        }
+        for (int f = lane + 128; f < a.D; f += 64) {      // (latent widths beyond 128)
+            const float mu = a.head[(size_t)b * a.ldH + f], sg = a.head[(size_t)b * a.ldH + a.Dp + f];
+            const float ls = __logf(sg);
+            kl += 0.5f * mu * mu + 0.5f * expm1f(2.0f * ls) - ls;
+        }
+        kl = wave_sum(kl);
+    }
+    if (lane == 0) {
+        float* pb = a.per_b;
+        const int B = a.B;
+        pb[PB_LME * B + b] = m + __logf(se / (float)k);          // utils.py:6-8
+        pb[PB_MEAN * B + b] = sum_lw / (float)k;
+        pb[PB_EQ14 * B + b] = eq14;
+        pb[PB_KL * B + b] = kl;
+        pb[PB_PX * B + b] = sum_px / (float)k;
+        pb[PB_T1 * B + b] = sum_t1 / (float)k;
+        pb[PB_T2 * B + b] = sum_t2 / (float)k;
+        pb[PB_DREG * B + b] = dreg;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // bern_pipe_kernel: the Bernoulli forward (decoder output layer + log p(x|z), iwae1.py:74-75,83,111) at large row counts,
 // software-pipelined INSIDE each wave.  dense_kernel<EPI_BERN> runs "MFMAs of a 64-pixel group, then its epilogue": the
@@ -1123,6 +1260,12 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
             lq2 += __shfl_xor(lq2, 16); lq2 += __shfl_xor(lq2, 32);
             if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; if (a.zlq_dreg) a.zlq_dreg[row] = lq2; }
+            if constexpr (QW) {      // (kept in LDS for the in-kernel lse_image at the end: an area nothing else touches)
+                if (a.lse_on && q == 0 && storer) {
+                    float* lz = (float*)(smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * KTC * 1024);
+                    lz[tile * 16 + rho] = lp; lz[208 + tile * 16 + rho] = lq; lz[416 + tile * 16 + rho] = lq2;
+                }
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -1421,9 +1564,31 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         if (qw >= 0 && q == 0) part[qw * 16 + rho] = v;
         __syncthreads();
         if (qw == 0) v = part[rho] + part[16 + rho] + part[32 + rho] + part[48 + rho];
-        if (qw > 0) return;
+        if (qw > 0 && !(PRE && a.lse_on)) return;
     }
-    if (q == 0 && valid) a.lpxz[row] = v;
+    if (q == 0 && valid && storer) a.lpxz[row] = v;
+    if constexpr (QW && PRE) {
+        // k divides the workgroup's 200 rows: they are whole images (200 / k of them) -- wave w does for image w what lse_kernel would
+        // (same function, same order of operations: bitwise the same results), with the terms this kernel made coming from LDS
+        if (a.lse_on) {
+            float* lz = (float*)(smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * KTC * 1024);
+            if (q == 0 && storer) lz[624 + tile * 16 + rho] = v;
+            __syncthreads();
+            const int nimg = ROWS / a.k, b = blockIdx.x * nimg + wave;
+            if (wave < nimg && b < a.B) {
+                struct Src {
+                    const float* lz; int l0; bool made_z, made_lqd;
+                    __device__ __forceinline__ float px(const LseArgs&, int s, int) const { return lz[624 + l0 + s]; }
+                    __device__ __forceinline__ float px_total(const LseArgs&, int s, int) const { return lz[624 + l0 + s]; }
+                    __device__ __forceinline__ float term(const LseArgs& la, int t, int s, int r) const {
+                        return (made_z && t == 1) ? lz[l0 + s] : (made_z && t == 2) ? lz[208 + l0 + s] : la.term[t][r];
+                    }
+                    __device__ __forceinline__ float lq_dreg(const LseArgs& la, int s, int r) const { return made_lqd ? lz[416 + l0 + s] : la.lq_dreg[r]; }
+                };
+                lse_image(a.lse, b, lane, Src{lz, wave * a.k, a.zhead != nullptr, a.zhead != nullptr && a.zlq_dreg != nullptr});
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -3386,121 +3551,12 @@ __global__ __launch_bounds__(256) void gauss_lp_kernel(GaussLpArgs a) {
     if (q == 0 && valid) a.out[row] = lp;
 }
 
-// one wave per image b: log_w over k, logmeanexp / softmax / objective gradients (iwae1.py:113-139)
+// one wave per image b
 __global__ void lse_kernel(LseArgs a) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= a.B) return;
-    const int k = a.k;
-    const bool single = k <= 64;          // one sample per lane: log_w stays in a register between the passes
-    // the image's head (for the KL term at the end): requested first, so that its round trip runs beside the log_w terms' instead of
-    // behind the whole kernel
-    float kmu[2] = {0.0f, 0.0f}, ksg[2] = {1.0f, 1.0f};
-    if (a.head) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = lane + 64 * i;
-            if (f < a.D) { kmu[i] = a.head[(size_t)b * a.ldH + f]; ksg[i] = a.head[(size_t)b * a.ldH + a.Dp + f]; }
-        }
-    }
-    float lw_reg = 0.0f;
-    float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
-    for (int s = lane; s < k; s += 64) {
-        const int r = b * k + s;
-        float px = a.term[0][r];
-        if (a.n_px_part > 1) {      // log p(x|z) as partial sums over pixel groups (small row counts): fixed order
-            // (all partials requested at once: as a loop of dependent adds each load waited for the one before it -- 13 L2 round
-            // trips, most of this kernel's 10 us at B = 20)
-            float part[16];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) part[i] = (i < a.n_px_part) ? a.term[0][(size_t)i * a.px_stride + r] : 0.0f;
-#pragma unroll
-            for (int i = 1; i < 16; ++i) px += part[i];
-            for (int i = 16; i < a.n_px_part; ++i) px += a.term[0][(size_t)i * a.px_stride + r];
-            a.term0_out[r] = px;
-        }
-        float lw = a.coef[0] * px;
-#pragma unroll
-        for (int t = 1; t < 5; ++t)
-            if (a.term[t]) lw += a.coef[t] * a.term[t][r];
-        a.logw[r] = lw;
-        lw_reg = lw;
-        m = fmaxf(m, lw);
-        sum_lw += lw;
-        sum_px += px;
-        if (a.term[1]) sum_t1 += a.term[1][r];
-        if (a.term[2]) sum_t2 += a.term[2][r];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        m = fmaxf(m, __shfl_xor(m, o));
-        sum_lw += __shfl_xor(sum_lw, o);
-        sum_px += __shfl_xor(sum_px, o);
-        sum_t1 += __shfl_xor(sum_t1, o);
-        sum_t2 += __shfl_xor(sum_t2, o);
-    }
-    float se = 0.0f;
-    for (int s = lane; s < k; s += 64) se += __expf((single ? lw_reg : a.logw[b * k + s]) - m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
-    const float inv_se = 1.0f / se;
-    const float invB = 1.0f / (float)a.B, invkB = invB / (float)k;
-    float eq14 = 0.0f, dreg = 0.0f;
-    for (int s = lane; s < k; s += 64) {
-        const int r = b * k + s;
-        const float lw = single ? lw_reg : a.logw[r];
-        const float wn = __expf(lw - m) * inv_se;       // iwae1.py:128-131 == softmax over k (:137)
-        eq14 += wn * lw;
-        a.wn[r] = wn;
-        float G;                                         // dLoss/dlog_w, loss = -objective (iwae1.py:157)
-        float4 cf = make_float4(1.0f, 0.0f, 0.0f, 0.0f); // (ca, cz, cq, cs) for latent_bwd_kernel
-        if (a.objective == OBJ_VAE_ELBO) {
-            G = -invkB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
-        } else if (a.objective == OBJ_VAE_ELBO_KL) {
-            G = -invkB;
-        } else if (a.objective == OBJ_DREG) {            // tasks/task02.py:61-76,95-96
-            G = -wn * invB;
-            const float c2 = wn * wn * invB;
-            cf.x = wn; cf.y = c2; cf.z = -c2;
-        } else {                                         // iwae_elbo, iwae_eq14 (same gradient, SURVEY 3.3)
-            G = -wn * invB; cf.y = -G * a.beta * a.cz_on; cf.w = G * a.beta;
-        }
-        if (a.lq_dreg) dreg += wn * wn * (a.term[1][r] + a.term0_out[r] - a.lq_dreg[r]);   // tasks/task02.py:70-73 (term0_out: total log p(x|z))
-        a.gx[r] = G;
-        a.cf[r] = cf;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { eq14 += __shfl_xor(eq14, o); dreg += __shfl_xor(dreg, o); }
-    // KL(q(z|x) || N(0,1)) per image (iwae1.py:116), TFP closed form
-    float kl = 0.0f;
-    if (a.head) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (lane + 64 * i < a.D) {
-                const float ls = __logf(ksg[i]);
-                kl += 0.5f * kmu[i] * kmu[i] + 0.5f * expm1f(2.0f * ls) - ls;
-            }
-        }
-        for (int f = lane + 128; f < a.D; f += 64) {      // (latent widths beyond 128)
-            const float mu = a.head[(size_t)b * a.ldH + f], sg = a.head[(size_t)b * a.ldH + a.Dp + f];
-            const float ls = __logf(sg);
-            kl += 0.5f * mu * mu + 0.5f * expm1f(2.0f * ls) - ls;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) kl += __shfl_xor(kl, o);
-    }
-    if (lane == 0) {
-        float* pb = a.per_b;
-        const int B = a.B;
-        pb[PB_LME * B + b] = m + __logf(se / (float)k);          // utils.py:6-8
-        pb[PB_MEAN * B + b] = sum_lw / (float)k;
-        pb[PB_EQ14 * B + b] = eq14;
-        pb[PB_KL * B + b] = kl;
-        pb[PB_PX * B + b] = sum_px / (float)k;
-        pb[PB_T1 * B + b] = sum_t1 / (float)k;
-        pb[PB_T2 * B + b] = sum_t2 / (float)k;
-        pb[PB_DREG * B + b] = dreg;
-    }
+    lse_image(a, b, lane, LseGlobalSrc{});
 }
 
 // Batch means of the per-image values (the scalar entries of the reference's result dict), one 256-thread block.
@@ -4017,13 +4073,19 @@ bool bern_pipe_ok(const DenseArgs& a) {
            (126 + a.k) / a.k + 1 <= BERN_XIMG_MAX && (a.Np32 >> 5) >= 2 && (a.Np32 >> 5) <= 2 * a.MG &&
            2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128 <= 80 * 1024;
 }
+// the decoder kernel can finish its images' log-mean-exp itself: 16-wave / 200-row shape with the whole decoder inside, k a divisor of 200 with
+// at most 16 images per workgroup (k = 20, 25, 40, 50, 100, 200), terms 1 and 2 the ones the kernel makes when it samples z itself
+bool bern_lse_ok(const DenseArgs& a) {
+    return bern_pipe_ok(a) && a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8 && a.k >= 13 && 200 % a.k == 0 &&
+           (!a.zhead || (a.lse.term[1] == a.zlp && a.lse.term[2] == a.zlq && (!a.lse.lq_dreg || a.lse.lq_dreg == a.zlq_dreg))) && a.lse.n_px_part <= 1;
+}
 void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     dim3 grid((a.M + 127) / 128, (a.MG + a.mg_per_block - 1) / a.mg_per_block);
     const size_t lds = 2 * DENSE_UNIT;
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
         if (a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8) {       // 16-wave / 200-row shape (see QW)
-            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024;
+            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024 + 4096;      // (last 4 KiB: the rows' terms for the in-kernel lse_image)
             if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
             else LAUNCH_EV((bern_pipe_kernel<7, false, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
         } else if (a.pre_img1) {       // the whole decoder in one launch

@@ -167,6 +167,7 @@ struct iwae_model {
     // lse_kernel's outputs once more, written by the copy of it that runs on the side stream (see forward_impl): the output layer's
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
+    bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
     MlpWs wdec1;
@@ -849,6 +850,42 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         }
     }
 
+    // log_w / log-mean-exp arguments (lse_kernel, or the decoder kernel where it does that itself); allocates the outputs
+    LseArgs la;
+    auto lse_args = [&](LseArgs& a) -> int {
+        memset(&a, 0, sizeof(a));
+        CHK(ensure(m->logw, (size_t)Mp * 4, st));
+        CHK(ensure(m->wn, (size_t)Mp * 4, st));
+        {   // the row weights are also read 64 at a time by the output layer's weight gradient: pad rows must stay finite
+            const void* before = m->gx.p;
+            CHK(ensure(m->gx, (size_t)Mp * 4, st));
+            if (m->gx.p != before) HIPCHK(hipMemsetAsync(m->gx.p, 0, m->gx.cap, st));
+        }
+        CHK(ensure(m->cf, (size_t)Mp * 16, st));
+        CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
+        if (!two) {
+            a.term[0] = lpxz; a.coef[0] = 1.f;
+            a.term[1] = t1; a.coef[1] = beta;
+            a.term[2] = t2; a.coef[2] = -beta;
+            a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
+            a.cz_on = 1.f;
+        } else {
+            a.term[0] = lpxz; a.coef[0] = 1.f;    // iwae2.py:128 (beta unused there)
+            a.term[1] = t1; a.coef[1] = 1.f;
+            a.term[2] = t2; a.coef[2] = 1.f;
+            a.term[3] = t3; a.coef[3] = -1.f;
+            a.term[4] = t4; a.coef[4] = -1.f;
+            a.head = nullptr;
+            a.cz_on = 0.f;
+        }
+        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
+        a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
+        a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
+        a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
+        a.n_px_part = 1; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
+        return IWAE_OK;
+    };
+
     // ---- decoder + Bernoulli log-likelihood (iwae1.py:81-83,111)
     MlpWs& w = m->wdec1;
     const int Hp = m->dec1[0].Np32;
@@ -943,14 +980,25 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             }
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
+            m->early_wout = bwd && m->s_mode && m->allow_early_wout;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
+            // Round 3: where the decoder kernel's workgroups own whole images (16-wave / 200-row shape, k a divisor of 200) it also does
+            // lse_kernel's work for them -- the backward pass starts right behind it: one launch (7 us) and one dispatch gap (6 us) less
+            // on the loop that sets the step, and no second lse_kernel on the side stream.
+            CHK(lse_args(la));
+            m->lse_fused = false;
+            if (!out_done && fuse_dec && m->allow_lse_fused && !m->want_stamps) {
+                a.lse = la; a.lse_on = 1;
+                if (bern_lse_ok(a)) m->lse_fused = true;
+                else { a.lse_on = 0; memset(&a.lse, 0, sizeof(a.lse)); }
+            }
             // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights -- not out_bwd -- so the
             // side stream forks early.  Round 2: it forks behind THIS kernel (event on its dispatch packet) and runs its own copy of
             // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
             // a cross-stream hand-off takes now pass beside the main stream's lse_kernel, not behind it.
-            m->early_wout = bwd && m->s_mode && m->allow_early_wout;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
-            m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1 && !out_done;
-            if (!out_done) { ScopedTimer tm(m, T_DEC_FWD); if (m->lse_dup && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
-            if (m->lse_dup && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
+            m->lse_dup = m->early_wout && m->allow_lse_dup && m->px_parts == 1 && !out_done && !m->lse_fused;
+            const bool fork_here = m->lse_dup || (m->lse_fused && m->early_wout);
+            if (!out_done) { ScopedTimer tm(m, T_DEC_FWD); if (fork_here && !m->time_this) set_launch_stop_event(m->ev_lse); launch_dense(EPI_BERN, a, st); }
+            if (fork_here && m->time_this) HIPCHK(hipEventRecord(m->ev_lse, st));      // (a timed step: the timer's stop event sits behind the kernel)
         HIPCHK(hipGetLastError());
         // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
         // stream, idle until the backward pass forks -- enqueued behind the decoder kernel so that its dispatch does not delay that one
@@ -959,39 +1007,13 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     }
 
     // ---- log_w, log-mean-exp over k, objectives (iwae1.py:113-139)
-    CHK(ensure(m->logw, (size_t)Mp * 4, st));
-    CHK(ensure(m->wn, (size_t)Mp * 4, st));
-    {   // the row weights are also read 64 at a time by the output layer's weight gradient: pad rows must stay finite
-        const void* before = m->gx.p;
-        CHK(ensure(m->gx, (size_t)Mp * 4, st));
-        if (m->gx.p != before) HIPCHK(hipMemsetAsync(m->gx.p, 0, m->gx.cap, st));
-    }
-    CHK(ensure(m->cf, (size_t)Mp * 16, st));
-    CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
     {
-        LseArgs a;
-        memset(&a, 0, sizeof(a));
-        if (!two) {
-            a.term[0] = lpxz; a.coef[0] = 1.f;
-            a.term[1] = t1; a.coef[1] = beta;
-            a.term[2] = t2; a.coef[2] = -beta;
-            a.head = ptr<float>(m->wenc1.head); a.ldH = 2 * m->Dp[0]; a.D = m->D[0]; a.Dp = m->Dp[0];
-            a.cz_on = 1.f;
-        } else {
-            a.term[0] = lpxz; a.coef[0] = 1.f;    // iwae2.py:128 (beta unused there)
-            a.term[1] = t1; a.coef[1] = 1.f;
-            a.term[2] = t2; a.coef[2] = 1.f;
-            a.term[3] = t3; a.coef[3] = -1.f;
-            a.term[4] = t4; a.coef[4] = -1.f;
-            a.head = nullptr;
-            a.cz_on = 0.f;
-        }
-        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
-        a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
-        a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
-        a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
-        a.n_px_part = m->px_parts; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
+        LseArgs a = la;
         if (m->px_parts > 1) a.term[0] = ptr<float>(m->px_part);
+        a.n_px_part = m->px_parts;
+        if (m->lse_fused) {      // the decoder kernel did it; the side stream (output layer's weight gradient) forks behind that kernel
+            if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
+        } else {
         // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights lse_kernel leaves -- not
         // out_bwd -- so the side stream forks here (ev_lse on this kernel's dispatch packet), one kernel earlier, and the
         // gradient runs beside out_bwd (both read s)
@@ -1012,6 +1034,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a2.cf = ptr<float4>(m->cf2); a2.per_b = ptr<float>(m->per_b2);
             HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));
             launch_lse(a2, m->side);
+        }
         }
         // batch means: a training step folds them into its last kernel (backward_impl), a forward-only call takes them here
         if (!bwd) launch_scalars(ptr<float>(m->per_b), B, two ? 1.f : beta, m->d_scalars, st);
@@ -1114,7 +1137,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     hipStream_t sd = m->side;
-    if (m->early_wout && m->lse_dup) {}                                              // forked behind the decoder kernel already (forward_impl)
+    if (m->early_wout && (m->lse_dup || m->lse_fused)) {}                            // forked behind the decoder kernel already (forward_impl)
     else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
@@ -2049,6 +2072,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
     else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
+    else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32
     else if (n == "no_small_dec_bwd") m->small_dec_bwd = !on;         // per-pixel-group out_bwd + finish + two dX launches below 8 192 rows

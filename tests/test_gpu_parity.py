@@ -335,11 +335,48 @@ def test_kernel_variants_agree(gpu, B, k):
     e0, g0 = run({})
     for env in ({"out_recompute": 1}, {"dense_g1": 0}, {"no_zin": 1}, {"no_bern_pipe": 1},
                 {"no_dec_fused": 1}, {"no_block_fused": 1}, {"no_early_wout": 1}, {"bern_qw_force": 1},
-                {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
+                {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"no_lse_fused": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
                 {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
+
+
+@pytest.mark.parametrize("layers,B,k,obj", [(1, 170, 50, "iwae_elbo"), (1, 170, 50, "dreg"), (1, 170, 50, "vae_elbo_kl"), (1, 340, 25, "iwae_eq14"),
+                                            (1, 425, 20, "vae_elbo"), (1, 90, 100, "iwae_elbo"), (1, 45, 200, "dreg"), (2, 170, 50, "iwae_elbo")])
+def test_decoder_kernel_does_the_log_mean_exp_bitwise(gpu, layers, B, k, obj):
+    """Round 3: where the one-launch decoder kernel's workgroups own whole images (its 16-wave / 200-row shape, k a divisor of 200) it
+    also does lse_kernel's work for them (iwae1.py:113-139: log_w, logmeanexp, softmax weights, the per-image objective values) -- the
+    same device function on the same numbers, so everything downstream must be BITWISE what the separate launch gives: scalars, log_w,
+    every gradient.  k <= 64 (one sample per lane) and k > 64, a last workgroup holding fewer images than the others (8 500 rows =
+    42.5 x 200), host noise and the device's own (then the kernel's prior / posterior terms come from its LDS copies), DReG's second
+    log q, the 2-layer model (terms of the chain kernel, read from memory); and against the oracle for the iwae_elbo cases."""
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x, P, eps = MG.inputs(layers, nh, nl, 784, B, k, 4400 + B + k)
+
+    def run(opts, e):
+        m = _model(layers, nh, nl, options=dict(opts, bern_qw_force=1))
+        m.set_params(O.flatten_params(P))
+        m.set_step(3, 1)
+        r = m.forward_backward(x, k, 0.7 if obj == "vae_elbo_kl" else 1.0, obj, eps=e, want=("log_w",))
+        g = m.get_grads()
+        m.close()
+        return r, g
+
+    for e in (eps, None):
+        r0, g0 = run({"no_lse_fused": 1}, e)
+        r1, g1 = run({}, e)
+        np.testing.assert_array_equal(r1["log_w"], r0["log_w"])
+        for key in r0:
+            if np.isscalar(r0[key]) or getattr(r0[key], "ndim", 1) == 0:
+                assert r1[key] == r0[key] or (np.isnan(r1[key]) and np.isnan(r0[key])), (key, r1[key], r0[key])
+        np.testing.assert_array_equal(g1, g0)
+    if obj == "iwae_elbo":
+        res_e, g_e = (O.loss_grads_1layer(P, x, eps, 1.0, obj, rnd=O.bf16_round) if layers == 1 else
+                      O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, obj, rnd=O.bf16_round))
+        r1, g1 = run({}, eps)
+        assert abs(r1["iwae_elbo"] - res_e["iwae_elbo"]) < EMU_SCALAR_ATOL
+        assert max(_grad_rel_errors(g1, g_e)) < EMU_GRAD_REL
 
 
 @pytest.mark.parametrize("B,k,layers", [(170, 50, 1), (20, 5, 1), (24, 6, 2)])
