@@ -1179,6 +1179,39 @@ def test_training_reduces_loss_and_matches_oracle_trajectory(gpu):
     m.close()
 
 
+@pytest.mark.parametrize("layers,obj,steps", [(1, "iwae_elbo", 400), (1, "dreg", 150), (2, "iwae_elbo", 150)])
+def test_full_size_training_is_reproducible_run_to_run(gpu, layers, obj, steps):
+    """The full-size step (B = 1 024, k = 50: BASELINE configs[1..3]) runs its kernels on three streams and sums every weight gradient from
+    fp32 slabs in a fixed order -- no atomics anywhere -- so a training run on the device's own counter-based noise must be BITWISE
+    reproducible: two models stepped the same number of times from the same seed end on identical parameters and Adam moments.  A missing
+    order between two streams (a weight image rewritten while its last reader runs, a row weight read before it is written) shows up here
+    as a difference; NaNs or a rising loss would too."""
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    B, k = 1024, 50
+    x = O.synthetic_binarized(B, 11)
+
+    def run():
+        m = _model(layers, nh, nl)
+        first = m.train_step(x, k, 1.0, 1e-3, obj)["iwae_elbo"]
+        for _ in range(steps - 2):
+            m.train_step(x, k, 1.0, 1e-3, obj, scalars=False)
+        last = m.train_step(x, k, 1.0, 1e-3, obj)["iwae_elbo"]
+        p = m.get_params()
+        mo, ve, t = m.get_adam_state()
+        m.close()
+        return first, last, p, mo, ve, t
+
+    f0, l0, p0, mo0, ve0, t0 = run()
+    f1, l1, p1, mo1, ve1, t1 = run()
+    assert np.all(np.isfinite(p0)) and np.isfinite(l0)
+    assert l0 > f0 + 20.0, (f0, l0)          # (random init: about -545 nat; a few hundred steps on one batch gain > 100)
+    assert t0 == t1 == steps
+    assert f0 == f1 and l0 == l1
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(mo0, mo1)
+    np.testing.assert_array_equal(ve0, ve1)
+
+
 def test_bad_arguments_fail_loudly(gpu):
     from iwae_amd.native import NativeModel
     with pytest.raises(ValueError):
