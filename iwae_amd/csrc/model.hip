@@ -238,6 +238,8 @@ struct iwae_model {
     bool allow_dec_fused = true;     // IWAE_NO_DEC_FUSED=1: the two tanh layers of the decoder stay dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
+    int early_first2 = -1;      // 2-layer model: first reduce block behind the image encoder's layers (everything whose weight gradients run on the side streams)
+    bool allow_defer2 = true;   // option no_defer2
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
     int64_t timing_calls = 0;
@@ -397,6 +399,7 @@ int build_descs(iwae_model* m) {
     m->elem_blocks = blocks;
     m->reduce_blocks = rblocks;
     m->early_first = -1;
+    m->early_first2 = (m->cfg.n_layers == 2 && m->enc2[0].nsub >= 1) ? m->descs[m->enc2[0].sub[0]].rblock_begin : -1;      // (table order: enc1, enc2, dec2, dec1)
     const int d0 = m->dec1[0].sub[0];
     if (m->dec1[0].nsub == 1 && m->dec1[1].nsub == 1 && m->dec1[2].nsub == 1 && m->dec1[1].sub[0] == d0 + 1 &&
         m->dec1[2].sub[0] == d0 + 2 && d0 + 3 == (int)m->descs.size())
@@ -1270,6 +1273,12 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // Without split (iwae_forward_backward: gradient only, e.g. the one-message data-parallel step) the same early decoder
     // reduction runs on the side stream and the main stream joins it behind its own, shorter, encoder reduction.
     const bool early = !fuse && m->early_first > 0 && !two;
+    // 2-layer training step at large row counts (round 3): every layer behind the image encoder has its weight gradients on the side
+    // streams; their slab sums + Adam follow there (one launch on `tail`, which picks `side` up), instead of the main stream waiting for
+    // both side streams and then summing all 94 MB itself.  The next forward joins in front of z1 (join_side).  The image rewrite is safe
+    // for the same reason as in the 1-layer step: the side streams' weight gradients wait for the events behind the dX chains
+    // (ev_fork2, ev_blk), the last readers of those images.
+    const bool defer2 = fuse && two && m->allow_defer && m->allow_defer2 && m->early_first2 > 0 && m->chain2_bwd && m->early_wout && m->use_side2 && !split;
     m->split_offset = m->nparam;
     if (early) {
         set_launch_stop_event(m->ev_dec);
@@ -1277,6 +1286,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                             m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
+    } else if (defer2) {       // (the side streams' layers are summed and updated there, further down: nothing to join)
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -1287,10 +1297,20 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     {
         ScopedTimer tm_red(m, T_REDUCE);
-        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : defer2 ? m->early_first2 : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
                             alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     }
     if (early && !split) CHK(join_side(m));
+    if (defer2) {
+        if (m->tail != m->side) {
+            HIPCHK(hipEventRecord(m->ev_join2, m->side));
+            HIPCHK(hipStreamWaitEvent(m->tail, m->ev_join2, 0));
+        }
+        set_launch_stop_event(m->ev_dec);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first2, m->reduce_blocks - m->early_first2, m->grad, m->param, m->mom,
+                            m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
+        m->dec_pending = true;
+    }
     if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
         // (which wait for ev_fork2, i.e. for dX of d1, the last reader of the decoder's weight images -- without that order
@@ -2072,6 +2092,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
     else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
+    else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32

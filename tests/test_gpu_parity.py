@@ -477,6 +477,36 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu):
     assert t0 == t1 == 25
 
 
+def test_two_layer_deferred_update_is_bitwise_equivalent(gpu):
+    """2-layer training step at >= 8 192 rows (round 3): the layers behind the image encoder (q(z2|z1), p(z1|z2), the decoder) are summed
+    from their slabs and updated on the side stream that carries their weight gradients, joined by the next forward in front of z1 --
+    scheduling only: 12 steps on the device's noise land on exactly the parameters and Adam moments of the run whose main stream joins
+    both side streams and updates everything itself (option no_defer2), with and without reads between the steps."""
+    B, k, nh, nl = 170, 50, [200, 100], [100, 50]
+    x = O.synthetic_binarized(B, 12)
+    P = O.init_params(2, nh, nl, 4, x_mean=O.synthetic_pixel_means())
+
+    def run(env, poke):
+        m = _model(2, nh, nl, options=env)
+        m.set_params(O.flatten_params(P))
+        for t in range(12):
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=(t % 5 == 4))
+            if poke and t % 4 == 1:
+                m.get_params()
+        out = m.get_params().copy(), m.get_adam_state()
+        m.close()
+        return out
+
+    p0, (m0, v0, t0) = run({"no_defer2": 1}, False)
+    p1, (m1, v1, t1) = run({}, False)
+    p2, _ = run({}, True)
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0, p2)
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(v0, v1)
+    assert t0 == t1 == 12
+
+
 @pytest.mark.parametrize("B,k,obj,nh,nl,xd", [(6, 5, "iwae_elbo", 200, 100, 784), (9, 3, "vae_elbo_kl", 64, 20, 48), (170, 50, "iwae_elbo", 200, 100, 784)])
 def test_conditional_model_matches_oracle(gpu, B, k, obj, nh, nl, xd):
     """tasks/task05.py:101-168 (CIWAE): encoder on concat(x, onehot(y)), decoder on concat(z, onehot(y)); the condition
