@@ -282,7 +282,8 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
 // per_b != null: one extra block turns the per-image values into the batch means (scalars) of the step.
 // fuse_adam: the Adam update (grad_scale 1) + weight-image refresh of each element follows its slab sum in the same thread.
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st);
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st,
+                         int first_block2 = 0, int nblocks2 = 0);      // (optional second block range of the same launch)
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
                  float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block = 0);   // blocks [first_block, first_block + nblocks) of the elementwise grid

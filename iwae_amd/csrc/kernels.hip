@@ -3848,12 +3848,13 @@ struct MeansArgs { const float* per_b; int B; float beta; float* out; };     // 
 // The grid covers reduce blocks [first_block, first_block + n) of the layer table: the whole table, or -- single-GPU
 // train step -- the decoder's layers on the side stream and the rest on the main stream (see backward_impl).
 __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* layers, int nlayers, float* grad, float* param, float* mom,
-                                                           float* vel, AdamCoef c, MeansArgs mn, int first_block) {
+                                                           float* vel, AdamCoef c, MeansArgs mn, int first_block, int n1, int first_block2) {
     if (mn.per_b && blockIdx.x == gridDim.x - 1) {      // the one extra block of the grid: batch means of this step
         batch_means_block(mn.per_b, mn.B, mn.beta, mn.out);
         return;
     }
-    const int bid = (int)blockIdx.x + first_block;
+    // (two block ranges: the layers whose weight gradients ran on one side stream need not be neighbours in the table)
+    const int bid = (int)blockIdx.x < n1 ? (int)blockIdx.x + first_block : (int)blockIdx.x - n1 + first_block2;
     // block = 64 groups of 4 consecutive out-features (float4 loads) x 4 split groups; partial sums meet in LDS.
     // A group never straddles a weight row: rblock counts are computed per row of 4-float groups (Nout4 = ceil(Nout/4)).
     __shared__ float4 red[4][64];
@@ -4229,10 +4230,12 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(gauss_bwd_kernel, grid1((size_t)a.Mp * (a.Dp / 4), 256), dim3(256), 0, st, a);
 }
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
-                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st) {
+                         float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st,
+                         int first_block2, int nblocks2) {
     const AdamCoef c = {alpha, 1.0f, beta1, beta2, eps, fuse_adam};
     const MeansArgs mn = {per_b, B, beta, scalars};
-    LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block);
+    LAUNCH_EV(reduce_grads_kernel, dim3(nblocks + nblocks2 + (per_b ? 1 : 0)), dim3(256), 0, st, layers, nlayers, grad, param, mom, vel, c, mn, first_block, nblocks,
+              first_block2);
 }
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st) {
     hipLaunchKernelGGL(scalars_kernel, dim3(1), dim3(256), 0, st, per_b, B, beta, out);

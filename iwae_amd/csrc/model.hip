@@ -240,6 +240,8 @@ struct iwae_model {
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
     int early_first2 = -1;      // 2-layer model: first reduce block behind the image encoder's layers (everything whose weight gradients run on the side streams)
     bool allow_defer2 = true;   // option no_defer2
+    bool allow_defer2_split = true, dec2_pending = false;      // ... one deferred update per side stream (option no_defer2_split: one, on `tail`)
+    hipEvent_t ev_dec2 = nullptr;
     int early_first = -1;       // first reduce block of the decoder's layers when they are the tail of the table, else -1
     int timing = 0;            // 0 off, n > 0: time every n-th forward (event records cost a few us of stream bubble each)
     int64_t timing_calls = 0;
@@ -471,6 +473,10 @@ int attach_dense_stamps(iwae_model* m, int epi, DenseArgs& a) {
 
 // orders the main stream behind a deferred decoder update (and the noise prefetch in front of it) still on the side stream
 int join_side(iwae_model* m) {
+    if (m->dec2_pending) {      // (2-layer step: the first side stream's own deferred update)
+        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_dec2, 0));
+        m->dec2_pending = false;
+    }
     if (!m->dec_pending) return IWAE_OK;
     HIPCHK(hipStreamWaitEvent(m->stream, m->ev_dec, 0));
     m->dec_pending = false;
@@ -1301,7 +1307,19 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                             alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     }
     if (early && !split) CHK(join_side(m));
-    if (defer2) {
+    if (defer2 && m->tail == m->side2 && m->tail != m->side && m->allow_defer2_split && m->dec2[0].nsub == 1 && m->dec1[0].nsub == 1 && m->dec1[2].nsub == 1) {
+        // each side stream sums and updates the layers whose weight gradients IT carried, as soon as its own chain ends: the second one the
+        // encode block q(z2|z1) and the decoder's two tanh layers, the first one the decode block p(z1|z2) and the output layer (two block
+        // ranges per launch: table order enc2 | dec2 | dec1).  The next forward waits for both events (join_side).
+        const int b_dec2 = m->descs[m->dec2[0].sub[0]].rblock_begin, b_dec1 = m->descs[m->dec1[0].sub[0]].rblock_begin, b_out = m->descs[m->dec1[2].sub[0]].rblock_begin;
+        set_launch_stop_event(m->ev_dec);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first2, b_dec2 - m->early_first2, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1,
+                            m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side2, b_dec1, b_out - b_dec1);
+        set_launch_stop_event(m->ev_dec2);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), b_dec2, b_dec1 - b_dec2, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1, m->adam_b2,
+                            m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side, b_out, m->reduce_blocks - b_out);
+        m->dec_pending = true; m->dec2_pending = true;
+    } else if (defer2) {
         if (m->tail != m->side) {
             HIPCHK(hipEventRecord(m->ev_join2, m->side));
             HIPCHK(hipStreamWaitEvent(m->tail, m->ev_join2, 0));
@@ -1824,6 +1842,7 @@ int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     HIPCHK(hipEventCreateWithFlags(&m->ev_join2, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_dec, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&m->ev_blk, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_dec2, hipEventDisableTiming));
     if (cfg->n_layers == 1) {
         add_block(m, m->enc1, "enc", m->X + m->C, m->H[0], m->D[0], false);      // tasks/task05.py:113-118 when C > 0
         add_mlp3(m, m->dec1, "dec", m->D[0] + m->C, m->H[0], m->X);
@@ -1915,6 +1934,7 @@ void iwae_destroy(iwae_handle m) {
     if (m->ev_join2) (void)hipEventDestroy(m->ev_join2);
     if (m->ev_dec) (void)hipEventDestroy(m->ev_dec);
     if (m->ev_lse) (void)hipEventDestroy(m->ev_lse);
+    if (m->ev_dec2) (void)hipEventDestroy(m->ev_dec2);
     if (m->ev_blk) (void)hipEventDestroy(m->ev_blk);
     if (m->own_stream && m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -2092,6 +2112,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
     else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
+    else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it

@@ -479,7 +479,7 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu):
 
 def test_two_layer_deferred_update_is_bitwise_equivalent(gpu):
     """2-layer training step at >= 8 192 rows (round 3): the layers behind the image encoder (q(z2|z1), p(z1|z2), the decoder) are summed
-    from their slabs and updated on the side stream that carries their weight gradients, joined by the next forward in front of z1 --
+    from their slabs and updated on the side streams that carry their weight gradients (each stream its own layers), joined by the next forward in front of z1 --
     scheduling only: 12 steps on the device's noise land on exactly the parameters and Adam moments of the run whose main stream joins
     both side streams and updates everything itself (option no_defer2), with and without reads between the steps."""
     B, k, nh, nl = 170, 50, [200, 100], [100, 50]
@@ -500,8 +500,10 @@ def test_two_layer_deferred_update_is_bitwise_equivalent(gpu):
     p0, (m0, v0, t0) = run({"no_defer2": 1}, False)
     p1, (m1, v1, t1) = run({}, False)
     p2, _ = run({}, True)
+    p3, _ = run({"no_defer2_split": 1}, True)      # (one deferred update on the last side stream instead of one per side stream)
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(p0, p2)
+    np.testing.assert_array_equal(p0, p3)
     np.testing.assert_array_equal(m0, m1)
     np.testing.assert_array_equal(v0, v1)
     assert t0 == t1 == 12
