@@ -1832,7 +1832,7 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
 // Weights: the forward head image, then the three backward images, one 64-feature group per unit through two LDS buffers.
 // ---------------------------------------------------------------------------------
 template <int MODE, int KTIN, int KTH, int KTL>
-__global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
+__global__ __launch_bounds__(512, 4) void gblock_bwd_kernel(GBlockBwdArgs a) {
     static_assert(KTIN % 2 == 0 && KTL % 2 == 0 && KTIN <= 4 && KTH <= 4 && KTL <= 4, "64-feature latent groups, <= 128 features");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int NWV = 8, KTD = 2 * KTL;                    // k-steps of dhead
@@ -1871,12 +1871,15 @@ __global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
         hf2[ks] = valid ? v : make_uint4(0, 0, 0, 0);
     }
     int u = 0;
-    auto unit_mfma = [&](auto kt_tag, auto bias_tag, const uint4* bin, f32x4 (&acc)[4]) {
+    // One unit: wait + barrier | weight DMA of the next unit | `after` (the stores the PREVIOUS unit's epilogue left behind and the loads
+    // THIS unit's epilogue will want: a store or a load issued here has a whole unit before the next wait) | MFMAs.
+    auto unit_mfma = [&](auto kt_tag, auto bias_tag, const uint4* bin, f32x4 (&acc)[4], auto&& after) {
         constexpr int KTin = decltype(kt_tag)::value;
         const int buf = u & 1;
         wait_all_vmem();
         __syncthreads();
         if (u + 1 < NUNITS) dma_unit(u + 1, buf ^ 1);
+        after();
         const char* lb = smem + buf * UNIT + a_off;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1894,23 +1897,43 @@ __global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
     {
         f32x4 muh[NGL][4];
 #pragma unroll
-        for (int g = 0; g < NGL; ++g) unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, muh[g]);
+        for (int g = 0; g < NGL; ++g) unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, muh[g], [] {});
         const float* hz = MODE == 0 ? a.head1 + (size_t)b * a.ldH1 : nullptr;
 #pragma unroll
         for (int g = 0; g < NGL; ++g) {
             f32x4 sa[4];
-            unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, sa);
+            // the epilogue's operands (draws, the image's head or the decode block's dz2) are requested in front of the unit's MFMAs,
+            // and the fragments the previous group's epilogue made are stored there (not behind it, in front of the next wait)
+            float ev[4][4];
+            float4 xq[4], yq[4];
+            unit_mfma(std::integral_constant<int, KTH>{}, std::true_type{}, hf2, sa, [&] {
+                if (g > 0 && valid) {
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (2 * (g - 1) + p2) * 32 + q * 8) = dhf[2 * (g - 1) + p2];
+                        *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (KTL + 2 * (g - 1) + p2) * 32 + q * 8) = dhf[KTL + 2 * (g - 1) + p2];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int f0 = 64 * g + 16 * t + 4 * q;
+                    ev[t][0] = ev[t][1] = ev[t][2] = ev[t][3] = 0.0f;
+                    xq[t] = make_float4(0.f, 0.f, 0.f, 0.f); yq[t] = xq[t];
+                    if (f0 < a.D) {
+                        eps4(a.eps, b, sidx, rowc, f0 >> 2, a.D, ev[t]);
+                        if (MODE == 1) xq[t] = *(const float4*)(a.DZIN + (size_t)rowc * (32 * KTL) + f0);      // dz2 from the decode block
+                    }
+                }
+            });
             float dmv[4][4], dsv[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int f0 = 64 * g + 16 * t + 4 * q;
-                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), y4 = x4;
-                if (f0 < a.D) {
-                    eps4(a.eps, b, sidx, rowc, f0 >> 2, a.D, e);
-                    if (MODE == 0) { x4 = *(const float4*)(hz + f0); y4 = *(const float4*)(hz + 32 * KTL + f0); }     // mu1, sigma1 of the image
-                    else x4 = *(const float4*)(a.DZIN + (size_t)rowc * (32 * KTL) + f0);                               // dz2 from the decode block
-                }
+                const float* e = ev[t];
+                float4 x4 = xq[t], y4 = yq[t];
+                // (MODE 0: mu1, sigma1 of the row's image -- a few KB per workgroup, cache-resident -- are read here: 32 more registers
+                // held across the MFMAs spilled)
+                if (MODE == 0 && f0 < a.D) { x4 = *(const float4*)(hz + f0); y4 = *(const float4*)(hz + 32 * KTL + f0); }
                 const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
                 float dzd[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1943,19 +1966,22 @@ __global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
                                             pack2(dsv[2 * p2 + 1][0], dsv[2 * p2 + 1][1]), pack2(dsv[2 * p2 + 1][2], dsv[2 * p2 + 1][3]));
                 dhf[2 * g + p2] = valid ? fm : make_uint4(0, 0, 0, 0);
                 dhf[KTL + 2 * g + p2] = valid ? fs : make_uint4(0, 0, 0, 0);
-                if (valid) {
-                    *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (2 * g + p2) * 32 + q * 8) = fm;
-                    *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (KTL + 2 * g + p2) * 32 + q * 8) = fs;
-                }
             }
         }
     }
     // a dX product with the tanh' of the stored activation: dout = (din W^T) * (1 - act^2)
-    auto dx_layer = [&](auto kt_tag, const uint4* din, const uint4* act, uint4 (&dout)[KTH], uint16_t* Dst) {
+    // (stores deferred by one unit: `first` = what the unit in front of this layer left behind; this layer's last group is left to the caller)
+    auto store_frags = [&](uint16_t* Dst, const uint4* f, int mg) {
+        if (!valid) return;
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+            if (2 * mg + p2 < KTH) *(uint4*)(Dst + (size_t)row * (32 * KTH) + (2 * mg + p2) * 32 + q * 8) = f[2 * mg + p2];
+    };
+    auto dx_layer = [&](auto kt_tag, const uint4* din, const uint4* act, uint4 (&dout)[KTH], uint16_t* Dst, auto&& first) {
 #pragma unroll
         for (int mg = 0; mg < MGH; ++mg) {
             f32x4 acc[4];
-            unit_mfma(kt_tag, std::false_type{}, din, acc);
+            unit_mfma(kt_tag, std::false_type{}, din, acc, [&] { if (mg == 0) first(); else store_frags(Dst, dout, mg - 1); });
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 const int kso = 2 * mg + p2;
@@ -1965,27 +1991,45 @@ __global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
                     for (int j = 0; j < 8; ++j) { const float y = bf_at(act[kso], j); v[j] = acc[2 * p2 + (j >> 2)][j & 3] * (1.0f - y * y); }
                     const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
                     dout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
-                    if (valid) *(uint4*)(Dst + (size_t)row * (32 * KTH) + kso * 32 + q * 8) = frag;
                 }
             }
         }
     };
     // ---- B. d2 = (dhead Wh^T)(1 - h2^2)
-    uint4 d2f[KTH];
-    dx_layer(std::integral_constant<int, KTD>{}, dhf, hf2, d2f, a.D2P);
-    // ---- C. d1 = (d2 W2^T)(1 - h1^2)
-    uint4 hf1[KTH], d1f[KTH];
+    uint4 d2f[KTH], hf1[KTH], d1f[KTH];
+    dx_layer(std::integral_constant<int, KTD>{}, dhf, hf2, d2f, a.D2P, [&] {
+        if (valid) {       // the last head group's fragments
 #pragma unroll
-    for (int ks = 0; ks < KTH; ++ks) {
-        const uint4 v = *(const uint4*)(a.H1 + (size_t)rowc * (32 * KTH) + ks * 32 + q * 8);
-        hf1[ks] = valid ? v : make_uint4(0, 0, 0, 0);
-    }
-    dx_layer(std::integral_constant<int, KTH>{}, d2f, hf1, d1f, a.D1P);
+            for (int p2 = 0; p2 < 2; ++p2) {
+                *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (2 * (NGL - 1) + p2) * 32 + q * 8) = dhf[2 * (NGL - 1) + p2];
+                *(uint4*)(a.DHP + (size_t)row * (32 * KTD) + (KTL + 2 * (NGL - 1) + p2) * 32 + q * 8) = dhf[KTL + 2 * (NGL - 1) + p2];
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KTH; ++ks) {      // h1 for the layer after this one: requested two units ahead
+            const uint4 v = *(const uint4*)(a.H1 + (size_t)rowc * (32 * KTH) + ks * 32 + q * 8);
+            hf1[ks] = valid ? v : make_uint4(0, 0, 0, 0);
+        }
+    });
+    // ---- C. d1 = (d2 W2^T)(1 - h1^2)
+    dx_layer(std::integral_constant<int, KTH>{}, d2f, hf1, d1f, a.D1P, [&] { store_frags(a.D2P, d2f, MGH - 1); });
     // ---- D. gradient of the block's input: dz = d1 W1^T
 #pragma unroll
     for (int g = 0; g < NGI; ++g) {
         f32x4 acc[4];
-        unit_mfma(std::integral_constant<int, KTH>{}, std::false_type{}, d1f, acc);
+        float4 ddq[4];
+        uint2 drq[4];
+        unit_mfma(std::integral_constant<int, KTH>{}, std::false_type{}, d1f, acc, [&] {
+            if (g == 0) store_frags(a.D1P, d1f, MGH - 1);
+            if (MODE == 1) {      // the other two terms of dz1, requested in front of the MFMAs
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int f0 = 64 * g + 16 * t + 4 * q;
+                    ddq[t] = *(const float4*)(a.DZDEC + (size_t)rowc * a.ldDZDEC + f0);
+                    drq[t] = *(const uint2*)(a.DZD + (size_t)rowc * (32 * KTIN) + f0);
+                }
+            }
+        });
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int f0 = 64 * g + 16 * t + 4 * q;
@@ -1993,8 +2037,8 @@ __global__ __launch_bounds__(512, 2) void gblock_bwd_kernel(GBlockBwdArgs a) {
             if (MODE == 0) {
                 *(float4*)(a.DZ2 + (size_t)row * (32 * KTIN) + f0) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
             } else {       // dz1 = decoder term + direct p(z1|z2) term + this path through q(z2|z1)
-                const float4 dd = *(const float4*)(a.DZDEC + (size_t)row * a.ldDZDEC + f0);
-                const uint2 dr = *(const uint2*)(a.DZD + (size_t)row * (32 * KTIN) + f0);
+                const float4 dd = ddq[t];
+                const uint2 dr = drq[t];
                 *(uint2*)(a.DZOUT + (size_t)row * (32 * KTIN) + f0) =
                     make_uint2(pack2(acc[t][0] + dd.x + bflo(dr.x), acc[t][1] + dd.y + bfhi(dr.x)), pack2(acc[t][2] + dd.z + bflo(dr.y), acc[t][3] + dd.w + bfhi(dr.y)));
             }
