@@ -363,6 +363,18 @@ def test_decoder_kernel_does_the_log_mean_exp_bitwise(gpu, layers, B, k, obj):
         m.close()
         return r, g
 
+    def run_fwd(opts):      # val_step: forward only (z from the sampling kernel, the kernel's terms read from memory; DReG's value reported too)
+        m = _model(layers, nh, nl, options=dict(opts, bern_qw_force=1))
+        m.set_params(O.flatten_params(P))
+        m.set_step(3, 1)
+        r = m.forward(x, k, 1.0, eps=eps)
+        m.close()
+        return r
+
+    f0, f1 = run_fwd({"no_lse_fused": 1}), run_fwd({})
+    for key in f0:
+        if np.isscalar(f0[key]) or getattr(f0[key], "ndim", 1) == 0:
+            assert f1[key] == f0[key] or (np.isnan(f1[key]) and np.isnan(f0[key])), ("forward", key, f1[key], f0[key])
     for e in (eps, None):
         r0, g0 = run({"no_lse_fused": 1}, e)
         r1, g1 = run({}, e)
