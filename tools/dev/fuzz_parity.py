@@ -1,5 +1,5 @@
 """Developer script (GPU box): random shapes through iwae_forward_backward against the rounding-aware oracle.
-usage: python tools/dev/fuzz_parity.py [n_cases] [seed]"""
+usage: python tools/dev/fuzz_parity.py [n_cases] [seed]      env FUZZ_LARGE=1: >= 8 192 rows; FUZZ_FUSED=1: the 200-row decoder kernel with its in-kernel log-mean-exp"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden"))
@@ -18,14 +18,25 @@ for c in range(n_cases):
     if os.environ.get("FUZZ_LARGE"):      # row counts that take the large-row kernel choices (>= 8192 / >= 16384 rows)
         B, k = int(rng.integers(130, 420)), int(rng.integers(45, 70))
     xd = int(rng.choice([48, 100, 784, 1000]))
-    if layers == 1:
+    fused = bool(os.environ.get("FUZZ_FUSED"))
+    if fused:      # the decoder kernel's 16-wave / 200-row shape with its in-kernel log-mean-exp: k a divisor of 200, hidden width 200, >= 8 192 rows
+        k = int(rng.choice([20, 25, 40, 50, 100, 200]))
+        B = int(rng.integers(8192 // k + 1, 12000 // k + 2))
+        xd = int(rng.choice([784, 500, 300]))
+    if layers == 1 and fused:
+        nh, nl = 200, int(rng.choice([20, 50, 64, 100, 128]))
+        obj = str(rng.choice(objs1)); beta = float(rng.choice([1.0, 0.5]))
+    elif fused:
+        nh = [200, 100]; nl = [100, 50]
+        obj = str(rng.choice(["vae_elbo", "iwae_elbo", "iwae_eq14"])); beta = 1.0
+    elif layers == 1:
         nh, nl = int(rng.choice([16, 40, 64, 100, 128, 200, 256])), int(rng.choice([2, 4, 10, 32, 50, 100, 128]))
         obj = str(rng.choice(objs1)); beta = float(rng.choice([1.0, 0.5]))
     else:
         nh = [int(rng.choice([32, 64, 200])), int(rng.choice([16, 100]))]; nl = [int(rng.choice([4, 20, 100])), int(rng.choice([2, 50]))]
         obj = str(rng.choice(["vae_elbo", "iwae_elbo", "iwae_eq14"])); beta = 1.0
     x, P, eps = MG.inputs(layers, nh, nl, xd, B, k, 1000 + c)
-    m = NativeModel(layers, nh, nl, x_dim=xd, seed=1)
+    m = NativeModel(layers, nh, nl, x_dim=xd, seed=1, options={"bern_qw_force": 1} if fused else None)
     m.set_params(O.flatten_params(P))
     r = m.forward_backward(x, k, beta, obj, eps=eps)
     if layers == 1:
