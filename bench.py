@@ -92,7 +92,11 @@ def kernel_models(cfg):
                             match="dec_bwd_rows_kernel" if M <= 1024 else "dec_bwd_kernel"),
         "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, s weighted on its way through the loaders' registers, side stream)" if big else
                                "wgradp_kernel<8,4,4,4,true> (output-layer weight gradient, side stream)",
-                          bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true"),
+                          bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true",
+                          note=("NOT on the loop that sets the step: it runs on the side stream beside dec_bwd_kernel and the hidden layers' gradients with ~40 us of slack, on "
+                                "96 one-per-CU workgroups by choice (DESIGN.md section 3, item 49: 128 workgroups make THIS kernel faster -- 51 us alone instead of 65, 95 us in the "
+                                "step instead of 105 -- and the step slower, 0.218 vs 0.213 ms; the two kernels running side by side move 5.1 TB/s of measured traffic between them)"
+                                if big and cfg["layers"] == 1 else None)),
         "dx_hidden": dict(name="dense_kernel<EPI_DX,7> (dpre1 = (dpre2 V2^T) * (1 - g1^2))", bytes=M * 6 * H, flop=2 * M * H * H, match="dense_kernel<2, 7"),
         "dx_latent": dict(name="dense_kernel<EPI_F32,7> (dz = dpre1 V1^T, fp32)", bytes=M * (2 * H + 4 * D), flop=2 * M * H * D, match="dense_kernel<3, 7"),
         "wgrad_hidden": dict(name=("wgradws_kernel<false,4,4>" if big else "wgradp_kernel<8,4,4,4,false>") + " (dV2 = g1^T dpre2, second side stream)",
@@ -346,6 +350,7 @@ def run():
                 "avg_launch_us": round(dom_us, 2), "launches": dom_n,
                 "algorithmic_bytes_per_launch": int(km["bytes"]), "flop_per_launch": km["flop"],
                 "mfma_tflops": round(km["flop"] / (dom_us * 1e-6) / 1e12, 1) if dom_us > 0 else 0.0,
+                "note": km.get("note"),
                 # every timed kernel: average launch (us), algorithmic GB/s and its fraction of the HBM peak
                 "all_kernels": {k: {"us": round(v[0], 2), "GBps": round(models[k]["bytes"] / (v[0] * 1e-6) / 1e9, 1) if v[0] > 0 else 0.0,
                                     "hbm_frac": round(models[k]["bytes"] / (v[0] * 1e-6) / 1e9 / PEAK_HBM_GBS, 3) if v[0] > 0 else 0.0,
