@@ -11,6 +11,12 @@ namespace iwae {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
+// a fetched quad of op(B) times the row weights of its k index / indices (GemmF32Args.brow_scale)
+__device__ __forceinline__ float4 scale_b_quad(const GemmF32Args& a, float4 t, int gk, bool b_nfast) {
+    if (b_nfast) { const float w = a.brow_scale[gk]; return make_float4(t.x * w, t.y * w, t.z * w, t.w * w); }
+    return make_float4(t.x * a.brow_scale[gk], t.y * a.brow_scale[gk + 1], t.z * a.brow_scale[gk + 2], t.w * a.brow_scale[gk + 3]);
+}
+
 // C[M,N] (=|+=) epi(op(A)[M,K] op(B)[K,N] + bias): 64 x 64 tile per 256-thread workgroup, K walked in steps of 16 through
 // LDS; wave (wm, wn) owns a 32 x 32 sub-tile = 2 x 2 MFMA tiles.  Element (m,k) of A is A[m*sam + k*sak], (k,n) of B is
 // B[k*sbk + n*sbn]: plain, transposed-A (weight gradient X^T G) and transposed-B (dX = G W^T) products are the same kernel;
@@ -57,10 +63,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
         const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
         const int lim = b_nfast ? a.N - gn : k_end - gk;
         const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
-        if (outer_ok && lim >= 4 && a.bvec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok && lim >= 4 && a.bvec) { float4 t = *(const float4*)p; if (a.brow_scale) t = scale_b_quad(a, t, gk, b_nfast); return t; }
         if (outer_ok) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e];
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e] * (a.brow_scale ? a.brow_scale[b_nfast ? gk : gk + e] : 1.0f);
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
                 const int m = m0 + 32 * wm + 16 * i + 4 * q + r;
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + bias;
+                if (a.orow_scale) v *= a.orow_scale[m];
                 if (a.epi == GEMM_EPI_TANH) v = tanhf(v);                       // iwae1.py:31-32,72-73
                 else if (a.epi == GEMM_EPI_EXP) v = expf(v) + 1e-6f;             // iwae1.py:34,42
                 else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n]; v *= 1.0f - y * y; }
@@ -151,10 +158,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
         const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
         const int lim = b_nfast ? a.N - gn : k_end - gk;
         const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
-        if (outer_ok && lim >= 4 && a.bvec) { const float4 t = *(const float4*)p; return t; }
+        if (outer_ok && lim >= 4 && a.bvec) { float4 t = *(const float4*)p; if (a.brow_scale) t = scale_b_quad(a, t, gk, b_nfast); return t; }
         if (outer_ok) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e * (b_nfast ? a.sbn : a.sbk)];
+            for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e * (b_nfast ? a.sbn : a.sbk)] * (a.brow_scale ? a.brow_scale[b_nfast ? gk : gk + e] : 1.0f);
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
@@ -222,7 +229,14 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
                 for (int j = 0; j < 4; ++j) {
                     if (nok[j]) {
                         const float l = acc[i][j][r] + bias4[j];
-                        sum += xr[n0 + 64 * wn + 16 * j + r16] * l - (fmaxf(l, 0.0f) + log1pf(expf(-fabsf(l))));      // iwae1.py:111
+                        const float xv = xr[n0 + 64 * wn + 16 * j + r16];
+                        // e = exp(-|l|) once, for softplus(l) = max(l,0) + log(1 + e) and sigmoid(l) = (l >= 0 ? 1 : e) / (1 + e).  Hardware exp2 / log2
+                        // (1 ulp each): the absolute error of a term is <= 1e-7 (log(1 + e) loses RELATIVE accuracy only where e < 1e-7, i.e. where the
+                        // term itself is < 1e-7) against sums of O(100) -- the float32 parity tolerances (scalars 1e-5, gradients 1e-4 relative) are far above
+                        const float e = __expf(-fabsf(l)), ope = 1.0f + e;
+                        sum += xv * l - (fmaxf(l, 0.0f) + __logf(ope));      // iwae1.py:111
+                        // training step: s = x - sigmoid(l) stays where the logits would have gone
+                        if (a.C && m < a.M) a.C[(size_t)m * a.ldc + n0 + 64 * wn + 16 * j + r16] = xv - (l >= 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(ope);
                     }
                 }
                 sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);      // the 16 columns of a tile sit on lanes r16
@@ -243,6 +257,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
                 const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + bias;
+                if (a.orow_scale) v *= a.orow_scale[m];
                 if (a.epi == GEMM_EPI_TANH) v = tanhf(v);
                 else if (a.epi == GEMM_EPI_EXP) v = expf(v) + 1e-6f;
                 else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n]; v *= 1.0f - y * y; }
@@ -262,13 +277,15 @@ __global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slab
 }
 
 // partial column sums of G [M][ld] over row split blockIdx.y: part[y][n] (bias gradients), summed by reduce_slabs_f32_kernel
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* G, size_t ld, int M, int N, int rows_per_split, float* part) {
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* G, size_t ld, int M, int N, int rows_per_split, float* part, const float* rowscale) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
     float s = 0.0f;
-    if (n < N)
-        for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n];
+    if (n < N) {
+        if (rowscale) { for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n] * rowscale[r]; }
+        else for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n];
+    }
     red[g][threadIdx.x & 63] = s;
     __syncthreads();
     if (g == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
@@ -348,9 +365,9 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
 }
-void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st) {
+void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st, const float* rowscale) {
     const int rps = (M + nsplit - 1) / nsplit;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, st, G, ld, M, N, rps, part);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, st, G, ld, M, N, rps, part, rowscale);
 }
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st) {
     hipLaunchKernelGGL(bern_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, ld, x, X, M, k, lpxz);

@@ -310,11 +310,15 @@ struct GemmF32Args {
     // log p(x|z) = sum_n x_n l_n - softplus(l_n) per row in part[(2 * column tile + half) * part_stride + m]; lse_kernel adds them in fixed order
     const float* XB; int bern_k, bern_X;  // x [B][bern_X] float32 in {0,1}; row m belongs to image m / bern_k
     float* part; size_t part_stride;
+    // training step (round 3): GEMM_EPI_BERN with C != null also keeps s = x - sigmoid(l) there (the gradient of that sum wrt l; what the
+    // backward pass reads instead of logits), and its consumers take the row weight g_r on the fly instead of a pass that makes dl = g_r s:
+    const float* brow_scale;              // element (k,n) of op(B) is multiplied by brow_scale[k] as it is fetched (the weight gradient X^T (g_r s)), or null
+    const float* orow_scale;              // row m of the product is multiplied by orow_scale[m] in front of the epilogue (dX = g_r (s W^T) ...), or null
 };
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
-void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st);      // part [nsplit][N]
+void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st, const float* rowscale = nullptr);      // part [nsplit][N]; rows weighted by rowscale[r] if given
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st);
 void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st);
 void launch_sigmoid_f32(float* v, size_t n, hipStream_t st);

@@ -167,6 +167,7 @@ struct iwae_model {
     // lse_kernel's outputs once more, written by the copy of it that runs on the side stream (see forward_impl): the output layer's
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
+    bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
@@ -1431,11 +1432,12 @@ int adam_impl(iwae_model* m, float lr, float gscale) {
 // path with plain row-major float32 tensors and one generic MFMA GEMM (fp32_kernels.hip); the per-sample kernels that already
 // work in float32 (sampling + densities, lse_kernel, latent_bwd_kernel, gauss_*_kernel, Adam) are shared.
 int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
-             const float* bias, int epi, const float* ACT, long ldact, bool accumulate) {
+             const float* bias, int epi, const float* ACT, long ldact, bool accumulate, const float* brow_scale = nullptr, const float* orow_scale = nullptr) {
     GemmF32Args a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.epi = epi; a.ACT = ACT; a.ldact = ldact; a.accumulate = accumulate ? 1 : 0; a.kchunk = K; a.slab_stride = 0;
+    a.brow_scale = brow_scale; a.orow_scale = orow_scale;
     launch_gemm_f32(a, 1, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -1445,11 +1447,15 @@ int f32_fwd(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, int r
     return f32_gemm(m, X, ldx, 1, m->param + kl.offW, kl.Nout, 1, Y, ldy, rows, kl.Nout, kl.Kin, m->param + kl.offb, epi, nullptr, 0, false);
 }
 // DX (+)= (G W^T) * (1 - ACT^2)   (ACT = the stored tanh output of the layer below, or null)
-int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int rows, float* DX, long lddx, const float* ACT, long ldact, bool accumulate) {
-    return f32_gemm(m, G, ldg, 1, m->param + kl.offW, 1, kl.Nout, DX, lddx, rows, kl.Kin, kl.Nout, nullptr, ACT ? GEMM_EPI_DTANH : GEMM_EPI_NONE, ACT, ldact, accumulate);
+// (rowscale: row r of G counts with weight rowscale[r] -- applied to the product's rows, in front of the tanh' factor)
+int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int rows, float* DX, long lddx, const float* ACT, long ldact, bool accumulate,
+           const float* rowscale = nullptr) {
+    return f32_gemm(m, G, ldg, 1, m->param + kl.offW, 1, kl.Nout, DX, lddx, rows, kl.Kin, kl.Nout, nullptr, ACT ? GEMM_EPI_DTANH : GEMM_EPI_NONE, ACT, ldact, accumulate,
+                    nullptr, rowscale);
 }
 // grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
-int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows) {
+// (rowscale: G's row r is multiplied by rowscale[r] as it is fetched -- the values the separate g_r s pass used to store)
+int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr) {
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
     const int tiles = (kl.Kin > 64 && kl.Nout > 64) ? ((kl.Kin + 127) / 128) * ((kl.Nout + 127) / 128) : ((kl.Kin + 63) / 64) * ((kl.Nout + 63) / 64);
     const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (1024 + tiles - 1) / tiles));
@@ -1459,6 +1465,7 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     GemmF32Args a;
     memset(&a, 0, sizeof(a));
     a.A = X; a.sam = 1; a.sak = ldx; a.B = G; a.sbk = ldg; a.sbn = 1; a.M = kl.Kin; a.N = kl.Nout; a.K = rows;
+    a.brow_scale = rowscale;
     a.kchunk = (rows + nsplit - 1) / nsplit; a.kchunk = (a.kchunk + 15) / 16 * 16;
     const int ns = (rows + a.kchunk - 1) / a.kchunk;
     if (ns == 1) { a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; launch_gemm_f32(a, 1, m->stream); }
@@ -1467,7 +1474,7 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
         launch_gemm_f32(a, ns, m->stream);
         launch_reduce_slabs_f32(ptr<float>(m->f32.slab), nW, ns, nW, m->grad + kl.offW, m->stream);
     }
-    launch_colsum_f32(G, ldg, rows, kl.Nout, ns, ptr<float>(m->f32.bpart), m->stream);
+    launch_colsum_f32(G, ldg, rows, kl.Nout, ns, ptr<float>(m->f32.bpart), m->stream, rowscale);
     launch_reduce_slabs_f32(ptr<float>(m->f32.bpart), kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -1611,8 +1618,11 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     CHK(f32_fwd(m, *d2, ptr<float>(m->f32.g1), H, M, ptr<float>(m->f32.g2), H, GEMM_EPI_TANH));
     // forward-only calls at large row counts (the k = 5000 evaluator): log p(x|z) in the epilogue of the output layer's GEMM -- the float32
     // logits (1.6 GB per launch of 2^19 rows) are neither written nor read back; per 64-column half tile a partial sum that lse_kernel adds
-    const bool fuse_bern = !bwd && !(want && want->logits) && gemm_f32_takes_big(M, X, 1);
+    // Round 3, training step: the same epilogue also leaves s = x - sigmoid(l) where the logits would have gone -- the backward pass reads s and
+    // takes the row weight g_r inside its two consumers (f32_dw / f32_dx with rowscale) instead of a pass that rewrites 160 MB into dl = g_r s.
+    const bool fuse_bern = m->allow_f32_bern_fused && !(want && want->logits) && gemm_f32_takes_big(M, X, 1);
     m->px_parts = 1;
+    m->f32_keeps_s = false;
     if (fuse_bern) {
         m->px_parts = 2 * ((X + 127) / 128);
         CHK(ensure(m->px_part, (size_t)m->px_parts * Mp * 4, st));
@@ -1620,6 +1630,11 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         memset(&ga, 0, sizeof(ga));
         ga.A = ptr<float>(m->f32.g2); ga.sam = H; ga.sak = 1; ga.B = m->param + d3->offW; ga.sbk = d3->Nout; ga.sbn = 1; ga.M = M; ga.N = X; ga.K = H;
         ga.bias = m->param + d3->offb; ga.epi = GEMM_EPI_BERN; ga.kchunk = H;
+        if (bwd) {
+            CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
+            ga.C = ptr<float>(m->f32.logits); ga.ldc = X;
+            m->f32_keeps_s = true;
+        }
         ga.XB = xd; ga.bern_k = k; ga.bern_X = X; ga.part = ptr<float>(m->px_part); ga.part_stride = (size_t)Mp;
         launch_gemm_f32(ga, 1, st);
     } else {
@@ -1673,12 +1688,14 @@ int backward_f32(iwae_model* m, int objective) {
     const KerasLayer *d1 = &m->klayers[b_dec1], *d2 = d1 + 1, *d3 = d1 + 2;
     const int H = d1->Nout, D0 = m->D[0], Dp0 = m->Dp[0];
     float* dl = ptr<float>(m->f32.logits);
-    launch_dl_f32(dl, X, m->f32_x, X, M, k, ptr<float>(m->gx), st);        // dl = g_r (x - sigmoid(l)), in place
+    const float* rw = nullptr;      // the row weight g_r, where the forward pass kept s instead of the logits (forward_f32): taken by the two consumers
+    if (m->f32_keeps_s) rw = ptr<float>(m->gx);
+    else launch_dl_f32(dl, X, m->f32_x, X, M, k, ptr<float>(m->gx), st);        // dl = g_r (x - sigmoid(l)), in place
     CHK(ensure(m->f32.d2, (size_t)M * H * 4, st));
     CHK(ensure(m->f32.d1, (size_t)M * H * 4, st));
     CHK(ensure(m->wdec1.dz, (size_t)Mp * Dp0 * 4, st));
-    CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M));
-    CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false));
+    CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw));
+    CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false, rw));
     CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M));
     CHK(f32_dx(m, *d2, ptr<float>(m->f32.d2), H, M, ptr<float>(m->f32.d1), H, ptr<float>(m->f32.g1), H, false));
     CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M));
@@ -2118,6 +2135,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
+    else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32

@@ -918,6 +918,38 @@ def test_float32_mode_matches_exact_oracle(gpu, layers, B, k, obj, beta, nh, nl,
     m.close()
 
 
+@pytest.mark.parametrize("layers,B,k,obj", [(1, 200, 50, "iwae_elbo"), (1, 200, 50, "dreg"), (2, 192, 50, "iwae_elbo")])
+def test_float32_mode_fused_output_layer_matches_exact_oracle(gpu, layers, B, k, obj):
+    """float32 mode at >= 9 400 rows (round 3): the output layer's 128-tile GEMM takes log p(x|z) in its epilogue (per half tile partial sums,
+    added by lse_kernel in a fixed order) and, in a training step, leaves s = x - sigmoid(l) where the logits would have gone; the backward pass
+    takes the row weight g_r inside the weight-gradient GEMM's operand fetch and the dX GEMM's epilogue instead of a pass that makes
+    dl = g_r s.  Scalars and every gradient tensor against the exact float64 oracle at the float32 tolerances, and against the same mode with
+    the separate bern_f32 / dl_f32 passes (option no_f32_bern_fused)."""
+    from iwae_amd.native import NativeModel
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x, P, eps = MG.inputs(layers, nh, nl, 784, B, k, 640 + B + k)
+    res, g = (O.loss_grads_1layer(P, x, eps, 1.0, obj) if layers == 1 else O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, obj))
+    keys = ("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "iwae_elbo", "iwae_eq14")
+    out = []
+    for opts in ({}, {"no_f32_bern_fused": 1}):
+        m = NativeModel(layers, nh, nl, x_dim=784, seed=123, precision="fp32", options=opts)
+        m.set_params(O.flatten_params(P))
+        r = m.forward_backward(x, k, 1.0, obj, eps=eps)
+        for key in keys:
+            assert abs(r[key] - res[key]) <= F32_SCALAR_REL * abs(res[key]) + 2e-4, (opts, key, r[key], res[key])
+        flat = m.get_grads()
+        assert max(_grad_rel_errors(flat, g)) < F32_GRAD_REL, opts
+        r0 = m.forward(x, k, 1.0, eps=eps)          # (forward only: nothing is written but the partial sums)
+        for key in keys:
+            assert abs(r0[key] - r[key]) <= 1e-6 * abs(r[key]) + 1e-5
+        out.append((r, flat.astype(np.float64)))
+        m.close()
+    (r1, g1), (r2, g2) = out
+    for key in keys:
+        assert abs(r1[key] - r2[key]) <= 2e-6 * abs(r2[key])
+    assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-5
+
+
 def test_float32_mode_against_golden_fixtures(gpu):
     """The tiny fixtures' exact (float64) expectations, element by element, at SURVEY 8(c)'s float32 tolerances."""
     from iwae_amd.native import NativeModel
