@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e];
         }
+        if (a.Cones) {      // the row of ones behind the last row of op(A)
+            if (a_kfast) { if (gm == a.M) { for (int e = 0; e < 4; ++e) v[e] = (gk + e < k_end) ? 1.0f : 0.0f; } }
+            else if (gk < k_end) { for (int e = 0; e < 4; ++e) if (gm + e == a.M) v[e] = 1.0f; }
+        }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
     auto fetch_b = [&](int k0) -> float4 {
@@ -113,7 +117,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 32 * wm + 16 * i + 4 * q + r;
-                if (m >= a.M) continue;
+                if (m >= a.M) {
+                    if (a.Cones && m == a.M) a.Cones[(size_t)blockIdx.z * a.cones_stride + n] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bias;
                 if (a.orow_scale) v *= a.orow_scale[m];
                 if (a.epi == GEMM_EPI_TANH) v = tanh_f32(v);                    // iwae1.py:31-32,72-73
@@ -156,6 +163,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
         if (outer_ok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < lim) v[e] = p[e * (a_kfast ? a.sak : a.sam)];
+        }
+        if (a.Cones) {      // the row of ones behind the last row of op(A)
+            if (a_kfast) { if (gm == a.M) { for (int e = 0; e < 4; ++e) v[e] = (gk + e < k_end) ? 1.0f : 0.0f; } }
+            else if (gk < k_end) { for (int e = 0; e < 4; ++e) if (gm + e == a.M) v[e] = 1.0f; }
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
@@ -262,7 +273,10 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
-                if (m >= a.M) continue;
+                if (m >= a.M) {
+                    if (a.Cones && m == a.M) a.Cones[(size_t)blockIdx.z * a.cones_stride + n] = acc[i][j][r];
+                    continue;
+                }
                 float v = acc[i][j][r] + bias;
                 if (a.orow_scale) v *= a.orow_scale[m];
                 if (a.epi == GEMM_EPI_TANH) v = tanh_f32(v);
@@ -366,8 +380,9 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     // 128 x 128 tiles wherever both extents exceed one 64-tile (the per-sample layers, the weight gradients); the small kernel for the
     // rest (few images, narrow heads: a 128-tile would be mostly padding)
     // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
-    if (gemm_f32_takes_big(a.M, a.N, nsplit)) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (a.M + 127) / 128, nsplit), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (a.M + 63) / 64, nsplit), dim3(256), 0, st, a);
+    const int Mg = a.M + (a.Cones ? 1 : 0);      // (the row of ones)
+    if (gemm_f32_takes_big(a.M, a.N, nsplit)) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (Mg + 127) / 128, nsplit), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (Mg + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, stride, nsplit, n, out);

@@ -314,6 +314,9 @@ struct GemmF32Args {
     // backward pass reads instead of logits), and its consumers take the row weight g_r on the fly instead of a pass that makes dl = g_r s:
     const float* brow_scale;              // element (k,n) of op(B) is multiplied by brow_scale[k] as it is fetched (the weight gradient X^T (g_r s)), or null
     const float* orow_scale;              // row m of the product is multiplied by orow_scale[m] in front of the epilogue (dX = g_r (s W^T) ...), or null
+    // weight gradients: op(A) = X^T gets one more row m == M of ONES, whose product row -- the column sums of op(B), i.e. the bias gradient --
+    // goes to Cones[z * cones_stride + n] instead of C (round 3: no separate pass over G for the bias gradients)
+    float* Cones; size_t cones_stride;
 };
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);

@@ -167,6 +167,7 @@ struct iwae_model {
     // lse_kernel's outputs once more, written by the copy of it that runs on the side stream (see forward_impl): the output layer's
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
+    int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
     bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
@@ -1458,7 +1459,7 @@ int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int ro
 int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr) {
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
     const int tiles = (kl.Kin > 64 && kl.Nout > 64) ? ((kl.Kin + 127) / 128) * ((kl.Nout + 127) / 128) : ((kl.Kin + 63) / 64) * ((kl.Nout + 63) / 64);
-    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (1024 + tiles - 1) / tiles));
+    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (m->f32_dw_tiles + tiles - 1) / tiles));
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     CHK(ensure(m->f32.slab, nsplit * nW * 4, m->stream));
     CHK(ensure(m->f32.bpart, (size_t)nsplit * kl.Nout * 4, m->stream));
@@ -1468,14 +1469,16 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     a.brow_scale = rowscale;
     a.kchunk = (rows + nsplit - 1) / nsplit; a.kchunk = (a.kchunk + 15) / 16 * 16;
     const int ns = (rows + a.kchunk - 1) / a.kchunk;
-    if (ns == 1) { a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; launch_gemm_f32(a, 1, m->stream); }
-    else {
-        a.C = ptr<float>(m->f32.slab); a.ldc = kl.Nout; a.slab_stride = nW;
+    // the bias gradient = the column sums of (weighted) G = the product row of a row of ONES appended to X^T (GemmF32Args.Cones): no pass of its own
+    if (ns == 1) {
+        a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; a.Cones = m->grad + kl.offb; a.cones_stride = 0;
+        launch_gemm_f32(a, 1, m->stream);
+    } else {
+        a.C = ptr<float>(m->f32.slab); a.ldc = kl.Nout; a.slab_stride = nW; a.Cones = ptr<float>(m->f32.bpart); a.cones_stride = (size_t)kl.Nout;
         launch_gemm_f32(a, ns, m->stream);
         launch_reduce_slabs_f32(ptr<float>(m->f32.slab), nW, ns, nW, m->grad + kl.offW, m->stream);
+        launch_reduce_slabs_f32(ptr<float>(m->f32.bpart), kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
     }
-    launch_colsum_f32(G, ldg, rows, kl.Nout, ns, ptr<float>(m->f32.bpart), m->stream, rowscale);
-    launch_reduce_slabs_f32(ptr<float>(m->f32.bpart), kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -2135,6 +2138,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
+    else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
