@@ -137,25 +137,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
 // was 39 % busy) and the activations of the 784-wide layer are fetched 7 times instead of 13; the k-steps of 16 are double
 // buffered in LDS (one barrier per step), the next step's quads are in flight under this step's 64 MFMAs.  Same operand addressing
 // (element strides), same K split, same epilogues; bit-for-bit the same k-ordered fmaf chain per element.
+// TM x TN = MFMA tiles per wave (2 x 2 waves): <4, 4> is the 128 x 128 tile; <2, 7> = 64 x 224 and <7, 2> = 224 x 64 take the products in which a
+// 200-wide dimension would fill a 128-tile pair to 78 % (round 3: most products of the step).
+template <int TM, int TN, bool a_kfast, bool b_nfast>      // (a_kfast = op(A)'s k index is the unit-stride one, b_nfast = op(B)'s n index: compile-time, the position arithmetic folds)
 __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {      // <= 128 registers: four workgroups per CU (1 024 slots: the 800 workgroups of a 51 200 x 200 product are one round, not two)
-    __shared__ float sA[2][128][17];
-    __shared__ float sB[2][16][144];
+    constexpr int BM = 32 * TM, BN = 32 * TN, BNP = BN + 16;      // (BNP = 16 mod 32: a half wave's B reads of k and k + 1 fall into different banks)
+    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256, QM = BM / 4, QN = BN / 4;      // quads per thread and operand; quads per k row (m- / n-fast)
+    __shared__ float sA[2][BM][17];
+    __shared__ float sB[2][16][BNP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, q = lane >> 4;
-    f32x4v acc[4][4];
+    f32x4v acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
-    // two quads per thread and operand: quad u of the A tile is (m, k..k+3) with m = (tid >> 2) + 64u (k-fast) or (m..m+3, k) with
-    // k = (tid >> 5) + 8u (m-fast); the B tile likewise
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    // quad u of a thread: number qq = tid + 256 u of the tile's quads; k-fast: 4 quads per row (m = qq >> 2, k = 4 (qq & 3)); m-fast: QM quads per k
+    // (k = qq / QM, m = 4 (qq % QM)); the B tile likewise
+    auto a_pos = [&](int u, int& lm, int& lk) { const int qq = tid + 256 * u; if (a_kfast) { lm = qq >> 2; lk = (qq & 3) * 4; } else { lk = qq / QM; lm = (qq % QM) * 4; } return qq < BM * 4; };
+    auto b_pos = [&](int u, int& ln, int& lk) { const int qq = tid + 256 * u; if (b_nfast) { lk = qq / QN; ln = (qq % QN) * 4; } else { ln = qq >> 2; lk = (qq & 3) * 4; } return qq < BN * 4; };
     auto fetch_a = [&](int k0, int u) -> float4 {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int gm = m0 + (a_kfast ? (tid >> 2) + 64 * u : (tid & 31) * 4), gk = k0 + (a_kfast ? (tid & 3) * 4 : (tid >> 5) + 8 * u);
+        int lm, lk;
+        if (!a_pos(u, lm, lk)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gm = m0 + lm, gk = k0 + lk;
         const float* p = a.A + (size_t)gm * a.sam + (size_t)gk * a.sak;
         const int lim = a_kfast ? k_end - gk : a.M - gm;
         const bool outer_ok = a_kfast ? gm < a.M : gk < k_end;
@@ -172,7 +180,9 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
     };
     auto fetch_b = [&](int k0, int u) -> float4 {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int gn = n0 + (b_nfast ? (tid & 31) * 4 : (tid >> 2) + 64 * u), gk = k0 + (b_nfast ? (tid >> 5) + 8 * u : (tid & 3) * 4);
+        int ln, lk;
+        if (!b_pos(u, ln, lk)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gn = n0 + ln, gk = k0 + lk;
         const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
         const int lim = b_nfast ? a.N - gn : k_end - gk;
         const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
@@ -183,23 +193,34 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
-    auto stash = [&](int buf, const float4 (&ra)[2], const float4 (&rb)[2]) {
+    auto stash = [&](int buf, const float4 (&ra)[NA], const float4 (&rb)[NB]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const float av4[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w}, bv4[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+        for (int u = 0; u < NA; ++u) {
+            int lm, lk;
+            if (!a_pos(u, lm, lk)) continue;
+            const float av4[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (a_kfast) sA[buf][(tid >> 2) + 64 * u][(tid & 3) * 4 + e] = av4[e]; else sA[buf][(tid & 31) * 4 + e][(tid >> 5) + 8 * u] = av4[e];
-                if (b_nfast) sB[buf][(tid >> 5) + 8 * u][(tid & 31) * 4 + e] = bv4[e]; else sB[buf][(tid & 3) * 4 + e][(tid >> 2) + 64 * u] = bv4[e];
-            }
+            for (int e = 0; e < 4; ++e) { if (a_kfast) sA[buf][lm][lk + e] = av4[e]; else sA[buf][lm + e][lk] = av4[e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            int ln, lk;
+            if (!b_pos(u, ln, lk)) continue;
+            const float bv4[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (b_nfast) sB[buf][lk][ln + e] = bv4[e]; else sB[buf][lk + e][ln] = bv4[e]; }
         }
     };
-    float4 ra[2], rb[2];
+    float4 ra[NA], rb[NB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { ra[u] = make_float4(0.f, 0.f, 0.f, 0.f); rb[u] = ra[u]; }
+    for (int u = 0; u < NA; ++u) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k_beg < k_end) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { ra[u] = fetch_a(k_beg, u); rb[u] = fetch_b(k_beg, u); }
+        for (int u = 0; u < NA; ++u) ra[u] = fetch_a(k_beg, u);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) rb[u] = fetch_b(k_beg, u);
     }
     stash(0, ra, rb);
     __syncthreads();
@@ -208,25 +229,28 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
         const bool more = k0 + 16 < k_end;
         if (more) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { ra[u] = fetch_a(k0 + 16, u); rb[u] = fetch_b(k0 + 16, u); }
+            for (int u = 0; u < NA; ++u) ra[u] = fetch_a(k0 + 16, u);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) rb[u] = fetch_b(k0 + 16, u);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            float av[4], bv[4];
+            float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = sA[buf][64 * wm + 16 * i + r16][4 * kk + q];
+            for (int i = 0; i < TM; ++i) av[i] = sA[buf][16 * TM * wm + 16 * i + r16][4 * kk + q];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = sB[buf][4 * kk + q][64 * wn + 16 * j + r16];
+            for (int j = 0; j < TN; ++j) bv[j] = sB[buf][4 * kk + q][16 * TN * wn + 16 * j + r16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (more) stash(buf ^ 1, ra, rb);
         __syncthreads();
         buf ^= 1;
     }
-    if (a.epi == GEMM_EPI_BERN) {       // the output layer of a forward-only call: log p(x|z) of this half tile's 64 columns per row, no logits in HBM
+    if constexpr (TM == 4 && TN == 4) {
+    if (a.epi == GEMM_EPI_BERN) {       // the output layer: log p(x|z) of this half tile's 64 columns per row, no logits in HBM
         float bias4[4];
         bool nok[4];
 #pragma unroll
@@ -262,17 +286,18 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
             }
         return;
     }
+    }
     float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 64 * wn + 16 * j + r16;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + 16 * TN * wn + 16 * j + r16;
             if (n >= a.N) continue;
             const float bias = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                const int m = m0 + 16 * TM * wm + 16 * i + 4 * q + r;
                 if (m >= a.M) {
                     if (a.Cones && m == a.M) a.Cones[(size_t)blockIdx.z * a.cones_stride + n] = acc[i][j][r];
                     continue;
@@ -368,8 +393,25 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
     hipLaunchKernelGGL(concat_f32_kernel, dim3((unsigned)(((size_t)rows * (na + nb) + 255) / 256)), dim3(256), 0, st, a, na, b, nb, rows, out);
 }
 
+// Tile choice of the big kernel: the candidate with the least padded area (ties: the 128 x 128 tile); returns its workgroup count per K split
+static long gemm_f32_pick(int M, int N, int& bm, int& bn) {
+    const int cand[3][2] = {{128, 128}, {64, 224}, {224, 64}};
+    long best = -1, wgs = 0;
+    for (int c = 0; c < 3; ++c) {
+        const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
+        const long area = tm * cand[c][0] * tn * cand[c][1];
+        if (best < 0 || area < best) { best = area; bm = cand[c][0]; bn = cand[c][1]; wgs = tm * tn; }
+    }
+    return wgs;
+}
+long gemm_f32_tiles(int M, int N) {      // output tiles of the kernel launch_gemm_f32 would take (f32_dw sizes its row splits from it)
+    if (M > 64 && N > 64) { int bm, bn; return gemm_f32_pick(M, N, bm, bn); }
+    return (long)((M + 63) / 64) * ((N + 63) / 64);
+}
 bool gemm_f32_takes_big(int M, int N, int nsplit) {
-    return M > 64 && N > 64 && (long)((N + 127) / 128) * ((M + 127) / 128) * nsplit >= 512;
+    if (!(M > 64 && N > 64)) return false;
+    int bm, bn;
+    return gemm_f32_pick(M, N, bm, bn) * nsplit >= 512;
 }
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;
@@ -381,7 +423,23 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     // rest (few images, narrow heads: a 128-tile would be mostly padding)
     // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
     const int Mg = a.M + (a.Cones ? 1 : 0);      // (the row of ones)
-    if (gemm_f32_takes_big(a.M, a.N, nsplit)) hipLaunchKernelGGL(gemm_f32_big_kernel, dim3((a.N + 127) / 128, (Mg + 127) / 128, nsplit), dim3(256), 0, st, a);
+    if (gemm_f32_takes_big(a.M, a.N, nsplit)) {
+        int bm = 128, bn = 128;
+        if (a.epi != GEMM_EPI_BERN) gemm_f32_pick(a.M, a.N, bm, bn);      // (the Bernoulli epilogue's partial sums are per 64-column half of a 128-tile)
+        const dim3 grid((a.N + bn - 1) / bn, (Mg + bm - 1) / bm, nsplit);
+        const bool ak = a.sak == 1, bnf = a.sbn == 1;
+#define IWAE_F32_BIG(TM, TN)                                                                                             \
+        do {                                                                                                             \
+            if (ak && bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);     \
+            else if (ak) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, a);      \
+            else if (bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, a);     \
+            else hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, a);             \
+        } while (0)
+        if (bm == 64) IWAE_F32_BIG(2, 7);
+        else if (bm == 224) IWAE_F32_BIG(7, 2);
+        else IWAE_F32_BIG(4, 4);
+#undef IWAE_F32_BIG
+    }
     else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (Mg + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {

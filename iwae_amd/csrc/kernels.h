@@ -318,6 +318,7 @@ struct GemmF32Args {
     // goes to Cones[z * cones_stride + n] instead of C (round 3: no separate pass over G for the bias gradients)
     float* Cones; size_t cones_stride;
 };
+long gemm_f32_tiles(int M, int N);                       // output tiles of the kernel launch_gemm_f32 takes for an M x N product
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);

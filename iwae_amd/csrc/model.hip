@@ -1458,7 +1458,7 @@ int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int ro
 // (rowscale: G's row r is multiplied by rowscale[r] as it is fetched -- the values the separate g_r s pass used to store)
 int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr) {
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
-    const int tiles = (kl.Kin > 64 && kl.Nout > 64) ? ((kl.Kin + 127) / 128) * ((kl.Nout + 127) / 128) : ((kl.Kin + 63) / 64) * ((kl.Nout + 63) / 64);
+    const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout);      // (+ 1: the row of ones whose product row is the bias gradient)
     const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (m->f32_dw_tiles + tiles - 1) / tiles));
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     CHK(ensure(m->f32.slab, nsplit * nW * 4, m->stream));
