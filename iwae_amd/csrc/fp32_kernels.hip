@@ -314,12 +314,29 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
 }
 
 // out[i] = sum over z of slabs[z*stride + i] (fixed order), i < n
+// Block = 64 consecutive elements x 4 slab groups (slab z goes to group z & 3), 8 slabs' loads in flight per thread, the groups' sums added in
+// group order through LDS: as one thread per element walking all slabs in turn this was a chain of up to 247 dependent round trips on a few
+// hundred workgroups (23 us per launch, 14 launches per float32 step: the second largest item of its kernel trace).
 __global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slabs, size_t stride, int nsplit, size_t n, float* out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + c;
     float s = 0.0f;
-    for (int z = 0; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
-    out[i] = s;
+    if (i < n) {
+        const float* p = slabs + i;
+        int z = g;
+        for (; z + 28 < nsplit; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < nsplit; z += 4) s += p[(size_t)z * stride];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // partial column sums of G [M][ld] over row split blockIdx.y: part[y][n] (bias gradients), summed by reduce_slabs_f32_kernel
@@ -443,7 +460,7 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (Mg + 63) / 64, nsplit), dim3(256), 0, st, a);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
+    hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
 }
 void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st, const float* rowscale) {
     const int rps = (M + nsplit - 1) / nsplit;
