@@ -428,7 +428,7 @@ long gemm_f32_tiles(int M, int N) {      // output tiles of the kernel launch_ge
 bool gemm_f32_takes_big(int M, int N, int nsplit) {
     if (!(M > 64 && N > 64)) return false;
     int bm, bn;
-    return gemm_f32_pick(M, N, bm, bn) * nsplit >= 512;
+    return gemm_f32_pick(M, N, bm, bn) * nsplit >= 512;      // (448, which lets the 100 x 200 weight gradient in -- 2 tiles x 247 row splits -- measured slower: 79 vs 59 us)
 }
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;

@@ -912,7 +912,9 @@ def test_float32_mode_matches_exact_oracle(gpu, layers, B, k, obj, beta, nh, nl,
     for key in keys:
         assert abs(r0[key] - r[key]) <= 1e-6 * abs(r[key]) + 1e-5
     r2 = m.train_step(x, k, beta, 1e-3, obj, eps=eps)
-    np.testing.assert_array_equal(m.get_grads(), flat)
+    # (bitwise at small row counts; from ~8 000 rows on the call without `logits` takes the output layer's fused epilogue: the same sums in another order)
+    g2 = m.get_grads().astype(np.float64)
+    assert np.linalg.norm(g2 - flat) / np.linalg.norm(flat) < 1e-5
     ref, _, _ = O.adam_update(O.flatten_params(P), flat.astype(np.float64), 0.0, 0.0, 1, 1e-3)
     assert np.max(np.abs(m.get_params() - ref)) < 2e-6
     m.close()
