@@ -30,9 +30,13 @@ __device__ __forceinline__ float4 scale_b_quad(const GemmF32Args& a, float4 t, i
 // the tile loads walk the unit-stride index fastest so they stay coalesced either way.
 // blockIdx.z = K split: split z covers k in [z*kchunk, (z+1)*kchunk) and writes C + z*slab_stride (fp32 slabs, summed in a
 // fixed order by reduce_slabs_f32_kernel: deterministic, no float atomics).
+// KB = k-steps of 16 per loop iteration (1 or 2): with few workgroups (the encoder's layers on the batch's 1 024 images: 64 of them, one per CU) an iteration is
+// one exposed round trip -- fetch, stash, barrier, 16 MFMAs -- and K = 784 is 49 of them (22 us per launch); KB = 2 makes it 25 (round 3).
+template <int KB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
-    __shared__ float sA[64][17];
-    __shared__ float sB[16][80];
+    constexpr int BK = 16 * KB;
+    __shared__ float sA[64][BK + 1];
+    __shared__ float sB[BK][80];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
@@ -43,17 +47,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-    // Each thread fetches ONE quad (4 consecutive elements along the unit-stride index) of the A tile and one of the B tile per
-    // k-step, as a float4 where the host found the operand 16-byte aligned (a.avec / a.bvec), and the NEXT k-step's quads are
-    // requested before this step's MFMAs: the global latency hides under them.
+    // Each thread fetches KB quads (4 consecutive elements along the unit-stride index) of the A tile and of the B tile per iteration, as
+    // float4 where the host found the operand 16-byte aligned (a.avec / a.bvec), and the NEXT iteration's quads are requested before
+    // this one's MFMAs: the global latency hides under them.
     const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;
-    const int a_in = a_kfast ? (tid & 3) * 4 : (tid & 15) * 4;        // k offset (kfast) or m offset (mfast) of the quad
-    const int a_out = a_kfast ? (tid >> 2) : (tid >> 4);               // m (kfast) or k (mfast)
-    const int b_in = b_nfast ? (tid & 15) * 4 : (tid & 3) * 4;         // n offset (nfast) or k offset (kfast)
-    const int b_out = b_nfast ? (tid >> 4) : (tid >> 2);               // k (nfast) or n (kfast)
-    auto fetch_a = [&](int k0) -> float4 {
+    auto a_pos = [&](int u, int& lm, int& lk) { const int qq = tid + 256 * u; if (a_kfast) { lm = qq / (4 * KB); lk = (qq % (4 * KB)) * 4; } else { lk = qq >> 4; lm = (qq & 15) * 4; } };
+    auto b_pos = [&](int u, int& ln, int& lk) { const int qq = tid + 256 * u; if (b_nfast) { lk = qq >> 4; ln = (qq & 15) * 4; } else { ln = qq / (4 * KB); lk = (qq % (4 * KB)) * 4; } };
+    auto fetch_a = [&](int k0, int u) -> float4 {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int gm = m0 + (a_kfast ? a_out : a_in), gk = k0 + (a_kfast ? a_in : a_out);
+        int lm, lk;
+        a_pos(u, lm, lk);
+        const int gm = m0 + lm, gk = k0 + lk;
         const float* p = a.A + (size_t)gm * a.sam + (size_t)gk * a.sak;
         const int lim = a_kfast ? k_end - gk : a.M - gm;             // elements of the quad that exist
         const bool outer_ok = a_kfast ? gm < a.M : gk < k_end;
@@ -68,9 +72,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
-    auto fetch_b = [&](int k0) -> float4 {
+    auto fetch_b = [&](int k0, int u) -> float4 {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int gn = n0 + (b_nfast ? b_in : b_out), gk = k0 + (b_nfast ? b_out : b_in);
+        int ln, lk;
+        b_pos(u, ln, lk);
+        const int gn = n0 + ln, gk = k0 + lk;
         const float* p = a.B + (size_t)gk * a.sbk + (size_t)gn * a.sbn;
         const int lim = b_nfast ? a.N - gn : k_end - gk;
         const bool outer_ok = b_nfast ? gk < k_end : gn < a.N;
@@ -81,19 +87,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args a) {
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    if (k_beg < k_end) { ra = fetch_a(k_beg); rb = fetch_b(k_beg); }
-    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
-        const float av4[4] = {ra.x, ra.y, ra.z, ra.w}, bv4[4] = {rb.x, rb.y, rb.z, rb.w};
+    float4 ra[KB], rb[KB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (a_kfast) sA[a_out][a_in + e] = av4[e]; else sA[a_in + e][a_out] = av4[e];
-            if (b_nfast) sB[b_out][b_in + e] = bv4[e]; else sB[b_in + e][b_out] = bv4[e];
+    for (int u = 0; u < KB; ++u) { ra[u] = make_float4(0.f, 0.f, 0.f, 0.f); rb[u] = ra[u]; }
+    if (k_beg < k_end) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) { ra[u] = fetch_a(k_beg, u); rb[u] = fetch_b(k_beg, u); }
+    }
+    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const float av4[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w}, bv4[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+            int lm, lka, ln, lkb;
+            a_pos(u, lm, lka);
+            b_pos(u, ln, lkb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a_kfast) sA[lm][lka + e] = av4[e]; else sA[lm + e][lka] = av4[e];
+                if (b_nfast) sB[lkb][ln + e] = bv4[e]; else sB[lkb + e][ln] = bv4[e];
+            }
         }
         __syncthreads();
-        if (k0 + 16 < k_end) { ra = fetch_a(k0 + 16); rb = fetch_b(k0 + 16); }
+        if (k0 + BK < k_end) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+            for (int u = 0; u < KB; ++u) { ra[u] = fetch_a(k0 + BK, u); rb[u] = fetch_b(k0 + BK, u); }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4 * KB; ++kk) {
             float av[2], bv[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) av[i] = sA[32 * wm + 16 * i + r16][4 * kk + q];
@@ -457,7 +477,12 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
         else IWAE_F32_BIG(4, 4);
 #undef IWAE_F32_BIG
     }
-    else hipLaunchKernelGGL(gemm_f32_kernel, dim3((a.N + 63) / 64, (Mg + 63) / 64, nsplit), dim3(256), 0, st, a);
+    else {
+        const dim3 grid((a.N + 63) / 64, (Mg + 63) / 64, nsplit);
+        // few workgroups walking a long K: two k-steps per iteration (half as many exposed round trips)
+        if ((long)grid.x * grid.y * grid.z < 512 && a.kchunk >= 64) hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, a);
+    }
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
