@@ -1022,23 +1022,57 @@ struct LseGlobalSrc {
     __device__ __forceinline__ float lq_dreg(const LseArgs& a, int, int r) const { return a.lq_dreg[r]; }
 };
 
-template <class SRC>
-__device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const int lane, const SRC& src) {
+// RED = the team working on one image: a wave (WaveRed: the training step's k) or a whole workgroup (BlockRed<NW>: the k = 5000 evaluator, where a wave
+// per image is ~100 waves on the machine walking 5 000 samples each: 26 % of the bf16 evaluator's time in round 3's profile).  `lane` = index in the team.
+struct WaveRed {
+    static constexpr int NT = 64;
+    __device__ __forceinline__ float sum(float v) const { return wave_sum(v); }
+    __device__ __forceinline__ float max(float v) const { return wave_max(v); }
+};
+template <int NW>
+struct BlockRed {      // (every thread of the workgroup calls sum / max the same number of times: they hold barriers)
+    static constexpr int NT = 64 * NW;
+    float* slots;      // NW floats of LDS
+    __device__ __forceinline__ float sum(float v) const {
+        const float w = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = w;
+        __syncthreads();
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t += slots[i];
+        return t;
+    }
+    __device__ __forceinline__ float max(float v) const {
+        const float w = wave_max(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = w;
+        __syncthreads();
+        float t = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t = fmaxf(t, slots[i]);
+        return t;
+    }
+};
+
+template <class SRC, class RED = WaveRed>
+__device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const int lane, const SRC& src, const RED red = RED()) {
+    constexpr int NT = RED::NT;
     const int k = a.k;
-    const bool single = k <= 64;          // one sample per lane: log_w stays in a register between the passes
+    const bool single = NT == 64 && k <= 64;          // one sample per lane: log_w stays in a register between the passes
     // the image's head (for the KL term at the end): requested first, so that its round trip runs beside the log_w terms' instead of
     // behind the whole kernel
     float kmu[2] = {0.0f, 0.0f}, ksg[2] = {1.0f, 1.0f};
     if (a.head) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int f = lane + 64 * i;
+            const int f = lane + NT * i;
             if (f < a.D) { kmu[i] = a.head[(size_t)b * a.ldH + f]; ksg[i] = a.head[(size_t)b * a.ldH + a.Dp + f]; }
         }
     }
     float lw_reg = 0.0f;
     float m = -INFINITY, sum_lw = 0.0f, sum_px = 0.0f, sum_t1 = 0.0f, sum_t2 = 0.0f;
-    for (int s = lane; s < k; s += 64) {
+    for (int s = lane; s < k; s += NT) {
         const int r = b * k + s;
         const float px = src.px(a, s, r);
         float lw = a.coef[0] * px;
@@ -1053,14 +1087,14 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
         if (a.term[1]) sum_t1 += src.term(a, 1, s, r);
         if (a.term[2]) sum_t2 += src.term(a, 2, s, r);
     }
-    m = wave_max(m); sum_lw = wave_sum(sum_lw); sum_px = wave_sum(sum_px); sum_t1 = wave_sum(sum_t1); sum_t2 = wave_sum(sum_t2);
+    m = red.max(m); sum_lw = red.sum(sum_lw); sum_px = red.sum(sum_px); sum_t1 = red.sum(sum_t1); sum_t2 = red.sum(sum_t2);
     float se = 0.0f;
-    for (int s = lane; s < k; s += 64) se += __expf((single ? lw_reg : a.logw[b * k + s]) - m);
-    se = wave_sum(se);
+    for (int s = lane; s < k; s += NT) se += __expf((single ? lw_reg : a.logw[b * k + s]) - m);
+    se = red.sum(se);
     const float inv_se = 1.0f / se;
     const float invB = 1.0f / (float)a.B, invkB = invB / (float)k;
     float eq14 = 0.0f, dreg = 0.0f;
-    for (int s = lane; s < k; s += 64) {
+    for (int s = lane; s < k; s += NT) {
         const int r = b * k + s;
         const float lw = single ? lw_reg : a.logw[r];
         const float wn = __expf(lw - m) * inv_se;       // iwae1.py:128-131 == softmax over k (:137)
@@ -1083,23 +1117,23 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
         a.gx[r] = G;
         a.cf[r] = cf;
     }
-    eq14 = wave_sum(eq14); dreg = wave_sum(dreg);
+    eq14 = red.sum(eq14); dreg = red.sum(dreg);
     // KL(q(z|x) || N(0,1)) per image (iwae1.py:116), TFP closed form
     float kl = 0.0f;
     if (a.head) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (lane + 64 * i < a.D) {
+            if (lane + NT * i < a.D) {
                 const float ls = __logf(ksg[i]);
                 kl += 0.5f * kmu[i] * kmu[i] + 0.5f * expm1f(2.0f * ls) - ls;
             }
         }
-        for (int f = lane + 128; f < a.D; f += 64) {      // (latent widths beyond 128)
+        for (int f = lane + 2 * NT; f < a.D; f += NT) {      // (latent widths beyond 128)
             const float mu = a.head[(size_t)b * a.ldH + f], sg = a.head[(size_t)b * a.ldH + a.Dp + f];
             const float ls = __logf(sg);
             kl += 0.5f * mu * mu + 0.5f * expm1f(2.0f * ls) - ls;
         }
-        kl = wave_sum(kl);
+        kl = red.sum(kl);
     }
     if (lane == 0) {
         float* pb = a.per_b;
@@ -3602,6 +3636,12 @@ __global__ void lse_kernel(LseArgs a) {
     if (b >= a.B) return;
     lse_image(a, b, lane, LseGlobalSrc{});
 }
+// one workgroup of NW waves per image (many samples per image: the evaluator's k)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void lse_block_kernel(LseArgs a) {
+    __shared__ float slots[NW];
+    lse_image(a, (int)blockIdx.x, (int)threadIdx.x, LseGlobalSrc{}, BlockRed<NW>{slots});
+}
 
 // Batch means of the per-image values (the scalar entries of the reference's result dict), one 256-thread block.
 // A cross-XCD "last wave reduces" inside lse_kernel would need agent-scope release/acquire fences, i.e. an L2
@@ -4264,7 +4304,11 @@ void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream
 }
 void launch_sample(const SampleArgs& a, hipStream_t st) { hipLaunchKernelGGL(sample_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st) { hipLaunchKernelGGL(gauss_lp_kernel, dim3((a.M + 63) / 64), dim3(256), 0, st, a); }
-void launch_lse(const LseArgs& a, hipStream_t st) { LAUNCH_EV(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a); }
+void launch_lse(const LseArgs& a, hipStream_t st) {
+    if (a.k >= 2048) LAUNCH_EV(lse_block_kernel<16>, dim3(a.B), dim3(1024), 0, st, a);
+    else if (a.k > 256) LAUNCH_EV(lse_block_kernel<4>, dim3(a.B), dim3(256), 0, st, a);
+    else LAUNCH_EV(lse_kernel, grid1((size_t)a.B * 64, 256), dim3(256), 0, st, a);
+}
 void launch_latent_bwd(const LatentBwdArgs& a, hipStream_t st) {
     if (a.dzh && !a.dz2 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<1>, dim3(a.Bp), dim3(256), 0, st, a);
     else if (!a.dzh && a.dz && a.dz2 && a.dz3 && a.eps.cache && !a.prior_head) hipLaunchKernelGGL(latent_bwd_kernel<2>, dim3(a.Bp), dim3(256), 0, st, a);
