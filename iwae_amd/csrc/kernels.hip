@@ -261,7 +261,7 @@ __device__ __forceinline__ float bern8(const f32x4& a0, const f32x4& a1, const u
 // step's noise, stores them (they ARE the P-layout rows of z, which the weight gradient needs) and sums the row's prior and
 // posterior log-densities on the way -- the separate sampling pass over the rows (42 MB, 14 us) disappears.
 template <int EPI, int KTC, int G, int NWV = (G == 2 ? 4 : 8), bool ZIN = false>   // KTC > 0: compile-time k-step count (<= 8, single window), straight-line MFMA phase; NWV waves
-__global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : (EPI == EPI_BERN ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD
+__global__ __launch_bounds__(64 * NWV, G == 1 ? 4 : ((EPI == EPI_BERN && KTC > 0) ? 2 : 1)) void dense_kernel(DenseArgs a) {   // 2nd = waves per SIMD (the run-time-K Bernoulli fallback -- hidden widths without an instantiation -- spilled 50 registers at two)
 #ifdef IWAE_DENSE_STAMPS
     unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
