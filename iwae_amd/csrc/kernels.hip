@@ -3468,6 +3468,14 @@ __global__ __launch_bounds__(512, 2) void wgradp_group_kernel(WgradPGroup g) {
     if ((int)blockIdx.x >= g.gx[l] || (int)blockIdx.y >= g.gy[l]) return;
     wgradp_body<8, 4, 4, 4, false>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
 }
+// ... with row weights on member 0 (the decoder's three layers at small row counts: the output layer's gradient is g2^T (g_r s))
+__global__ __launch_bounds__(512, 2) void wgradp_group_sc_kernel(WgradPGroup g) {
+    int l = 0;
+    while (l + 1 < g.n && (int)blockIdx.z >= g.zbeg[l + 1]) ++l;
+    if ((int)blockIdx.x >= g.gx[l] || (int)blockIdx.y >= g.gy[l]) return;
+    if (l == 0) wgradp_body<8, 4, 4, 4, true>(g.a[0], blockIdx.x, blockIdx.y, blockIdx.z);
+    else wgradp_body<8, 4, 4, 4, false>(g.a[l], blockIdx.x, blockIdx.y, blockIdx.z - g.zbeg[l]);
+}
 
 // ---------------------------------------------------------------------------------
 // elementwise / reduction kernels
@@ -4260,7 +4268,8 @@ void launch_wgradws_group(const WgradPGroup& g, hipStream_t st) {
 void launch_wgradp_group(const WgradPGroup& g, hipStream_t st) {
     int mx = 0, my = 0;
     for (int l = 0; l < g.n; ++l) { mx = std::max(mx, g.gx[l]); my = std::max(my, g.gy[l]); }
-    hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, g);
+    if (g.a[0].rowscale) hipLaunchKernelGGL(wgradp_group_sc_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256 + 1024), st, g);
+    else hipLaunchKernelGGL(wgradp_group_kernel, dim3(mx, my, g.zbeg[g.n]), dim3(512), WG_NST * (WG_SR * 512 + WG_SR * 256), st, g);
 }
 // shape: 8 = 8 waves / 8 j-tiles per block (small), 16 = 16 waves / 16 j-tiles; specialised waves (IT <= 14): 7 = 8 + 4 waves / 16 j-tiles,
 // 9 = 8 + 8 waves / 8 j-tiles

@@ -169,6 +169,7 @@ struct iwae_model {
     DevBuf logw2, wn2, gx2, cf2, per_b2;
     int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
     bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
+    bool allow_wg3 = true;                           // few rows: the decoder's three weight gradients as one grouped launch (option no_wg3)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
@@ -725,8 +726,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
         iwae_model::EpsTag& tg = m->eps_tag[np];
         if (m->eval_k_total > 0 || !(tg.valid && tg.step == m->noise_step && tg.row_offset == ro && tg.M == M)) {
-            CHK(join_side(m));          // a speculative draw into this slot may still be on the side stream
+            CHK(join_side(m));          // a speculative draw into this slot may still be on a side stream
             if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+            if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
             CHK(draw_eps(m, np, m->noise_step, M, st));
             if (m->eval_k_total > 0) m->eval_tag_kill = np;      // (a k-chunk's draws: the tag does not describe them)
         }
@@ -1017,7 +1019,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         HIPCHK(hipGetLastError());
         // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
         // stream, idle until the backward pass forks -- enqueued behind the decoder kernel so that its dispatch does not delay that one
-        if (bwd && keep_eps && m->side) CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, m->side, m->eps_blocks));
+        // (few rows, where the backward pass launches the decoder's weight gradients as one group on the SECOND side stream and `side` carries nothing
+        // that a later event would cover: the draw goes to that second stream, in front of the group and the decoder update whose event the next step waits for)
+        if (bwd && keep_eps && m->side)
+            CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, (m->allow_wg3 && m->use_side2 && M <= 4096) ? m->side2 : m->side, m->eps_blocks));
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
 
@@ -1152,6 +1157,32 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // they start on the side stream right behind it and fill the machine next to the dz -> encoder chain; the
     // first decoder layer's gradient additionally waits for dpre1 (second event).
     hipStream_t sd = m->side;
+    // Few rows (round 3): the decoder's three weight gradients as ONE grouped launch behind the dX chain (the B = 20 step is bound by the host's
+    // launches and the streams' hand-offs, not by these kernels: 13 -> 11 launches, two events less)
+    bool group3 = false;
+    WgradPGroup g3;
+    if (m->allow_wg3 && M <= 4096 && fused_dx && m->early_wout && m->use_side2 && m->s_mode) {
+        memset(&g3, 0, sizeof(g3));
+        Linear* ls[3] = {&m->dec1[2], &m->dec1[1], &m->dec1[0]};
+        const uint16_t* xs[3] = {ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.g1P), ptr<uint16_t>(m->zP[0])};
+        const uint16_t* gs[3] = {ptr<uint16_t>(w.dlP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
+        int ns[3], nw[3];
+        group3 = true;
+        for (int i = 0; i < 3; ++i) {
+            CHK(wgradp_plan(m, *ls[i], xs[i], gs[i], M, g3.a[i], ns[i], nw[i]));
+            group3 = group3 && nw[i] == 8;
+            g3.gx[i] = (ls[i]->JT + 7) / 8; g3.gy[i] = (ls[i]->IT + 15) / 16;
+            g3.zbeg[i + 1] = g3.zbeg[i] + ns[i];
+        }
+        g3.n = 3;
+        g3.a[0].rowscale = ptr<float>(m->lse_dup ? m->gx2 : m->gx);
+    }
+    if (group3) {
+        HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
+        { ScopedTimer tm(m, T_WGRAD_OUT, m->side2); launch_wgradp_group(g3, m->side2); }
+        HIPCHK(hipGetLastError());
+        m->tail = m->side2;
+    } else {
     if (m->early_wout && (m->lse_dup || m->lse_fused)) {}                            // forked behind the decoder kernel already (forward_impl)
     else if (m->early_wout) HIPCHK(hipStreamWaitEvent(m->side, m->ev_lse, 0));            // forked behind lse_kernel (forward_impl)
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
@@ -1202,6 +1233,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         HIPCHK(hipGetLastError());
     }
     if (ws == m->side2) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
+    }      // (!group3)
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
@@ -2140,6 +2172,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
+    else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32
