@@ -1316,7 +1316,16 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         // Quarter waves (QW) take tile qw of every 64-feature group of BOTH layers for the shared tile 12 -- the units are
         // barrier-separated, so only a per-unit split keeps the four SIMDs level -- and exchange the 8-byte fragment halves
         // through LDS (xch_out; read back as whole fragments behind the next layer's first barrier: xch_in).
-        auto hidden = [&](auto nb_tag, uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout, const char* xch_in, char* xch_out) {
+        // (round 3: a group's activation stores are issued at the TOP of the next unit, behind its barrier and weight DMA -- issued at the end of their own
+        // unit they were what the next unit's wait waited for, eight times per tile; the fragments are the next layer's operand and live anyway.
+        // `first`: the stores the unit in front of this layer left behind; this layer's last group is left to the caller)
+        auto store_group = [&](uint16_t* Gout, const uint4 (&bout)[KTC], int mg) {
+            if (!(valid && storer && Gout) || (QW && qw >= 0)) return;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+                if (2 * mg + p2 < KTC) *(uint4*)(Gout + (size_t)row * (32 * KTC) + (2 * mg + p2) * 32 + q * 8) = bout[2 * mg + p2];
+        };
+        auto hidden = [&](auto nb_tag, uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout, const char* xch_in, char* xch_out, auto&& first) {
             constexpr int NB = decltype(nb_tag)::value;
             const bool quarter = QW && qw >= 0;
 #pragma unroll
@@ -1325,6 +1334,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                 wait_all_vmem();
                 __syncthreads();
                 dma_unit(u + 1, buf ^ 1);          // behind the last unit of layer 2 comes the output layer's group 0
+                if (mg == 0) first(); else store_group(Gout, bout, mg - 1);
                 const char* lb = smem + buf * UNIT + a_off;
                 const char* lbias = smem + buf * UNIT + KTin * 4096 + q * 16;
                 if (quarter) {
@@ -1362,8 +1372,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
                         const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-                        bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
-                        if (valid && storer && Gout) *(uint4*)(Gout + (size_t)row * (32 * KTC) + kso * 32 + q * 8) = frag;     // forward-only calls keep nothing (Gout = null)
+                        bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);      // (stored one unit later: store_group; forward-only calls keep nothing, Gout = null)
                     }
                 }
             }
@@ -1371,9 +1380,9 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         char* xch1 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096;      // g1 / g2 of the shared tile: 7 KiB each
         char* xch2 = xch1 + KTC * 1024;
         DS_STAMP(0);
-        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1);
+        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1, [] {});
         DS_STAMP(1);
-        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2, xch1, xch2);
+        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2, xch1, xch2, [&] { store_group(a.pre_G1, g1f, MGH - 1); });
         DS_STAMP(2);
     }
 
@@ -1508,6 +1517,13 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     wait_all_vmem();
     __syncthreads();
     if (2 < H) dma_group(1, 1);
+    if constexpr (PRE) {      // the second tanh layer's last group of activations (deferred by one unit like the others)
+        if (valid && storer && a.pre_G2 && !(QW && qw >= 0)) {
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2)
+                if (2 * (MGH - 1) + p2 < KTC) *(uint4*)(a.pre_G2 + (size_t)row * (32 * KTC) + (2 * (MGH - 1) + p2) * 32 + q * 8) = bfr[2 * (MGH - 1) + p2];
+        }
+    }
     if constexpr (PRE && QW) {
         if (qw >= 0) {      // the shared tile's g2 fragments, assembled from the four quarter waves' pieces
             const char* xch2 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096 + KTC * 1024;
