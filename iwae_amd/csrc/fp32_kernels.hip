@@ -359,21 +359,6 @@ __global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slab
     if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
-// partial column sums of G [M][ld] over row split blockIdx.y: part[y][n] (bias gradients), summed by reduce_slabs_f32_kernel
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* G, size_t ld, int M, int N, int rows_per_split, float* part, const float* rowscale) {
-    __shared__ float red[4][64];
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
-    float s = 0.0f;
-    if (n < N) {
-        if (rowscale) { for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n] * rowscale[r]; }
-        else for (int r = r0 + g; r < r1; r += 4) s += G[(size_t)r * ld + n];
-    }
-    red[g][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (g == 0 && n < N) part[(size_t)blockIdx.y * N + n] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
 // log p(x|z) per data row from float32 logits: sum_j x_j l_j - softplus(l_j) (iwae1.py:111); one wave per row (image-major rows: b = row / k)
 __global__ __launch_bounds__(256) void bern_f32_kernel(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -486,10 +471,6 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
-}
-void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st, const float* rowscale) {
-    const int rps = (M + nsplit - 1) / nsplit;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, st, G, ld, M, N, rps, part, rowscale);
 }
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st) {
     hipLaunchKernelGGL(bern_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, ld, x, X, M, k, lpxz);

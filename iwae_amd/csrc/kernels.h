@@ -322,7 +322,6 @@ long gemm_f32_tiles(int M, int N);                       // output tiles of the 
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
-void launch_colsum_f32(const float* G, size_t ld, int M, int N, int nsplit, float* part, hipStream_t st, const float* rowscale = nullptr);      // part [nsplit][N]; rows weighted by rowscale[r] if given
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st);
 void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st);
 void launch_sigmoid_f32(float* v, size_t n, hipStream_t st);
