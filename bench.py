@@ -212,11 +212,12 @@ def run():
     ap.add_argument("--no-llh-eval", action="store_true", help="skip the untimed k = 5000 evaluator run (profiling: keeps its kernels out of the statistics)")
     ap.add_argument("--settle", type=int, default=SETTLE_STEPS, help="untimed steps in front of the timed region in any case (profiling scripts pass 0: then exactly --warmup)")
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel event pass behind the timed region (profiling)")
+    ap.add_argument("--timing-every", type=int, default=TIMING_EVERY, help="the per-kernel event pass brackets the kernels of every n-th step")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="iwae_set_option switch for A/B measurements (repeatable; tools/README.md)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the data-parallel code path with ONE rank (trivial collectives)")
     ap.add_argument("--dp-torch", action="store_true", help="data-parallel exchange through torch.distributed.all_reduce instead of the library's own RCCL calls")
     args = ap.parse_args()
-    force_dist = args.force_dist or bool(os.environ.get("IWAE_BENCH_FORCE_DIST"))
+    force_dist = args.force_dist
     options = {}
     for kv in args.opt:
         name, _, val = kv.partition("=")
@@ -287,12 +288,15 @@ def run():
     # per-kernel launch durations: a SEPARATE pass behind the timed region (HIP events on the stream each kernel runs on)
     models = kernel_models(cfg)
     ktimes = {k: (0.0, 0) for k in models}
+    allreduce_us = None
     if not args.no_kernel_times:
-        net.enable_timing(int(os.environ.get("IWAE_BENCH_TIMING", TIMING_EVERY)))
+        net.enable_timing(args.timing_every)
         for _ in range(TIMING_STEPS):
             step()
         net.sync()
         ktimes = {k: net.kernel_time(k) for k in models}
+        if dp.in_library:      # the data-parallel step's two all-reduces (events around each ncclAllReduce on the stream that carries it)
+            allreduce_us = {seg: round(net.kernel_time("allreduce_" + seg)[0], 2) for seg in ("enc", "dec")}
         net.enable_timing(0)
     elbo = net.forward(x_np[lo:lo + B], K)["iwae_elbo"]
     llh_eval = None
@@ -331,7 +335,7 @@ def run():
                                    + (" + RCCL all-reduce of the flat fp32 gradient" if world > 1 else ""),
                        "config_id": args.config, "global_batch": B * world, "n_samples": K, "parallelism": "dp%d" % world,
                        # which exchange path ran, and over how many ranks RCCL itself says (ncclCommCount on the library's communicator)
-                       "dp_path": dp.path, "rccl_ranks": rccl_ranks, "settle_steps": settle, "options": options,
+                       "dp_path": dp.path, "rccl_ranks": rccl_ranks, "allreduce_us": allreduce_us, "settle_steps": settle, "options": options,
                        "step_gemm_tflops": round(flop_step * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3), "llh_eval_k5000": llh_eval},
         }

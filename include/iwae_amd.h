@@ -176,6 +176,10 @@ int iwae_set_step(iwae_handle h, uint32_t noise_step, uint32_t batch_offset); /*
  * the library itself does not link against it.  iwae_comm_destroy (or iwae_destroy) releases the communicators. */
 int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes);
 int iwae_comm_init(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
+/* The checks of iwae_comm_init that need no other rank (arguments, handle state, RCCL loadable), without the rendezvous: ncclCommInitRank
+ * blocks until every rank has entered it, so a multi-process caller runs this first, agrees on the outcome over its own channel, and only
+ * then lets every rank call iwae_comm_init (no reference counterpart: the reference is single-device, /root/reference/main.py:24,32). */
+int iwae_comm_preflight(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
 int iwae_comm_destroy(iwae_handle h);
 /* what RCCL itself reports for the handle's communicators (ncclCommCount / ncclCommUserRank): *world_size = 0, *rank = -1 when
  * the handle has none.  bench.py records it so a multi-GPU line shows which exchange path ran and over how many ranks. */

@@ -64,6 +64,7 @@ SYMBOLS = {
     "iwae_set_step": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "iwae_comm_unique_id": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "iwae_comm_init": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, C.c_int32]),
+    "iwae_comm_preflight": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, C.c_int32]),
     "iwae_comm_destroy": (C.c_int, [_P]),
     "iwae_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "iwae_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),

@@ -164,6 +164,16 @@ struct WgradPArgs {
     unsigned long long* stamps;             // diagnostic build (STAMPS=1) only: wgradws_kernel's per-wave phase cycle sums [workgroups * waves][8], else null
 };
 
+// wgrad_rows_kernel (round 4): weight gradient of one linear map on FEW rows (<= 2 048) with the whole row reduction inside the workgroup
+// and the optimizer update in its epilogue -- no slabs, no reduction launch
+#define WGR_MAX_JOBS 4
+struct WgradRowsJob {
+    const uint16_t* X; int ldX;             // layer input, P-layout [R][ldX]
+    const uint16_t* G; int ldG;             // dpre of the layer's outputs, P-layout [R][ldG]
+    int R;                                  // valid rows
+    int sub0, sub1, split;                  // layer-table index of out-features < split and (merged mu | sigma head) >= split; sub1 = -1: none
+    int ib, jb, wg_begin;                   // filled by launch_wgrad_rows: 64-feature blocks of the in / out space, first workgroup
+};
 struct WgradPGroup {                        // up to 3 independent 8-wave weight gradients in one launch
     WgradPArgs a[3];
     int n;
@@ -284,6 +294,9 @@ void launch_gauss_bwd(const GaussBwdArgs& a, hipStream_t st);
 void launch_reduce_grads(const LayerDesc* layers, int nlayers, int first_block, int nblocks, float* grad, float* param, float* mom, float* vel,
                          float alpha, float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, hipStream_t st,
                          int first_block2 = 0, int nblocks2 = 0);      // (optional second block range of the same launch)
+// fuse_adam: Keras Adam (grad_scale 1) + image refresh in the epilogue; per_b != null: one extra block makes the step's batch means
+void launch_wgrad_rows(const WgradRowsJob* jobs, int njobs, const LayerDesc* layers, float* grad, float* param, float* mom, float* vel, float alpha,
+                       float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, const char* zero, hipStream_t st);
 void launch_scalars(const float* per_b, int B, float beta, float* out, hipStream_t st);
 void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param, const float* grad, float* mom, float* vel,
                  float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block = 0);   // blocks [first_block, first_block + nblocks) of the elementwise grid

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <string.h>
 #include <type_traits>
 #include <algorithm>
 #include "kernels.h"
@@ -3929,18 +3930,18 @@ struct AdamCoef { float alpha, gscale, beta1, beta2, eps; int on; };
 
 // Keras Adam (epsilon outside the square root, main.py:93) on one element + refresh of the bf16 weight images /
 // the fp32 bias block the GEMM kernels read.  is_bias: element j of the bias, else weight (in-feature i, out-feature j).
-__device__ __forceinline__ void adam_element(const LayerDesc& L, bool is_bias, int i, int j, size_t idx, float g, bool update,
-                                             float* param, float* mom, float* vel, const AdamCoef& c) {
-    float w = param[idx];
-    if (update) {
-        g *= c.gscale;
-        const float m = c.beta1 * mom[idx] + (1.0f - c.beta1) * g;
-        const float v = c.beta2 * vel[idx] + (1.0f - c.beta2) * g * g;
-        mom[idx] = m;
-        vel[idx] = v;
-        w -= c.alpha * m / (sqrtf(v) + c.eps);
-        param[idx] = w;
-    }
+// The update's arithmetic with its roundings spelled out (explicit fused multiply-adds): the same function is inlined into
+// reduce_grads_kernel, adam_kernel and wgrad_rows_kernel, and the single-GPU step must land on bit-identical parameters whichever of them
+// applies it (left to -ffp-contract, the compiler fused a different product of b1*m + (1-b1)*g in one of the three contexts).
+__device__ __forceinline__ void adam_math(float& w, float& m, float& v, float g, const AdamCoef& c) {
+    g *= c.gscale;
+    m = __builtin_fmaf(c.beta1, m, (1.0f - c.beta1) * g);
+    v = __builtin_fmaf(c.beta2, v, ((1.0f - c.beta2) * g) * g);
+    const float q = (c.alpha * m) / (sqrtf(v) + c.eps);
+    w = w - q;
+}
+// refresh of the bf16 weight images / the fp32 bias block the GEMM kernels read, from the (new) master value w
+__device__ __forceinline__ void image_refresh(const LayerDesc& L, bool is_bias, int i, int j, float w) {
     if (is_bias) {
         *(float*)(L.imgF + img_mg_bias_byte(L.joff + j, L.KT_F)) = w;
     } else {
@@ -3951,6 +3952,18 @@ __device__ __forceinline__ void adam_element(const LayerDesc& L, bool is_bias, i
             else *(uint16_t*)(L.imgB + img_mg_byte(i, L.joff + j, L.KT_B)) = h;
         }
     }
+}
+__device__ __forceinline__ void adam_element(const LayerDesc& L, bool is_bias, int i, int j, size_t idx, float g, bool update,
+                                             float* param, float* mom, float* vel, const AdamCoef& c) {
+    float w = param[idx];
+    if (update) {
+        float m = mom[idx], v = vel[idx];
+        adam_math(w, m, v, g, c);
+        mom[idx] = m;
+        vel[idx] = v;
+        param[idx] = w;
+    }
+    image_refresh(L, is_bias, i, j, w);
 }
 
 // Sums the per-split fp32 slabs of every layer into the flat gradient; with c.on the Adam update of the same
@@ -4039,6 +4052,195 @@ __global__ void adam_kernel(const LayerDesc* layers, int nlayers, float* param, 
     const size_t idx = is_b ? (L.offb + (e - nW)) : (L.offW + e);
     adam_element(L, is_b, is_b ? 0 : e / L.Nout, is_b ? e - nW : e % L.Nout, idx, c.on ? grad[idx] : 0.0f, c.on != 0, param, mom, vel, c);
 }
+// ---------------------------------------------------------------------------------
+// wgrad_rows_kernel (round 4): the weight gradients of a BasicBlock applied to FEW rows (the image encoder: R = batch size <= 2 048)
+// with the WHOLE row reduction inside one workgroup -- no row splits, no fp32 slabs, no reduction launch -- and the Keras Adam update
+// (+ weight-image refresh) of the workgroup's 64 x 64 block of the weight matrix in its epilogue.  Before: wgradp_group_kernel (32 - 48
+// workgroups of 256 x 128 features walking row splits: 18.6 us alone) -> slabs -> reduce_grads_kernel (+ Adam: 14.6 us), two dependent
+// launches at the END of the step's main chain, in front of the next encoder forward.
+//   grid: one workgroup per (linear map, 64 in-features, 64 out-features) [+ one block for the step's batch means]
+//   wave w of 4: data rows [w*RW, (w+1)*RW) -- its own ring of 4 stages x 32 rows x (128 B of X + 128 B of G) filled by its own LDS-DMA and
+//   read back through ds_read_b64_tr_b16 (the P-layout operands are row-major; the contraction index is the data row): no workgroup
+//   barrier in the loop, a wave waits only for its own vmcnt.  16 accumulator tiles (4 i-tiles x 4 j-tiles) per wave + the bias
+//   gradient through the matrix pipe (ones x G).  The four waves' partial sums meet in LDS (fixed order: deterministic), then every
+//   thread owns 16 elements: gradient -> flat buffer, and (c.on) m, v, theta, the bf16 images.  Reference: tape.gradient + apply_gradients,
+//   src/iwae1.py:159-160 (Adam: main.py:93).
+// ---------------------------------------------------------------------------------
+struct WgradRowsArgs {
+    WgradRowsJob job[WGR_MAX_JOBS];
+    int njobs;
+    const LayerDesc* layers;
+    float *grad, *param, *mom, *vel;
+    AdamCoef c;
+    MeansArgs mn;              // per_b != null: the last block of the grid makes the step's batch means
+    const char* zero;          // >= 1 KiB of zeros
+};
+#define WGR_NST 4
+#define WGR_STAGE 8192         // bytes per stage and wave: 32 rows x 128 B of X, 32 rows x 128 B of G
+__global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradRowsArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    typedef __attribute__((ext_vector_type(4))) short v4s;
+    if (a.mn.per_b && blockIdx.x == gridDim.x - 1) {
+        batch_means_block(a.mn.per_b, a.mn.B, a.mn.beta, a.mn.out);
+        return;
+    }
+    int jn = 0;
+#pragma unroll
+    for (int t = 1; t < WGR_MAX_JOBS; ++t)
+        if (t < a.njobs && (int)blockIdx.x >= a.job[t].wg_begin) jn = t;
+    const WgradRowsJob J = a.job[jn];
+    const int wl = (int)blockIdx.x - J.wg_begin;
+    const int bi = wl / J.jb, bj = wl - bi * J.jb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, l16 = lane & 15, qp = l16 >> 2, p = l16 & 3;
+    const int RW = ((J.R + 3) / 4 + 31) & ~31;                  // data rows per wave (multiple of the 32-row stage)
+    const int rbeg = wave * RW, rend = min(J.R, rbeg + RW);
+    const int nstage = rend > rbeg ? (rend - rbeg + 31) / 32 : 0;
+    char* ring = smem + wave * (WGR_NST * WGR_STAGE);
+    // 16-byte slot s of row r lands at slot s ^ swz(r) (applied on the SOURCE address): at a 128-byte row pitch odd rows are half a bank
+    // cycle apart by themselves, row bit 1 picks the other half (the narrow strip of wgradws_kernel)
+    auto swz = [](int r) { return ((r >> 1) & 1) << 2; };
+    // DMA pieces of a stage: 4 of X (8 rows x 128 B each), 4 of G; a lane fetches the same (row in stage, slot) in every stage
+    const int prl = lane >> 3, psl = lane & 7;
+    const char* zsrc = a.zero + lane * 16;
+    const char* xsrc[4]; const char* gsrc[4]; int xlim[4], glim[4];
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+        const int rl = 8 * pc + prl;
+        const int cx = bi * 64 + ((psl ^ swz(rl)) * 8), cg = bj * 64 + ((psl ^ swz(rl)) * 8);
+        xsrc[pc] = (const char*)J.X + ((size_t)(rbeg + rl) * J.ldX + cx) * 2;
+        gsrc[pc] = (const char*)J.G + ((size_t)(rbeg + rl) * J.ldG + cg) * 2;
+        xlim[pc] = cx < J.ldX ? rend - rbeg - rl : -(1 << 30);      // the piece's row is valid in stage c iff 32*c < lim
+        glim[pc] = cg < J.ldG ? rend - rbeg - rl : -(1 << 30);
+    }
+    const size_t xstride = (size_t)32 * J.ldX * 2, gstride = (size_t)32 * J.ldG * 2;
+    auto issue = [&](int c) {
+        const uint32_t base = lds_addr_of(ring + (c % WGR_NST) * WGR_STAGE);
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+            glds16(32 * c < xlim[pc] ? xsrc[pc] + (size_t)c * xstride : zsrc, (uint32_t)__builtin_amdgcn_readfirstlane((int)(base + (uint32_t)pc * 1024u)));
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+            glds16(32 * c < glim[pc] ? gsrc[pc] + (size_t)c * gstride : zsrc, (uint32_t)__builtin_amdgcn_readfirstlane((int)(base + 4096u + (uint32_t)pc * 1024u)));
+    };
+    f32x4 acc[4][4], accb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        accb[u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][u] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);      // bf16 1.0 x 8
+    const bool do_bias = bi == 0;
+    for (int c = 0; c < min(nstage, WGR_NST - 1); ++c) issue(c);
+    const int row_off = (4 * q + qp) * 128;
+    for (int c = 0; c < nstage; ++c) {
+        wait_vmem_but_ws(8 * min(WGR_NST - 2, nstage - 1 - c));     // stage c has landed; the (<= 2) younger stages may still fly
+        if (c + WGR_NST - 1 < nstage) issue(c + WGR_NST - 1);        // into the buffer stage c - 1 has left (its reads fed MFMAs already issued)
+        const char* xb = ring + (c % WGR_NST) * WGR_STAGE + row_off;
+        const char* gb = xb + 4096;
+        auto frag = [&](const char* base, int t) {       // tile t of the 64-feature block: P chunk 4*(t>>1)+p (swizzled by the row), half t&1
+            const char* p0 = base + ((((4 * (t >> 1)) ^ swz(qp)) + p) * 16) + 8 * (t & 1);
+            const v4s r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)p0);
+            const v4s r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(p0 + 16 * 128));
+            const uint2 lo = __builtin_bit_cast(uint2, r0), hi = __builtin_bit_cast(uint2, r1);
+            return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        };
+        uint4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = frag(gb, u);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint4 av = frag(xb, t);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = mfma16(av, g[u], acc[t][u]);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accb[u] = mfma16(ones, g[u], accb[u]);
+        }
+    }
+    // the waves' partial sums meet in LDS: each wave writes its 16 tiles into its own ring (conflict-free 16-byte stores), the bias row behind them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(f32x4*)(ring + ((t * 4 + u) * 64 + lane) * 16) = acc[t][u];
+    if (q == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *(float*)(ring + 16384 + (u * 16 + l16) * 4) = accb[u][0];
+    }
+    __syncthreads();
+    // thread (wave, lane) owns tile pairs n = 4*wave .. 4*wave+3 with the accumulator's lane map: i = 16t + 4q + ii, j = 16u + l16.
+    // All of a thread's 16 elements first (their sums, then theta / m / v requested in ONE batch), then the arithmetic, then the stores:
+    // element by element the epilogue was 16 dependent round trips to memory (33 us in the step for 0.24 M elements).
+    const int jg = bj * 64;
+    const LayerDesc L0 = a.layers[J.sub0];
+    const LayerDesc L1 = a.layers[J.sub1 >= 0 ? J.sub1 : J.sub0];
+    float gsum[16], pw[16], pm[16], pv[16];
+    size_t eidx[16];
+    bool eok[16];
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int n = 4 * wave + nn, t = n >> 2, u = n & 3;
+        f32x4 v = *(const f32x4*)(smem + (n * 64 + lane) * 16);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 o = *(const f32x4*)(smem + w * (WGR_NST * WGR_STAGE) + (n * 64 + lane) * 16);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        const bool second = J.sub1 >= 0 && jg + 16 * u >= J.split;       // (wave-uniform: the split is a multiple of 32 features)
+        const int joff = second ? L1.joff : L0.joff, Nout = second ? L1.Nout : L0.Nout, Kin = second ? L1.Kin : L0.Kin;
+        const size_t offW = second ? L1.offW : L0.offW;
+        const int jj = jg + 16 * u + l16 - joff;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = bi * 64 + 16 * t + 4 * q + ii, e = 4 * nn + ii;
+            eok[e] = jj >= 0 && jj < Nout && i < Kin;
+            eidx[e] = eok[e] ? offW + (size_t)i * Nout + jj : offW;
+            gsum[e] = v[ii];
+        }
+    }
+    if (a.c.on) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { pw[e] = a.param[eidx[e]]; pm[e] = a.mom[eidx[e]]; pv[e] = a.vel[eidx[e]]; }
+    }
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+        const int n = 4 * wave + nn, t = n >> 2, u = n & 3;
+        const bool second = J.sub1 >= 0 && jg + 16 * u >= J.split;
+        const int jj = jg + 16 * u + l16 - (second ? L1.joff : L0.joff);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = bi * 64 + 16 * t + 4 * q + ii, e = 4 * nn + ii;
+            if (eok[e]) {
+                a.grad[eidx[e]] = gsum[e];
+                if (a.c.on) {
+                    adam_math(pw[e], pm[e], pv[e], gsum[e], a.c);
+                    a.mom[eidx[e]] = pm[e];
+                    a.vel[eidx[e]] = pv[e];
+                    a.param[eidx[e]] = pw[e];
+                    if (second) image_refresh(L1, false, i, jj, pw[e]); else image_refresh(L0, false, i, jj, pw[e]);
+                }
+            }
+        }
+    }
+    if (do_bias && tid < 64) {
+        float b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) b += *(const float*)(smem + w * (WGR_NST * WGR_STAGE) + 16384 + tid * 4);
+        const int j = jg + tid;
+        const bool second = J.sub1 >= 0 && j >= J.split;
+        const LayerDesc L = second ? a.layers[J.sub1] : L0;
+        const int jj = j - L.joff;
+        if (jj >= 0 && jj < L.Nout) {
+            const size_t idx = L.offb + jj;
+            a.grad[idx] = b;
+            if (a.c.on) adam_element(L, true, 0, jj, idx, b, true, a.param, a.mom, a.vel, a.c);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // exports in the reference's [k, B, ...] order (iwae1.py:141-151), debug dumps
 // ---------------------------------------------------------------------------------
@@ -4361,6 +4563,25 @@ void launch_adam(const LayerDesc* layers, int nlayers, int nblocks, float* param
                  float alpha, float gscale, float beta1, float beta2, float eps, int do_update, hipStream_t st, int first_block) {
     const AdamCoef c = {alpha, gscale, beta1, beta2, eps, do_update};
     LAUNCH_EV(adam_kernel, dim3(nblocks), dim3(256), 0, st, layers, nlayers, param, grad, mom, vel, c, first_block);
+}
+void launch_wgrad_rows(const WgradRowsJob* jobs, int njobs, const LayerDesc* layers, float* grad, float* param, float* mom, float* vel, float alpha,
+                       float beta1, float beta2, float eps, int fuse_adam, const float* per_b, int B, float beta, float* scalars, const char* zero, hipStream_t st) {
+    WgradRowsArgs a;
+    memset(&a, 0, sizeof(a));
+    int wgs = 0;
+    for (int i = 0; i < njobs && i < WGR_MAX_JOBS; ++i) {
+        a.job[i] = jobs[i];
+        a.job[i].ib = (jobs[i].ldX + 63) / 64;
+        a.job[i].jb = (jobs[i].ldG + 63) / 64;
+        a.job[i].wg_begin = wgs;
+        wgs += a.job[i].ib * a.job[i].jb;
+    }
+    a.njobs = njobs;
+    a.layers = layers; a.grad = grad; a.param = param; a.mom = mom; a.vel = vel;
+    a.c = AdamCoef{alpha, 1.0f, beta1, beta2, eps, fuse_adam};
+    a.mn = MeansArgs{per_b, B, beta, scalars};
+    a.zero = zero;
+    LAUNCH_EV(wgrad_rows_kernel, dim3(wgs + (per_b ? 1 : 0)), dim3(256), (size_t)4 * WGR_NST * WGR_STAGE, st, a);
 }
 void launch_export_rows(const float* in, int B, int k, float* out, hipStream_t st) {
     hipLaunchKernelGGL(export_rows_kernel, grid1((size_t)B * k, 256), dim3(256), 0, st, in, B, k, out);

@@ -110,9 +110,10 @@ static int load_rccl() {
     } while (0)
 
 // kernels iwae_enable_timing brackets with HIP events (on the stream each is launched on); names: iwae_kernel_time
-enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_DEC_BWD, T_COUNT };
+enum TimedKernel { T_OUT_BWD = 0, T_DEC_FWD, T_WGRAD_OUT, T_DX_HID, T_DX_LAT, T_WGRAD_HID, T_WGRAD_LAT, T_LATENT_BWD, T_ENC_FWD, T_REDUCE, T_DEC_BWD, T_AR_ENC, T_AR_DEC, T_COUNT };
 static const char* const kTimedNames[T_COUNT] = {"out_bwd", "decoder_fwd", "wgrad_out", "dx_hidden", "dx_latent", "wgrad_hidden", "wgrad_latent",
-                                                 "latent_bwd", "encoder_fwd", "reduce_adam", "decoder_bwd"};
+                                                 "latent_bwd", "encoder_fwd", "reduce_adam", "decoder_bwd",
+                                                 "allreduce_enc", "allreduce_dec"};      // (the data-parallel step's two ncclAllReduce calls, each on its own stream)
 
 struct iwae_model {
     iwae_config cfg;
@@ -170,6 +171,7 @@ struct iwae_model {
     int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
     bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
     bool allow_wg3 = true;                           // few rows: the decoder's three weight gradients as one grouped launch (option no_wg3)
+    bool allow_wgrad_rows = true;                    // few rows (<= 2 048): the image encoder's weight gradients + Adam in ONE launch, whole row reduction per workgroup (wgrad_rows_kernel; option no_wgrad_rows)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
@@ -615,7 +617,8 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
 // dx_done: the dX chain (dhead -> d2 -> d1 -> dx) has been computed already (gblock_bwd_kernel): only the weight gradients are left
-int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false, hipStream_t side_st = nullptr) {
+int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false, hipStream_t side_st = nullptr,
+              bool skip_wgrad = false) {
     bool chain_fused = dx_done;
     if (dx_done) need_dx = false;
     if (!dx_done && m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
@@ -632,6 +635,7 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
         CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
     }
     if (need_dx) CHK(dense_dx(m, blk[0], ptr<uint16_t>(w.d1P), R, nullptr, nullptr, ptr<float>(w.dx)));
+    if (skip_wgrad) { HIPCHK(hipGetLastError()); return IWAE_OK; }      // (the caller takes the weight gradients: block_wgrad_rows)
     const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
     const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
     Linear* ls[3] = {&blk[2], &blk[1], &blk[0]};
@@ -662,6 +666,32 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
     } else {
         for (int i = 0; i < 3; ++i) launch_wgradp(g.a[i], nsplit[i], nw[i], ws);
     }
+    HIPCHK(hipGetLastError());
+    return IWAE_OK;
+}
+
+// Few rows (the image encoder: R = batch size): the block's three weight gradients with the whole row reduction inside each workgroup and
+// (fuse) the Adam update in the epilogue -- one launch instead of the grouped weight gradient + slabs + reduce_grads_kernel (round 4).
+// with_means: one extra block turns the step's per-image values into its batch means (what reduce_grads_kernel's extra block did).
+bool wgrad_rows_ok(const iwae_model* m, const Linear* blk, int R) {
+    return m->allow_wgrad_rows && R <= 2048 && blk[0].nsub == 1 && blk[1].nsub == 1 && blk[2].nsub <= 2;
+}
+int block_wgrad_rows(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, float alpha, bool fuse, bool with_means) {
+    if (m->descs_dirty) CHK(build_descs(m));
+    const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
+    const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
+    Linear* ls[3] = {&blk[2], &blk[1], &blk[0]};
+    WgradRowsJob jobs[3];
+    memset(jobs, 0, sizeof(jobs));
+    for (int i = 0; i < 3; ++i) {
+        jobs[i].X = xs[i]; jobs[i].ldX = ls[i]->Kp32; jobs[i].G = gs[i]; jobs[i].ldG = ls[i]->Np32; jobs[i].R = R;
+        jobs[i].sub0 = ls[i]->sub[0];
+        jobs[i].sub1 = ls[i]->nsub == 2 ? ls[i]->sub[1] : -1;
+        jobs[i].split = ls[i]->nsub == 2 ? ls[i]->joff[1] : (1 << 30);
+    }
+    const bool two = m->cfg.n_layers == 2;
+    launch_wgrad_rows(jobs, 3, m->d_descs, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0,
+                      with_means ? ptr<float>(m->per_b) : nullptr, m->B, two ? 1.f : m->beta, m->d_scalars, m->d_zero, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -698,6 +728,12 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
     HIPCHK(hipGetLastError());
     tg.valid = true; tg.step = step; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
     return IWAE_OK;
+}
+
+// the stream that carries the speculative draw of the NEXT step's noise: one that this step's backward pass orders behind the main stream
+// and whose last event the next forward joins (see the call in forward_impl; m->early_wout must be decided)
+hipStream_t eps_draw_stream(const iwae_model* m, int M) {
+    return (m->allow_wg3 && m->use_side2 && m->side2 && M <= 4096 && m->early_wout) ? m->side2 : m->side;
 }
 
 int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd,
@@ -1020,9 +1056,13 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // The NEXT step's noise (speculating step + 1 with the same batch shape; the tag is checked on use): drawn now, on the side
         // stream, idle until the backward pass forks -- enqueued behind the decoder kernel so that its dispatch does not delay that one
         // (few rows, where the backward pass launches the decoder's weight gradients as one group on the SECOND side stream and `side` carries nothing
-        // that a later event would cover: the draw goes to that second stream, in front of the group and the decoder update whose event the next step waits for)
+        // that a later event would cover: the draw goes to that second stream, in front of the group and the decoder update whose event the next step waits for.
+        // Round 4 (advisor finding): the choice must follow what the backward pass will really use.  It touches `side2` only when the output layer's
+        // gradient forks early (early_wout, known here); without that -- hidden widths without a stored-s instantiation, options out_recompute /
+        // no_early_wout -- everything runs on `side`, the stream whose event the next step joins and which is re-ordered behind the main stream every
+        // step (the ring slot written here was last read by step t - 2's backward pass on the main stream).)
         if (bwd && keep_eps && m->side)
-            CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, (m->allow_wg3 && m->use_side2 && M <= 4096) ? m->side2 : m->side, m->eps_blocks));
+            CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, eps_draw_stream(m, M), m->eps_blocks));
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
     }
 
@@ -1175,7 +1215,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             g3.zbeg[i + 1] = g3.zbeg[i] + ns[i];
         }
         g3.n = 3;
-        g3.a[0].rowscale = ptr<float>(m->lse_dup ? m->gx2 : m->gx);
+        g3.a[0].rowscale = ptr<float>(m->gx);      // (the main stream's row weights: this group waits for ev_fork2, i.e. for the main stream -- never the side stream's copy)
     }
     if (group3) {
         HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
@@ -1309,8 +1349,13 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
-    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false));
+    // Round 4: on few rows the image encoder's weight gradients, their sum over ALL rows and (fused step) the Adam update are one launch
+    // (wgrad_rows_kernel) -- the encoder's layers (the head of the table) then need no slabs and no share of reduce_grads_kernel
+    const bool rows_enc = wgrad_rows_ok(m, m->enc1, B);
+    CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false, false, nullptr, rows_enc));
     if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
+    const int enc_end = m->enc1[2].sub[m->enc1[2].nsub - 1] + 1;      // first table entry behind the image encoder's layers
+    const int rb_lo = !rows_enc ? 0 : enc_end < (int)m->descs.size() ? m->descs[enc_end].rblock_begin : m->reduce_blocks;
     // split (data-parallel step, iwae_forward_backward_split): the decoder's layers are summed into the flat gradient on the
     // side stream, right behind their weight gradients, and NOT joined here -- the caller's all-reduce of that segment is
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
@@ -1340,9 +1385,14 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         }
     }
     {
+        // the main stream's share of the table: [rb_lo, rb_hi) -- empty when wgrad_rows_kernel took the encoder and everything else is
+        // deferred to the side streams (the full-size 1- and 2-layer steps): then that kernel's extra block makes the batch means too
+        const int rb_hi = (defer || early) ? m->early_first : defer2 ? m->early_first2 : m->reduce_blocks;
         ScopedTimer tm_red(m, T_REDUCE);
-        launch_reduce_grads(m->d_descs, (int)m->descs.size(), 0, (defer || early) ? m->early_first : defer2 ? m->early_first2 : m->reduce_blocks, m->grad, m->param, m->mom, m->vel,
-                            alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+        if (rows_enc) CHK(block_wgrad_rows(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, alpha, fuse, rb_hi <= rb_lo));
+        if (!rows_enc || rb_hi > rb_lo)
+            launch_reduce_grads(m->d_descs, (int)m->descs.size(), rb_lo, rb_hi - rb_lo, m->grad, m->param, m->mom, m->vel,
+                                alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
     }
     if (early && !split) CHK(join_side(m));
     if (defer2 && m->tail == m->side2 && m->tail != m->side && m->allow_defer2_split && m->dec2[0].nsub == 1 && m->dec1[0].nsub == 1 && m->dec1[2].nsub == 1) {
@@ -1567,6 +1617,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     if (!eps) {       // the step's draws, kept for the backward pass and the 2-layer densities (same generator as the bf16 path)
         const int np = (m->epsc_par + 1) % 3;
         if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+        if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));      // (a bf16 step's speculative draw may sit on either side stream)
         CHK(draw_eps(m, np, m->noise_step, M, st));
         if (m->eval_k_total > 0) m->eps_tag[np].valid = false;      // a k-chunk's draws: the tag (step, offset, rows) does not describe them
         m->epsc_par = np;
@@ -1809,17 +1860,17 @@ int dp_finish(iwae_model* m, float lr) {
         // event recorded after it -- a wait that is normally already satisfied.  (Round 3 first had them the other way round: the main
         // stream's update and the next encoder forward then waited for the decoder's reduction, +22 us per step in the one-rank
         // rehearsal.)  Every rank enqueues them in this order.  Option dp_concurrent = 1 drops the wait.
-        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream));
+        { ScopedTimer tm(m, T_AR_ENC); NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream)); }
         if (!m->dp_concurrent) HIPCHK(hipEventRecord(m->ev_ar, m->stream));
         launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
         if (!m->dp_concurrent) HIPCHK(hipStreamWaitEvent(m->tail, m->ev_ar, 0));
-        NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail));
+        { ScopedTimer tm(m, T_AR_DEC, m->tail); NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail)); }
         set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
                     m->tail, b0);
     } else {
         CHK(join_side(m));
-        NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, n, ncclFloat32, ncclSum, m->comm_main, m->stream));
+        { ScopedTimer tm(m, T_AR_ENC); NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, n, ncclFloat32, ncclSum, m->comm_main, m->stream)); }
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
     }
     HIPCHK(hipGetLastError());
@@ -2172,6 +2223,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
+    else if (n == "no_wgrad_rows") m->allow_wgrad_rows = !on;         // few rows: the encoder's weight gradients as the grouped launch + slabs + reduce_grads_kernel
     else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
@@ -2266,14 +2318,22 @@ int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes) {
     return IWAE_OK;
 }
 
-int iwae_comm_init(iwae_handle m, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank) {
+// Everything iwae_comm_init can refuse WITHOUT talking to another rank: arguments, handle state, RCCL loadable.  ncclCommInitRank is itself
+// a blocking rendezvous: a rank that fails one of these checks must not leave the others inside it, so callers agree on the preflight's
+// outcome first (iwae_amd/parallel.py::init_in_library_exchange) and only then enter iwae_comm_init together.
+int iwae_comm_preflight(iwae_handle m, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank) {
     if (!m || !unique_id || id_bytes != 2 * sizeof(ncclUniqueId)) return fail(IWAE_ERR_ARG, "comm_init: bad id blob (iwae_comm_unique_id makes it)");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(IWAE_ERR_ARG, "comm_init: need 0 <= rank < world_size");
     if (world_size != m->cfg.world_size || rank != m->cfg.rank)
         return fail(IWAE_ERR_ARG, "comm_init: world_size / rank differ from the iwae_config this handle was created with");
     if (m->comm_main) return fail(IWAE_ERR_STATE, "comm_init: communicators already exist (iwae_comm_destroy first)");
-    HIPCHK(hipSetDevice(m->cfg.device));
     CHK(load_rccl());
+    return IWAE_OK;
+}
+
+int iwae_comm_init(iwae_handle m, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank) {
+    CHK(iwae_comm_preflight(m, unique_id, id_bytes, world_size, rank));
+    HIPCHK(hipSetDevice(m->cfg.device));
     CHK(join_side(m));
     HIPCHK(hipStreamSynchronize(m->stream));
     ncclUniqueId ids[2];

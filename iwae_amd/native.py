@@ -131,6 +131,11 @@ class NativeModel:
         check(self.lib.iwae_comm_init(self.h, blob, len(blob), int(world_size), int(rank)))
         self.comm = True
 
+    def comm_preflight(self, unique_id, world_size, rank):
+        """The non-collective checks of comm_init (arguments, state, RCCL loadable); raises like comm_init would, without the rendezvous."""
+        blob = bytes(unique_id)
+        check(self.lib.iwae_comm_preflight(self.h, blob, len(blob), int(world_size), int(rank)))
+
     def comm_info(self):
         """(world size, rank) as RCCL reports them for the handle's communicators; (0, -1) without communicators."""
         w, r = C.c_int32(), C.c_int32()

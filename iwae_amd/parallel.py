@@ -94,7 +94,8 @@ def all_ranks_ok(ok, group=None, device=None):
 
 def init_in_library_exchange(net, rank, world_size, group=None, device=None):
     """Brings up the library's own RCCL communicators on every rank, or on none: the id blob (or rank 0's failure) reaches every
-    rank, every rank attempts comm_init, and the outcome is agreed on collectively.  Returns None on success, else the reason as
+    rank, every rank runs the non-collective preflight and the ranks agree on it, then every rank enters comm_init (the rendezvous) and the
+    outcome is agreed on collectively once more.  Returns None on success, else the reason as
     a string -- the SAME decision on every rank, with the communicators of the ranks that did succeed destroyed again, so no rank
     is left issuing ncclAllReduce while another issues something else (a rank-asymmetric failure used to be a hang)."""
     err = None
@@ -102,6 +103,14 @@ def init_in_library_exchange(net, rank, world_size, group=None, device=None):
         blob = share_comm_id(type(net).comm_unique_id, rank, group)
     except Exception as e:              # noqa: BLE001 -- identical on every rank (see share_comm_id)
         return str(e)
+    # ncclCommInitRank is a blocking rendezvous: a rank that would refuse before reaching it (RCCL not loadable, world / rank mismatch,
+    # communicators already there) must say so BEFORE anyone enters it -- a non-collective preflight, agreed on collectively
+    try:
+        net.comm_preflight(blob, world_size, rank)
+    except Exception as e:              # noqa: BLE001
+        err = "rank %d: comm_init refused: %s: %s" % (rank, type(e).__name__, e)
+    if not all_ranks_ok(err is None, group, device):
+        return err or ("rank %d: ready, but another rank refused comm_init before the rendezvous" % rank)
     try:
         net.comm_init(blob, world_size, rank)
     except Exception as e:              # noqa: BLE001

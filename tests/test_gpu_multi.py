@@ -27,8 +27,22 @@ def test_two_gpu_in_library_exchange_matches_one_gpu_full_batch(gpu, tmp_path, l
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_gpu_worker.py"), str(r), str(world), str(port), outs[r]], env=env)
              for r in range(world)]
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+    # poll all children together: fail as soon as one exits non-zero, and never leave a child behind holding a GPU / sitting in a rendezvous
+    import time
+    try:
+        deadline = time.time() + 600
+        while True:
+            codes = [p.poll() for p in procs]
+            assert all(c in (None, 0) for c in codes), "a rank exited with %s" % codes
+            if all(c == 0 for c in codes):
+                break
+            assert time.time() < deadline, "2-GPU ranks did not finish in 600 s"
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     r0, r1 = np.load(outs[0]), np.load(outs[1])
     # replicas stay bit-identical: same summed gradient, same Adam on every rank
     np.testing.assert_array_equal(r0["params"], r1["params"])

@@ -166,8 +166,8 @@ class _FakeNet:
     """Stands in for NativeModel in the host-logic tests of the exchange initialisation (no GPU, no RCCL)."""
     fail_id = False
 
-    def __init__(self, fail_init):
-        self.fail_init, self.inited, self.destroyed = fail_init, False, False
+    def __init__(self, fail_init, fail_preflight=False):
+        self.fail_init, self.fail_preflight, self.inited, self.destroyed, self.entered = fail_init, fail_preflight, False, False, False
 
     @classmethod
     def comm_unique_id(cls):
@@ -175,8 +175,18 @@ class _FakeNet:
             raise OSError("librccl.so: cannot open shared object file")
         return bytes(range(256))
 
+    def comm_preflight(self, blob, world, rank):      # iwae_comm_preflight: what comm_init can refuse without another rank
+        assert blob == bytes(range(256))
+        if self.fail_preflight:
+            raise RuntimeError("comm_init: communicators already exist (iwae_comm_destroy first)")
+
     def comm_init(self, blob, world, rank):
         assert blob == bytes(range(256))
+        self.entered = True
+        # ncclCommInitRank is a blocking rendezvous: model it -- a rank that never arrives would leave the others here (the test would
+        # time out), which is exactly what the agreed preflight in front of it has to rule out
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.barrier()
         if self.fail_init:
             raise RuntimeError("ncclCommInitRank: unhandled system error")
         self.inited = True
@@ -199,6 +209,8 @@ def _dp_init_worker(rank, world, port, scenario, q):
         net = _FakeNetNoId(False)
     elif scenario == "init_fails_on_rank1":      # rank-asymmetric failure: rank 0's communicators are given back, everyone raises
         net = _FakeNet(rank == 1)
+    elif scenario == "preflight_fails_on_rank1": # rank 1 would refuse BEFORE the rendezvous: nobody may enter it (round-3 advisor finding)
+        net = _FakeNet(False, fail_preflight=(rank == 1))
     else:
         net = _FakeNet(False)
     out = {"rank": rank}
@@ -207,7 +219,7 @@ def _dp_init_worker(rank, world, port, scenario, q):
         out.update(raised=False, path=dp.path, in_library=dp.in_library)
     except RuntimeError as e:
         out.update(raised=True, msg=str(e))
-    out.update(inited=net.inited, destroyed=net.destroyed)
+    out.update(inited=net.inited, destroyed=net.destroyed, entered=net.entered)
     # whatever happened, the ranks are still in step: one more collective must complete
     t = torch.ones(1)
     dist.all_reduce(t)
@@ -216,7 +228,7 @@ def _dp_init_worker(rank, world, port, scenario, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", ["ok", "id_fails_on_rank0", "init_fails_on_rank1"])
+@pytest.mark.parametrize("scenario", ["ok", "id_fails_on_rank0", "init_fails_on_rank1", "preflight_fails_on_rank1"])
 def test_exchange_initialisation_is_collective_and_never_falls_back_silently(scenario):
     """world 2 over gloo.  A failing RCCL initialisation -- rank 0 cannot make the id, or comm_init fails on ONE rank -- must
     raise on EVERY rank (no rank left behind in a broadcast, none on a different exchange path), with the communicators of
@@ -239,6 +251,8 @@ def test_exchange_initialisation_is_collective_and_never_falls_back_silently(sce
         assert all("in-library RCCL exchange could not be initialised" in o["msg"] for o in outs)
         if scenario == "id_fails_on_rank0":
             assert all("librccl.so" in o["msg"] and not o["inited"] for o in outs)
+        elif scenario == "preflight_fails_on_rank1":
+            assert all(not o["entered"] and not o["inited"] for o in outs), outs      # no rank entered the rendezvous
         else:
             assert outs[0]["inited"] and outs[0]["destroyed"] and not outs[1]["inited"]      # rank 0 gave its communicators back
 

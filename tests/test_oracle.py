@@ -184,3 +184,65 @@ def test_conditional_prior_closed_form_matches_autograd():
         for (a, b), (c, d) in zip(g, gt):
             assert np.max(np.abs(a - c)) < 1e-12 and np.max(np.abs(b - d)) < 1e-12
         assert (np.abs(g[7][0]).max() == 0.0) == (obj == "vae_elbo_kl")
+
+
+# ---------------------------------------------------------------- third-party pin of the TFP semantics (missing #4)
+def test_log_densities_match_torch_distributions():
+    """The oracle's log-density formulas (oracle/iwae_np.py, re-typed in oracle/iwae_torch.py) restate the published semantics of
+    tfd.Normal.log_prob, tfd.Bernoulli(logits).log_prob and tfd.kl_divergence (reference call sites: src/iwae1.py:105-116).  TensorFlow
+    Probability is not installed; torch.distributions is an INDEPENDENT implementation of the same distributions: element by element."""
+    import torch.distributions as D
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((5, 9, 13)) * 3.0
+    loc = rng.standard_normal((9, 13))
+    scale = np.exp(rng.standard_normal((9, 13))) + 1e-6
+    got = O.normal_log_prob(x, loc[None], scale[None])
+    ref = D.Normal(torch.from_numpy(loc), torch.from_numpy(scale)).log_prob(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # Bernoulli(logits): binary targets (the reference's binarised pixels) over a wide range of logits, incl. +-40 (softplus tails)
+    logits = np.concatenate([rng.standard_normal(200) * 8.0, [-40.0, 40.0, 0.0, -1e-9, 700.0, -700.0]])
+    xb = (rng.random(logits.shape) < 0.5).astype(np.float64)
+    got = O.bernoulli_log_prob(xb, logits)
+    ref = D.Bernoulli(logits=torch.from_numpy(logits)).log_prob(torch.from_numpy(xb)).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(O.sigmoid(logits), torch.sigmoid(torch.from_numpy(logits)).numpy(), rtol=1e-12, atol=1e-15)      # (tanh form: absolute, not relative, in the far tail)
+    # KL(N(mu, sigma) || N(0, 1)), the closed form TFP registers for two Normals (iwae1.py:116)
+    got = O.kl_normal_std(loc, scale)
+    ref = D.kl_divergence(D.Normal(torch.from_numpy(loc), torch.from_numpy(scale)), D.Normal(torch.zeros(9, 13, dtype=torch.float64), torch.ones(9, 13, dtype=torch.float64))).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-10, atol=1e-12)
+    # utils.py:6-8 against torch.logsumexp
+    lw = rng.standard_normal((50, 11)) * 30.0 - 300.0
+    np.testing.assert_allclose(O.logmeanexp(lw, 0), (torch.logsumexp(torch.from_numpy(lw), 0) - np.log(50.0)).numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("beta", [1.0, 0.7])
+def test_forward_dict_matches_a_torch_distributions_restatement(beta):
+    """src/iwae1.py:98-151 written a THIRD time, with torch.distributions objects where the reference uses tfd objects (Normal(...).log_prob,
+    Bernoulli(logits=...).log_prob, kl_divergence, softmax, logsumexp) instead of hand-typed formulas: every entry of the result dict."""
+    import torch.distributions as D
+    x, P, eps = MG.inputs(1, 16, 4, 48, 6, 9, 11)
+    res = O.forward_1layer(P, x, eps, beta)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    (W1, b1), (W2, b2), (Wm, bm), (Ws, bs), (V1, c1), (V2, c2), (V3, c3) = [(t(W), t(b)) for W, b in P]
+    xt, et = t(x), t(eps)
+    h = torch.tanh(torch.tanh(xt @ W1 + b1) @ W2 + b2)
+    qzx = D.Normal(h @ Wm + bm, torch.exp(h @ Ws + bs) + 1e-6)                    # iwae1.py:31-44
+    z = qzx.loc + qzx.scale * et                                                   # :59 (the draw made explicit)
+    pxz = D.Bernoulli(logits=torch.tanh(torch.tanh(z @ V1 + c1) @ V2 + c2) @ V3 + c3)   # :79-85
+    pz = D.Normal(torch.zeros_like(qzx.loc), torch.ones_like(qzx.loc))
+    lpz = pz.log_prob(z).sum(-1)                                                   # :107
+    lqzx = qzx.log_prob(z).sum(-1)                                                 # :109
+    lpxz = pxz.log_prob(xt.expand(eps.shape[0], *xt.shape)).sum(-1)                # :111
+    log_w = lpxz + beta * (lpz - lqzx)                                             # :113
+    kl = D.kl_divergence(qzx, pz).sum(-1)                                          # :116
+    k = eps.shape[0]
+    want = {
+        "vae_elbo": log_w.mean(0).mean(),                                          # :120
+        "vae_elbo_kl": (lpxz.mean(0) - beta * kl).mean(),                          # :121
+        "iwae_elbo": (torch.logsumexp(log_w, 0) - np.log(k)).mean(),               # :125, utils.py:6-8
+        "iwae_eq14": (torch.softmax(log_w, 0) * log_w).sum(0).mean(),              # :128-134
+        "snis_z": (torch.softmax(log_w, 0).unsqueeze(-1) * z).sum(0),              # :137-139
+        "lpxz": lpxz, "lpz": lpz, "lqzx": lqzx, "z": z, "logits": pxz.logits,
+    }
+    for key, v in want.items():
+        np.testing.assert_allclose(res[key], v.numpy(), rtol=1e-10, atol=1e-10, err_msg=key)
