@@ -4171,57 +4171,93 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradRowsArgs a) {
         for (int u = 0; u < 4; ++u) *(float*)(ring + 16384 + (u * 16 + l16) * 4) = accb[u][0];
     }
     __syncthreads();
-    // thread (wave, lane) owns tile pairs n = 4*wave .. 4*wave+3 with the accumulator's lane map: i = 16t + 4q + ii, j = 16u + l16.
-    // All of a thread's 16 elements first (their sums, then theta / m / v requested in ONE batch), then the arithmetic, then the stores:
-    // element by element the epilogue was 16 dependent round trips to memory (33 us in the step for 0.24 M elements).
+    // Epilogue.  Thread (wave, lane) owns, of the 64 x 64 block, the i-tiles t = 2s, 2s+1 (s = wave >> 1: one 32-in-feature k-step) and the
+    // j-tiles u = 2(wave & 1), +1 with the accumulator's lane map: i = 64 bi + 16t + 4q + ii, j = 64 bj + 16u + l16 -- 16 elements, of which
+    // the 8 of one u (two tiles x four in-features) are ONE 16-byte chunk of the forward weight image (layout.h: a lane's 8 values of a
+    // k-step).  All sums first, then theta / m / v requested in one batch, the arithmetic, the stores; the new weights go into the images as
+    // 16-byte stores -- the forward image straight from registers, the backward image (rows = in-features) through a bf16 tile in LDS.
+    // (Element by element with 2-byte image stores the epilogue was 16 dependent round trips and ~100 scattered stores per thread: 15 of
+    // the kernel's 18 us.)
     const int jg = bj * 64;
     const LayerDesc L0 = a.layers[J.sub0];
     const LayerDesc L1 = a.layers[J.sub1 >= 0 ? J.sub1 : J.sub0];
+    const int s2 = wave >> 1, u0 = 2 * (wave & 1);
     float gsum[16], pw[16], pm[16], pv[16];
     size_t eidx[16];
     bool eok[16];
+    char* tileB = smem + 20480;                 // bf16 [64 in-features][64 out-features], pitch 144 B (behind wave 0's tiles and bias row)
+    constexpr int TB_PITCH = 144;
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-        const int n = 4 * wave + nn, t = n >> 2, u = n & 3;
-        f32x4 v = *(const f32x4*)(smem + (n * 64 + lane) * 16);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const f32x4 o = *(const f32x4*)(smem + w * (WGR_NST * WGR_STAGE) + (n * 64 + lane) * 16);
-            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        }
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = u0 + uu;
         const bool second = J.sub1 >= 0 && jg + 16 * u >= J.split;       // (wave-uniform: the split is a multiple of 32 features)
         const int joff = second ? L1.joff : L0.joff, Nout = second ? L1.Nout : L0.Nout, Kin = second ? L1.Kin : L0.Kin;
         const size_t offW = second ? L1.offW : L0.offW;
         const int jj = jg + 16 * u + l16 - joff;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = bi * 64 + 16 * t + 4 * q + ii, e = 4 * nn + ii;
-            eok[e] = jj >= 0 && jj < Nout && i < Kin;
-            eidx[e] = eok[e] ? offW + (size_t)i * Nout + jj : offW;
-            gsum[e] = v[ii];
+        for (int tt = 0; tt < 2; ++tt) {
+            const int n = (2 * s2 + tt) * 4 + u;
+            f32x4 v = *(const f32x4*)(smem + (n * 64 + lane) * 16);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 o = *(const f32x4*)(smem + w * (WGR_NST * WGR_STAGE) + (n * 64 + lane) * 16);
+                v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = bi * 64 + 32 * s2 + 16 * tt + 4 * q + ii, e = 8 * uu + 4 * tt + ii;
+                eok[e] = jj >= 0 && jj < Nout && i < Kin;
+                eidx[e] = eok[e] ? offW + (size_t)i * Nout + jj : offW;
+                gsum[e] = v[ii];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        pw[e] = a.param[eidx[e]];
+        if (a.c.on) { pm[e] = a.mom[eidx[e]]; pv[e] = a.vel[eidx[e]]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        if (eok[e]) {
+            a.grad[eidx[e]] = gsum[e];
+            if (a.c.on) {
+                adam_math(pw[e], pm[e], pv[e], gsum[e], a.c);
+                a.mom[eidx[e]] = pm[e];
+                a.vel[eidx[e]] = pv[e];
+                a.param[eidx[e]] = pw[e];
+            }
+        } else {
+            pw[e] = 0.0f;          // pad rows / columns of the images stay zero
         }
     }
     if (a.c.on) {
+        // forward image (rows = out-features): this lane's 8 in-features of k-step (64 bi + 32 s2) / 32 for out-feature j
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { pw[e] = a.param[eidx[e]]; pm[e] = a.mom[eidx[e]]; pv[e] = a.vel[eidx[e]]; }
-    }
+        for (int uu = 0; uu < 2; ++uu) {
+            const int jl = 16 * (u0 + uu) + l16, j = jg + jl;
+            const int kf0 = bi * 64 + 32 * s2 + 4 * q;
+            const uint4 ch = make_uint4(pack2(pw[8 * uu + 0], pw[8 * uu + 1]), pack2(pw[8 * uu + 2], pw[8 * uu + 3]),
+                                        pack2(pw[8 * uu + 4], pw[8 * uu + 5]), pack2(pw[8 * uu + 6], pw[8 * uu + 7]));
+            if (j < J.ldG && kf0 < 32 * L0.KT_F) *(uint4*)(L0.imgF + img_mg_byte(j, kf0, L0.KT_F)) = ch;
+            if (L0.imgB) {
 #pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-        const int n = 4 * wave + nn, t = n >> 2, u = n & 3;
-        const bool second = J.sub1 >= 0 && jg + 16 * u >= J.split;
-        const int jj = jg + 16 * u + l16 - (second ? L1.joff : L0.joff);
+                for (int tt = 0; tt < 2; ++tt) {      // tile [in-feature 32 s2 + 16 tt + 4q + ii][out-feature jl]
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = bi * 64 + 16 * t + 4 * q + ii, e = 4 * nn + ii;
-            if (eok[e]) {
-                a.grad[eidx[e]] = gsum[e];
-                if (a.c.on) {
-                    adam_math(pw[e], pm[e], pv[e], gsum[e], a.c);
-                    a.mom[eidx[e]] = pm[e];
-                    a.vel[eidx[e]] = pv[e];
-                    a.param[eidx[e]] = pw[e];
-                    if (second) image_refresh(L1, false, i, jj, pw[e]); else image_refresh(L0, false, i, jj, pw[e]);
+                    for (int ii = 0; ii < 4; ++ii)
+                        *(uint16_t*)(tileB + (32 * s2 + 16 * tt + 4 * q + ii) * TB_PITCH + jl * 2) = (uint16_t)(pack2(pw[8 * uu + 4 * tt + ii], 0.0f) & 0xffffu);
                 }
+            }
+        }
+        if (L0.imgB) {      // backward image (rows = in-features, k = out-feature space): 512 chunks of 16 bytes per block, two per thread
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int c = tid + 256 * r, il = c >> 3, sp = (c >> 2) & 1, qq = c & 3;
+                const int i = bi * 64 + il, kf0 = jg + 32 * sp + 4 * qq;
+                const uint2 lo = *(const uint2*)(tileB + il * TB_PITCH + (32 * sp + 4 * qq) * 2);
+                const uint2 hi = *(const uint2*)(tileB + il * TB_PITCH + (32 * sp + 16 + 4 * qq) * 2);
+                if (i < J.ldX && kf0 < 32 * L0.KT_B) *(uint4*)(L0.imgB + img_mg_byte(i, kf0, L0.KT_B)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
         }
     }

@@ -674,7 +674,7 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
 // (fuse) the Adam update in the epilogue -- one launch instead of the grouped weight gradient + slabs + reduce_grads_kernel (round 4).
 // with_means: one extra block turns the step's per-image values into its batch means (what reduce_grads_kernel's extra block did).
 bool wgrad_rows_ok(const iwae_model* m, const Linear* blk, int R) {
-    return m->allow_wgrad_rows && R <= 2048 && blk[0].nsub == 1 && blk[1].nsub == 1 && blk[2].nsub <= 2;
+    return m->allow_wgrad_rows && R <= 2048 && blk[0].nsub == 1 && blk[1].nsub == 1 && blk[2].nsub <= 2 && !blk[0].kmajor && !blk[1].kmajor && !blk[2].kmajor;      // (its epilogue writes MG-major images)
 }
 int block_wgrad_rows(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, float alpha, bool fuse, bool with_means) {
     if (m->descs_dirty) CHK(build_descs(m));
