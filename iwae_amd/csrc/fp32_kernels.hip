@@ -5,6 +5,7 @@
 // gradients rel 1e-4 against the float64 oracle) and for the k = 5000 evaluator; the bf16 kernels in kernels.hip are the fast path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace iwae {
@@ -331,6 +332,271 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
                 *dst = a.accumulate ? *dst + v : v;
             }
         }
+}
+
+// ---------------------------------------------------------------------------------
+// dec_fwd_f32_kernel (round 4): the WHOLE decoder forward in float32 -- z -> tanh -> tanh -> logits -> log p(x|z) (src/iwae1.py:79-85,111) --
+// in one launch, row-block stationary like the bf16 path's decoder kernel.  Before: three launches of the generic GEMM (88 TFLOP/s on the
+// 784-wide product, 53 on the 200-wide ones: tiles of 7-13 k-steps pay their prologue, epilogue and a float32 round trip of every activation
+// through HBM) = 0.35 of the f32 MFMA peak for the k = 5000 evaluator.
+//   * a wave owns 16 data rows through all three layers; a workgroup = 4 waves = 64 rows, 80.9 KB of LDS -> two independent workgroups per
+//     CU (two waves per SIMD in different phases: one's epilogue arithmetic runs beside the other's MFMAs);
+//   * v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact float32 products): the wave's accumulators are ALL out-feature tiles of its
+//     rows (<= 13 tiles = 208 features per pass; the 784 pixels take 4 passes of 13/12 tiles), A operand = its rows' activations from its
+//     PRIVATE strip of LDS, B operand = the layer's weights, streamed 16 in-features at a time through two shared LDS slabs by LDS-DMA
+//     straight from the float32 master parameters (Keras [in][out] rows: a slab is 16 contiguous row segments);
+//   * because a wave holds the whole layer output of its rows in registers, the layer's activations are dead when its k loop ends: the
+//     next layer's input OVERWRITES them in place (one 16 x 212 float strip per wave for z, g1, g2 in turn);
+//   * lane quad q contracts k = 4j + q in MFMA step j (the instruction's natural order): a slab row pitch of 208 floats puts quads q, q + 1
+//     16 banks apart (conflict-free ds_read_b32), and the activations are stored k-permuted inside each 16-block (position 4(k&3) + (k>>2))
+//     so that a lane's four k values of a block are ONE ds_read_b128;
+//   * epilogues: bias + tanh (one hardware exp2) -> the strip [+ g1 / g2 rows for the backward pass]; output layer: log p(x|z) summed per
+//     row in registers over the passes (a wave owns whole rows: no partial sums, no cross-wave reduction) [+ s = x - sigmoid(l)].
+// ---------------------------------------------------------------------------------
+#ifdef IWAE_DENSE_STAMPS      // diagnostic build (STAMPS=1): per-wave cycle sums of the kernel's phases -> a.stamps[wave][8]
+#define DF_STAMP(slot)                                                                 \
+    {                                                                                  \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        df_sum[slot] += t_ - df_prev;                                                  \
+        df_prev = t_;                                                                  \
+    }
+#else
+#define DF_STAMP(slot)
+#endif
+#define DF_TP 13                    // out-feature tiles (16 each) a wave accumulates per pass
+#define DF_PA 212                   // activation strip pitch in floats (= 4 * 53: rows fall into different bank quads for ds_read_b128)
+#define DF_SLAB (16 * 16 * DF_TP)   // floats per weight slab: 16 in-features x 208 out-features
+__device__ __forceinline__ void df_glds16(const char* g, uint32_t lds_wave_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_wave_base) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void dec_fwd_f32_kernel(DecFwdF32Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_df[];
+#ifdef IWAE_DENSE_STAMPS
+    unsigned long long df_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, df_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(df_prev)::"memory");
+#endif
+    float* strip_all = (float*)smem_df;                                  // [4 waves][16 rows][DF_PA]
+    float* slab_all = (float*)(smem_df + 4 * 16 * DF_PA * 4);            // [2][16][208]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16;                          // the wave's first data row
+    float* strip = strip_all + wave * 16 * DF_PA;
+    const int permn = 4 * (n16 & 3) + (n16 >> 2);                        // position of column n16 inside a 16-block of the strip
+    const uint32_t slab_lds = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)slab_all;
+    const char* zsrc = a.zero + lane * 16;
+
+    // ---- the wave's 16 rows of z into its strip (k-permuted, pad columns and rows >= M zero): float4 requests, all of a lane's in flight
+    // before the first LDS store (element by element with a division per element this was 9 % of the kernel: 40 k cycles per wave)
+    {
+        const int Kp = (a.Din + 15) & ~15, Q = Kp >> 2;                  // quads per row (Kp / 4 <= 52)
+        const bool vec = (a.Din & 3) == 0 && (a.ldz & 3) == 0 && (((uintptr_t)a.Z) & 15) == 0;
+        float4 zq[13];                                                     // 16 rows x <= 52 quads = <= 832 quads = 13 per lane
+        int zpos[13];
+#pragma unroll
+        for (int it = 0; it < 13; ++it) {
+            const int idx = lane + 64 * it;
+            zq[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            zpos[it] = -1;
+            if (idx < 16 * Q) {
+                const int r = idx / Q, c = 4 * (idx - r * Q);
+                zpos[it] = r * DF_PA + (c & ~15) + ((c & 15) >> 2);       // element e of the quad (column c + e) goes to + 4 e
+                if (m0 + r < a.M && c < a.Din) {
+                    const float* src = a.Z + (size_t)(m0 + r) * a.ldz + c;
+                    if (vec) zq[it] = *(const float4*)src;
+                    else { zq[it].x = src[0]; if (c + 1 < a.Din) zq[it].y = src[1]; if (c + 2 < a.Din) zq[it].z = src[2]; if (c + 3 < a.Din) zq[it].w = src[3]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 13; ++it) {
+            if (zpos[it] >= 0) {
+                strip[zpos[it]] = zq[it].x; strip[zpos[it] + 4] = zq[it].y; strip[zpos[it] + 8] = zq[it].z; strip[zpos[it] + 12] = zq[it].w;
+            }
+        }
+    }
+    // the images of the lane's four rows (4q + r): base of their x rows, once (per load this was an integer division by k: 23 % of the kernel)
+    const float* xrow[4];
+    const int img0 = min(m0, a.M - 1) / a.k, nimg = min(m0 + 15, a.M - 1) / a.k - img0 + 1;      // (wave-uniform)
+    const bool x_in_lds = nimg <= 3;
+    int xslot[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int im = min(m0 + 4 * q + r, a.M - 1) / a.k;
+        xrow[r] = a.XB + (size_t)im * a.X;
+        xslot[r] = x_in_lds ? im - img0 : 0;
+    }
+    float rowsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    DF_STAMP(0)      // z staging
+
+    // one layer: K in-features -> N out-features.  OUT = false: tanh into the strip (+ Gout); OUT = true: Bernoulli log-likelihood
+    auto layer = [&](auto out_tag, const float* W, const float* bias, const int K, const int N, float* Gout) {
+        constexpr bool OUT = decltype(out_tag)::value;
+        const int NT = (N + 15) >> 4, npass = (NT + DF_TP - 1) / DF_TP, TP = (NT + npass - 1) / npass, nkb = (K + 15) >> 4;
+        for (int pass = 0; pass < npass; ++pass) {
+            const int t0 = pass * TP, cnt = min(TP, NT - t0), c0 = 16 * t0;
+            // DMA of a slab: granule g = tid + 256 u (16 bytes) of the [16][208] slab <- W[16 kb + g / 52][c0 + 4 (g % 52)].  A lane's source
+            // advances by 16 weight rows per slab: a running pointer and a stride (both zero-line / 0 for granules outside the layer), two
+            // vector adds per piece and slab -- as per-slab index arithmetic + selects it was ~15 (3.8 vector instructions per MFMA in the
+            // first version's counters: the waves' issue slots, not the matrix pipe, set its pace)
+            const char* gcur[4]; unsigned gstep[4]; int grow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = tid + 256 * u, r = g / (4 * DF_TP), cq = g - r * (4 * DF_TP);
+                const bool ok = r < 16 && cq < 4 * cnt && c0 + 4 * cq < N;      // (N is a multiple of 4: a granule is all in or all out)
+                grow[u] = ok ? r : (1 << 20);
+                gcur[u] = ok ? (const char*)(W + (size_t)r * N + c0 + 4 * cq) : zsrc;
+                gstep[u] = ok ? (unsigned)(16 * N * 4) : 0u;
+            }
+            const bool ragged = (K & 15) != 0;       // the last slab has rows beyond K: they read the zero line
+            auto issue = [&](int kb, int buf) {
+                const bool last_ragged = ragged && kb == nkb - 1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (256 * u + 64 * wave < 16 * 4 * DF_TP) {          // (wave-uniform: pieces past the slab's 832 granules are never issued)
+                        const char* src = (last_ragged && 16 * kb + grow[u] >= K) ? zsrc : gcur[u];
+                        df_glds16(src, (uint32_t)__builtin_amdgcn_readfirstlane((int)(slab_lds + (uint32_t)buf * (DF_SLAB * 4) + (uint32_t)(256 * u + 64 * wave) * 16u)));
+                        gcur[u] += gstep[u];
+                    }
+                }
+            };
+            f32x4v acc[DF_TP];
+#pragma unroll
+            for (int t = 0; t < DF_TP; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            DF_STAMP(1)      // pass set-up
+            __syncthreads();              // every wave is done with both slabs of the pass / layer before (and the strip is written)
+            DF_STAMP(2)      // barrier between passes
+            issue(0, 0);
+            // The epilogue's operands -- the bias of the pass's 208 columns and, for the output layer, x of the wave's images at those columns --
+            // come as ONE 16-byte request per lane and segment, made at the top of the pass's last slab and parked in the slab buffer that
+            // is free by then (the wave's quarter of it), from where the epilogue reads them with ds_read_b32.  As 13 + 52 dword loads per
+            // pass they were 23 % of the kernel: what a load costs a CU is its instruction, not its bytes (phase stamps: ~200 cycles each).
+            const int segcol = c0 + 4 * lane;
+            const bool segok = lane < 4 * DF_TP && lane < 4 * cnt && segcol < N;
+            float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), px[3] = {pb, pb, pb};
+            for (int kb = 0; kb < nkb; ++kb) {
+                const int buf = kb & 1;
+                DF_STAMP(3)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                DF_STAMP(4)      // own DMA pieces landed
+                __syncthreads();          // slab kb has landed for everyone; everyone has left slab kb - 1
+                DF_STAMP(2)      // barrier
+                if (kb + 1 < nkb) issue(kb + 1, buf ^ 1);
+                if (kb == nkb - 1 && segok) {
+                    pb = *(const float4*)(bias + segcol);
+                    if constexpr (OUT) {
+                        if (x_in_lds) {
+#pragma unroll
+                            for (int si = 0; si < 3; ++si)
+                                if (si < nimg) px[si] = *(const float4*)(a.XB + (size_t)(img0 + si) * a.X + segcol);
+                        }
+                    }
+                }
+                DF_STAMP(5)      // DMA issue (+ the epilogue operands' requests in the last slab)
+                const float4 av = *(const float4*)(strip + n16 * DF_PA + 16 * kb + 4 * q);      // row n16 of the wave: k = 16 kb + 4 j + q at .j
+                const float a4[4] = {av.x, av.y, av.z, av.w};
+                const float* sl = slab_all + buf * DF_SLAB + q * (16 * DF_TP) + n16;
+                // 52 MFMAs (step j = i / 13, tile t = i % 13), their B operands through an explicit 8-deep read pipeline: left to itself the
+                // compiler emitted ds_read2 -> lgkmcnt(0) -> 2 MFMAs per pair, one exposed LDS round trip per 64 cycles of matrix pipe
+                constexpr int NM = 4 * DF_TP, PD = 8;
+                float bq[PD];
+#pragma unroll
+                for (int i = 0; i < PD; ++i) bq[i] = sl[(4 * (i / DF_TP)) * (16 * DF_TP) + 16 * (i % DF_TP)];
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    acc[i % DF_TP] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i / DF_TP], bq[i % PD], acc[i % DF_TP], 0, 0, 0);      // (all 13 tiles, branch-free: the slab columns of tiles >= cnt are zeros)
+                    if (i + PD < NM) bq[i % PD] = sl[(4 * ((i + PD) / DF_TP)) * (16 * DF_TP) + 16 * ((i + PD) % DF_TP)];
+                }
+                // the order the scheduler must keep: PD reads up front, then one read behind every MFMA (0x100 = DS read, 0x008 = MFMA)
+                __builtin_amdgcn_sched_group_barrier(0x100, PD + 1, 0);      // (+ the A operand's ds_read_b128)
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i + PD < NM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                DF_STAMP(6)      // fragment reads + MFMAs
+            }
+            // park the epilogue operands: the buffer slab nkb - 1 did NOT use is free (everyone left it at the top of the last slab, the next
+            // DMA into it comes behind the next pass's barriers); wave-private quarter, so the wave's own LDS order is all the ordering needed
+            float* scr = slab_all + (nkb & 1) * DF_SLAB + wave * (16 * 4 * DF_TP);
+            if (lane < 4 * DF_TP) {
+                *(float4*)(scr + 4 * lane) = pb;
+                if constexpr (OUT) {
+#pragma unroll
+                    for (int si = 0; si < 3; ++si) *(float4*)(scr + 16 * DF_TP * (1 + si) + 4 * lane) = px[si];
+                }
+            }
+            // accumulator tile t: lane (n16, q) reg r = row 4q + r of the wave, out-feature c0 + 16 t + n16
+            if constexpr (!OUT) {
+#pragma unroll
+                for (int t = 0; t < DF_TP; ++t) {
+                    if (t < cnt) {
+                        const int col = c0 + 16 * t + n16;
+                        const float bvt = scr[16 * t + n16];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = col < N ? tanh_f32(acc[t][r] + bvt) : 0.0f;
+                            strip[(4 * q + r) * DF_PA + 16 * (t0 + t) + permn] = v;       // (in place: this layer's input is dead, see above)
+                            if (Gout && col < N && m0 + 4 * q + r < a.M) Gout[(size_t)(m0 + 4 * q + r) * a.ldg + col] = v;
+                        }
+                    }
+                }
+            } else {
+                // log p(x|z) = sum_n x l - softplus(l) = sum_n (x - 1/2) l - |l| / 2 - log(1 + e^-|l|)   (iwae1.py:111); the logarithms of a row's
+                // 13 columns of this pass as ONE log2 of the product of (1 + e) <= 2^13 -- per logit a multiply, one exp2, four plain instructions
+                float s_xl[4] = {0.f, 0.f, 0.f, 0.f}, s_al[4] = {0.f, 0.f, 0.f, 0.f}, prod[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+                for (int t = 0; t < DF_TP; ++t) {
+                    const int col = c0 + 16 * t + n16;
+                    const bool ok = t < cnt && col < N;
+                    const float bvt = scr[16 * t + n16];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x1 = x_in_lds ? scr[16 * DF_TP * (1 + xslot[r]) + 16 * t + n16] : (ok ? xrow[r][col] : 0.0f);      // (more than 3 images per wave: k < 8 -- straight from memory)
+                        const float l = ok ? acc[t][r] + bvt : 0.0f, xm = ok ? x1 - 0.5f : 0.0f;
+                        const float e = __builtin_amdgcn_exp2f(-fabsf(l) * 1.4426950408889634f);      // exp(-|l|)
+                        s_xl[r] = fmaf(xm, l, s_xl[r]);
+                        s_al[r] += fabsf(l);
+                        prod[r] = ok ? fmaf(prod[r], e, prod[r]) : prod[r];
+                        if (a.S && ok && m0 + 4 * q + r < a.M)      // training step: s = x - sigmoid(l) = (x - 1/2) - sign(l) (1 / (1 + e) - 1/2)
+                            a.S[(size_t)(m0 + 4 * q + r) * a.ldS + col] = xm - __builtin_copysignf(__builtin_amdgcn_rcpf(1.0f + e) - 0.5f, l);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rowsum[r] += s_xl[r] - 0.5f * s_al[r] - 0.6931471805599453f * __builtin_amdgcn_logf(prod[r]);
+            }
+        }
+    };
+    layer(std::false_type{}, a.W1, a.b1, a.Din, a.H, a.G1);
+    DF_STAMP(7)
+    layer(std::false_type{}, a.W2, a.b2, a.H, a.H, a.G2);
+    DF_STAMP(7)
+    layer(std::true_type{}, a.W3, a.b3, a.H, a.X, nullptr);
+    DF_STAMP(7)      // (epilogues: what is left of a pass behind its last slab)
+#ifdef IWAE_DENSE_STAMPS
+    if (a.stamps && lane == 0) {
+        for (int i_ = 0; i_ < 8; ++i_) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i_] = df_sum[i_];
+    }
+#endif
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = rowsum[r];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);      // the 16 columns of a tile sit on lanes n16
+        if (n16 == 0 && m0 + 4 * q + r < a.M) a.lpxz[m0 + 4 * q + r] = v;
+    }
+}
+bool dec_fwd_f32_ok(const DecFwdF32Args& a) {
+    return a.Din >= 1 && a.Din <= 16 * DF_TP && a.H >= 4 && a.H <= 16 * DF_TP && a.H % 4 == 0 && a.X % 4 == 0 && a.k >= 1 &&
+           ((uintptr_t)a.W1 & 15) == 0 && ((uintptr_t)a.W2 & 15) == 0 && ((uintptr_t)a.W3 & 15) == 0 &&
+           ((uintptr_t)a.b1 & 15) == 0 && ((uintptr_t)a.b2 & 15) == 0 && ((uintptr_t)a.b3 & 15) == 0 && ((uintptr_t)a.XB & 15) == 0;      // (16-byte segment requests)
+}
+void launch_dec_fwd_f32(const DecFwdF32Args& a, hipStream_t st) {
+    const size_t lds = (size_t)4 * 16 * DF_PA * 4 + (size_t)2 * DF_SLAB * 4;
+    hipLaunchKernelGGL(dec_fwd_f32_kernel, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
 }
 
 // out[i] = sum over z of slabs[z*stride + i] (fixed order), i < n

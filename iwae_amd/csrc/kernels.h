@@ -166,11 +166,12 @@ struct WgradPArgs {
 
 // wgrad_rows_kernel (round 4): weight gradient of one linear map on FEW rows (<= 2 048) with the whole row reduction inside the workgroup
 // and the optimizer update in its epilogue -- no slabs, no reduction launch
-#define WGR_MAX_JOBS 4
+#define WGR_MAX_JOBS 6
 struct WgradRowsJob {
     const uint16_t* X; int ldX;             // layer input, P-layout [R][ldX]
     const uint16_t* G; int ldG;             // dpre of the layer's outputs, P-layout [R][ldG]
     int R;                                  // valid rows
+    const float* rowscale;                  // optional [>= R rounded up to 32]: G rows are multiplied by it on the way in (the output layer: G = the stored s), else null
     int sub0, sub1, split;                  // layer-table index of out-features < split and (merged mu | sigma head) >= split; sub1 = -1: none
     int ib, jb, wg_begin;                   // filled by launch_wgrad_rows: 64-feature blocks of the in / out space, first workgroup
 };
@@ -331,6 +332,20 @@ struct GemmF32Args {
     // goes to Cones[z * cones_stride + n] instead of C (round 3: no separate pass over G for the bias gradients)
     float* Cones; size_t cones_stride;
 };
+// dec_fwd_f32_kernel: the decoder forward in float32 in ONE launch (z -> tanh -> tanh -> logits -> log p(x|z)), rows stationary
+struct DecFwdF32Args {
+    const float* Z; int ldz; int Din;      // decoder input rows [M][ldz] (z, or concat(z, y)), Din features
+    int M, H, X;                           // data rows, hidden width, pixels
+    const float *W1, *b1, *W2, *b2, *W3, *b3;      // Keras kernels [in][out] and biases inside the float32 master parameters
+    float *G1, *G2; int ldg;               // the tanh activations [M][ldg], kept for the backward pass (null: forward only)
+    float* S; int ldS;                     // s = x - sigmoid(l) [M][ldS] for the backward pass, or null
+    const float* XB; int k;                // x [B][X] float32 in {0,1}; row m belongs to image m / k
+    float* lpxz;                           // [M] log p(x|z) per row
+    const char* zero;                      // >= 1 KiB of zeros
+    unsigned long long* stamps;            // diagnostic build (STAMPS=1) only: [workgroups * 4 waves][8] phase cycle sums, else null
+};
+bool dec_fwd_f32_ok(const DecFwdF32Args& a);
+void launch_dec_fwd_f32(const DecFwdF32Args& a, hipStream_t st);
 long gemm_f32_tiles(int M, int N);                       // output tiles of the kernel launch_gemm_f32 takes for an M x N product
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);

@@ -4149,6 +4149,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradRowsArgs a) {
         uint4 g[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) g[u] = frag(gb, u);
+        if (J.rowscale) {      // row-weighted G (workgroup-uniform): a fragment's 8 data rows are 4q..4q+3 and 16+4q..16+4q+3 of the stage; dl = bf16(g_r * s), one rounding
+            const float* rs = J.rowscale + rbeg + 32 * c + 4 * q;
+            const float4 s0 = *(const float4*)rs, s1 = *(const float4*)(rs + 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                g[u] = make_uint4(pack2(bflo(g[u].x) * s0.x, bfhi(g[u].x) * s0.y), pack2(bflo(g[u].y) * s0.z, bfhi(g[u].y) * s0.w),
+                                  pack2(bflo(g[u].z) * s1.x, bfhi(g[u].z) * s1.y), pack2(bflo(g[u].w) * s1.z, bfhi(g[u].w) * s1.w));
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint4 av = frag(xb, t);
@@ -4257,7 +4265,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradRowsArgs a) {
                 const int i = bi * 64 + il, kf0 = jg + 32 * sp + 4 * qq;
                 const uint2 lo = *(const uint2*)(tileB + il * TB_PITCH + (32 * sp + 4 * qq) * 2);
                 const uint2 hi = *(const uint2*)(tileB + il * TB_PITCH + (32 * sp + 16 + 4 * qq) * 2);
-                if (i < J.ldX && kf0 < 32 * L0.KT_B) *(uint4*)(L0.imgB + img_mg_byte(i, kf0, L0.KT_B)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                // (MG-major or K-major: the 16-byte chunk of (row i, k-step quarter) holds the same 8 out-features either way, layout.h)
+                if (i < J.ldX && kf0 < J.ldG)
+                    *(uint4*)(L0.imgB + (L0.imgB_kmajor ? img_k_byte(i, kf0, L0.MT_B) : img_mg_byte(i, kf0, L0.KT_B))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
         }
     }

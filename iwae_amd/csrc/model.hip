@@ -169,8 +169,10 @@ struct iwae_model {
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
     int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
+    bool allow_f32_dec_fused = true;                           // float32 mode: the decoder forward as one launch (dec_fwd_f32_kernel; option no_f32_dec_fused)
     bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
     bool allow_wg3 = true;                           // few rows: the decoder's three weight gradients as one grouped launch (option no_wg3)
+    bool allow_dec_rows = true;                      // ... and, with <= 2 048 DATA rows, the decoder's in the same launch (dec_rows_step; option no_dec_rows)
     bool allow_wgrad_rows = true;                    // few rows (<= 2 048): the image encoder's weight gradients + Adam in ONE launch, whole row reduction per workgroup (wgrad_rows_kernel; option no_wgrad_rows)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
@@ -676,21 +678,30 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
 bool wgrad_rows_ok(const iwae_model* m, const Linear* blk, int R) {
     return m->allow_wgrad_rows && R <= 2048 && blk[0].nsub == 1 && blk[1].nsub == 1 && blk[2].nsub <= 2 && !blk[0].kmajor && !blk[1].kmajor && !blk[2].kmajor;      // (its epilogue writes MG-major images)
 }
-int block_wgrad_rows(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, float alpha, bool fuse, bool with_means) {
+// Few DATA rows too (M = B * k <= 2 048: the reference's default regime, B = 20): the decoder's three weight gradients join the encoder's in the
+// SAME launch (six jobs; the output layer's G = the stored s takes its row weights on the way in) -- no side-stream launches, no slabs, no
+// deferred reduction, no cross-stream events in the whole backward pass.  1-layer model only (the 2-layer model's per-sample blocks keep their path).
+bool dec_rows_step(const iwae_model* m, int M, int B) {
+    return m->allow_dec_rows && m->cfg.n_layers == 1 && M <= 2048 && wgrad_rows_ok(m, m->enc1, B) && m->dec1[0].nsub == 1 && m->dec1[1].nsub == 1 &&
+           m->dec1[2].nsub == 1 && !m->dec1[0].kmajor && !m->dec1[1].kmajor;
+}
+int block_wgrad_rows(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, float alpha, bool fuse, bool with_means, bool with_decoder = false) {
     if (m->descs_dirty) CHK(build_descs(m));
-    const uint16_t* xs[3] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP};
-    const uint16_t* gs[3] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P)};
-    Linear* ls[3] = {&blk[2], &blk[1], &blk[0]};
-    WgradRowsJob jobs[3];
+    const uint16_t* xs[6] = {ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.h1P), inP, ptr<uint16_t>(m->wdec1.g2P), ptr<uint16_t>(m->wdec1.g1P), ptr<uint16_t>(m->zP[0])};
+    const uint16_t* gs[6] = {ptr<uint16_t>(w.dheadP), ptr<uint16_t>(w.d2P), ptr<uint16_t>(w.d1P), ptr<uint16_t>(m->wdec1.dlP), ptr<uint16_t>(m->wdec1.d2P), ptr<uint16_t>(m->wdec1.d1P)};
+    Linear* ls[6] = {&blk[2], &blk[1], &blk[0], &m->dec1[2], &m->dec1[1], &m->dec1[0]};
+    const int njobs = with_decoder ? 6 : 3;
+    WgradRowsJob jobs[6];
     memset(jobs, 0, sizeof(jobs));
-    for (int i = 0; i < 3; ++i) {
-        jobs[i].X = xs[i]; jobs[i].ldX = ls[i]->Kp32; jobs[i].G = gs[i]; jobs[i].ldG = ls[i]->Np32; jobs[i].R = R;
+    for (int i = 0; i < njobs; ++i) {
+        jobs[i].X = xs[i]; jobs[i].ldX = ls[i]->Kp32; jobs[i].G = gs[i]; jobs[i].ldG = ls[i]->Np32; jobs[i].R = i < 3 ? R : m->M;
         jobs[i].sub0 = ls[i]->sub[0];
         jobs[i].sub1 = ls[i]->nsub == 2 ? ls[i]->sub[1] : -1;
         jobs[i].split = ls[i]->nsub == 2 ? ls[i]->joff[1] : (1 << 30);
     }
+    if (with_decoder && m->s_mode) jobs[3].rowscale = ptr<float>(m->gx);      // the forward pass kept s: dl = g_r s is made on the way in (else dlP already holds dl)
     const bool two = m->cfg.n_layers == 2;
-    launch_wgrad_rows(jobs, 3, m->d_descs, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0,
+    launch_wgrad_rows(jobs, njobs, m->d_descs, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0,
                       with_means ? ptr<float>(m->per_b) : nullptr, m->B, two ? 1.f : m->beta, m->d_scalars, m->d_zero, m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -733,6 +744,7 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
 // the stream that carries the speculative draw of the NEXT step's noise: one that this step's backward pass orders behind the main stream
 // and whose last event the next forward joins (see the call in forward_impl; m->early_wout must be decided)
 hipStream_t eps_draw_stream(const iwae_model* m, int M) {
+    if (dec_rows_step(m, M, m->B)) return m->stream;      // (that backward pass touches no side stream at all: the draw stays in stream order)
     return (m->allow_wg3 && m->use_side2 && m->side2 && M <= 4096 && m->early_wout) ? m->side2 : m->side;
 }
 
@@ -1033,7 +1045,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             }
         }
             CHK(attach_dense_stamps(m, EPI_BERN, a));
-            m->early_wout = bwd && m->s_mode && m->allow_early_wout;      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
+            m->early_wout = bwd && m->s_mode && m->allow_early_wout && !dec_rows_step(m, M, B);      // (few data rows: no side-stream work in the backward pass at all)      // (round 3: the 2-layer model too -- its weight gradients are 220 us of kernels, on ONE side stream behind dec_bwd they ended 100 us after the main stream)
             // Round 3: where the decoder kernel's workgroups own whole images (16-wave / 200-row shape, k a divisor of 200) it also does
             // lse_kernel's work for them -- the backward pass starts right behind it: one launch (7 us) and one dispatch gap (6 us) less
             // on the loop that sets the step, and no second lse_kernel on the side stream.
@@ -1126,6 +1138,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     CHK(ensure(w.d1P, (size_t)Mp * Hp * 2, st));
     CHK(ensure(w.dz, (size_t)Mp * m->Dp[0] * 4, st));
     bool fused_dx = false, dz_half = false;
+    const bool dec_rows = dec_rows_step(m, M, B);      // the decoder's weight gradients ride in the encoder's wgrad_rows_kernel launch (few data rows)
     {
         Linear& L = m->dec1[2];
         OutBwdArgs a;
@@ -1163,7 +1176,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 r.DZ = ptr<float>(w.dz); r.DZH = dz_half ? (uint16_t*)w.dz.p : nullptr;
                 if (dec_bwd_rows_ok(r)) {
                     ScopedTimer tm(m, T_DEC_BWD);
-                    set_launch_stop_event(m->ev_fork2);
+                    if (!dec_rows) set_launch_stop_event(m->ev_fork2);
                     launch_dec_bwd_rows(r, st);
                     rows_kernel = true;
                 }
@@ -1185,7 +1198,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                     d.o.stamps = ptr<unsigned long long>(m->dstamps);
                 }
                 ScopedTimer tm(m, T_DEC_BWD);
-                set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
+                if (!dec_rows) set_launch_stop_event(m->ev_fork2);          // dpre2, dpre1 and the last read of the decoder's weight images: one event
                 launch_dec_bwd(d, st);
             } else {
             // (forked behind lse_kernel already: the side stream then needs nothing from the main stream until dX of d1 is done)
@@ -1201,7 +1214,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // launches and the streams' hand-offs, not by these kernels: 13 -> 11 launches, two events less)
     bool group3 = false;
     WgradPGroup g3;
-    if (m->allow_wg3 && M <= 4096 && fused_dx && m->early_wout && m->use_side2 && m->s_mode) {
+    if (!dec_rows && m->allow_wg3 && M <= 4096 && fused_dx && m->early_wout && m->use_side2 && m->s_mode) {
         memset(&g3, 0, sizeof(g3));
         Linear* ls[3] = {&m->dec1[2], &m->dec1[1], &m->dec1[0]};
         const uint16_t* xs[3] = {ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.g1P), ptr<uint16_t>(m->zP[0])};
@@ -1217,7 +1230,13 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         g3.n = 3;
         g3.a[0].rowscale = ptr<float>(m->gx);      // (the main stream's row weights: this group waits for ev_fork2, i.e. for the main stream -- never the side stream's copy)
     }
-    if (group3) {
+    if (dec_rows) {
+        if (!fused_dx) {      // (the dX chain as three launches; their weight gradients follow in wgrad_rows_kernel, further down the main stream)
+            { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
+            { ScopedTimer tm(m, T_DX_LAT); CHK(dense_dx(m, m->dec1[0], ptr<uint16_t>(w.d1P), M, nullptr, nullptr, ptr<float>(w.dz))); }
+        }
+        m->tail = m->side;
+    } else if (group3) {
         HIPCHK(hipStreamWaitEvent(m->side2, m->ev_fork2, 0));
         { ScopedTimer tm(m, T_WGRAD_OUT, m->side2); launch_wgradp_group(g3, m->side2); }
         HIPCHK(hipGetLastError());
@@ -1277,7 +1296,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
     if (m->descs_dirty) CHK(build_descs(m));
-    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two;      // (2-layer: the main stream needs the side-stream block gradients anyway)
+    const bool defer = fuse && m->allow_defer && m->early_first > 0 && !two && !dec_rows;      // (2-layer: the main stream needs the side-stream block gradients anyway)
 
     const float* dz1 = ptr<float>(w.dz);
     const float *dz1_b = nullptr, *dz1_c = nullptr;
@@ -1361,7 +1380,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // ordered behind the side stream and runs beside the encoder's backward pass; join_side() (every later entry point) joins.
     // Without split (iwae_forward_backward: gradient only, e.g. the one-message data-parallel step) the same early decoder
     // reduction runs on the side stream and the main stream joins it behind its own, shorter, encoder reduction.
-    const bool early = !fuse && m->early_first > 0 && !two;
+    const bool early = !fuse && m->early_first > 0 && !two && !dec_rows;
     // 2-layer training step at large row counts (round 3): every layer behind the image encoder has its weight gradients on the side
     // streams; their slab sums + Adam follow there (one launch on `tail`, which picks `side` up), instead of the main stream waiting for
     // both side streams and then summing all 94 MB itself.  The next forward joins in front of z1 (join_side).  The image rewrite is safe
@@ -1376,6 +1395,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (defer2) {       // (the side streams' layers are summed and updated there, further down: nothing to join)
+    } else if (dec_rows) {     // (nothing ran on a side stream)
     } else if (!defer) {       // join: every weight gradient launched on the side stream is in its slabs
         HIPCHK(hipEventRecord(m->ev_join, m->tail));
         HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
@@ -1386,13 +1406,19 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     }
     {
         // the main stream's share of the table: [rb_lo, rb_hi) -- empty when wgrad_rows_kernel took the encoder and everything else is
-        // deferred to the side streams (the full-size 1- and 2-layer steps): then that kernel's extra block makes the batch means too
+        // deferred to the side streams (the full-size 1- and 2-layer steps) or rode in the same launch (few data rows: dec_rows); that
+        // kernel's extra block makes the batch means whenever it runs
         const int rb_hi = (defer || early) ? m->early_first : defer2 ? m->early_first2 : m->reduce_blocks;
+        const int rb_d0 = dec_rows ? m->descs[m->dec1[0].sub[0]].rblock_begin : rb_hi;        // (dec_rows: the decoder's three layers drop out of the range)
+        const int d_end = m->dec1[2].sub[0] + 1;
+        const int rb_d1 = !dec_rows ? rb_hi : d_end < (int)m->descs.size() ? m->descs[d_end].rblock_begin : m->reduce_blocks;
         ScopedTimer tm_red(m, T_REDUCE);
-        if (rows_enc) CHK(block_wgrad_rows(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, alpha, fuse, rb_hi <= rb_lo));
-        if (!rows_enc || rb_hi > rb_lo)
-            launch_reduce_grads(m->d_descs, (int)m->descs.size(), rb_lo, rb_hi - rb_lo, m->grad, m->param, m->mom, m->vel,
-                                alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st);
+        if (rows_enc) CHK(block_wgrad_rows(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, alpha, fuse, true, dec_rows));
+        const int n1 = std::max(0, std::min(rb_d0, rb_hi) - rb_lo), n2 = std::max(0, rb_hi - rb_d1);
+        if (!rows_enc || n1 + n2 > 0)
+            launch_reduce_grads(m->d_descs, (int)m->descs.size(), rb_lo, n1, m->grad, m->param, m->mom, m->vel,
+                                alpha, m->adam_b1, m->adam_b2, m->adam_eps, fuse ? 1 : 0, rows_enc ? nullptr : ptr<float>(m->per_b), B, two ? 1.f : m->beta, m->d_scalars, st,
+                                rb_d1, n2);
     }
     if (early && !split) CHK(join_side(m));
     if (defer2 && m->tail == m->side2 && m->tail != m->side && m->allow_defer2_split && m->dec2[0].nsub == 1 && m->dec1[0].nsub == 1 && m->dec1[2].nsub == 1) {
@@ -1698,8 +1724,37 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     const int b_dec1 = m->dec1[0].sub[0];
     const KerasLayer *d1 = &m->klayers[b_dec1], *d2 = d1 + 1, *d3 = d1 + 2;
     const int H = d1->Nout;
-    CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
-    CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
+    // Round 4: the whole decoder forward in ONE launch where its shapes fit (dec_fwd_f32_kernel: rows stationary, activations in LDS, the
+    // weights streamed from the float32 master parameters; log p(x|z) per row comes out whole) -- the k = 5000 evaluator's three GEMM launches
+    // ran at 0.35 of the f32 MFMA peak between them.  A training step also keeps g1, g2 and s = x - sigmoid(l) for the backward pass.
+    DecFwdF32Args df;
+    memset(&df, 0, sizeof(df));
+    df.Z = ptr<float>(m->f32.z[0]); df.ldz = Dz; df.Din = Dz; df.M = M; df.H = H; df.X = X;
+    df.W1 = m->param + d1->offW; df.b1 = m->param + d1->offb; df.W2 = m->param + d2->offW; df.b2 = m->param + d2->offb;
+    df.W3 = m->param + d3->offW; df.b3 = m->param + d3->offb;
+    df.XB = xd; df.k = k; df.lpxz = lpxz; df.zero = m->d_zero; df.ldg = H; df.ldS = X;
+    const bool fused_dec = m->allow_f32_dec_fused && !(want && want->logits) && M >= 4096 && dec_fwd_f32_ok(df);
+    if (bwd || !fused_dec) {
+        CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
+        CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
+    }
+    if (fused_dec) {
+        m->px_parts = 1;
+        m->f32_keeps_s = false;
+        if (bwd) {
+            CHK(ensure(m->f32.logits, (size_t)M * X * 4, st));
+            df.G1 = ptr<float>(m->f32.g1); df.G2 = ptr<float>(m->f32.g2); df.S = ptr<float>(m->f32.logits);
+            m->f32_keeps_s = true;
+        }
+#ifdef IWAE_DENSE_STAMPS
+        if (m->dstamp_epi == 11) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 11): phase stamps of dec_fwd_f32_kernel
+            m->dstamp_waves = ((M + 63) / 64) * 4;
+            CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st));
+            df.stamps = ptr<unsigned long long>(m->dstamps);
+        }
+#endif
+        launch_dec_fwd_f32(df, st);
+    } else {
     CHK(f32_fwd(m, *d1, ptr<float>(m->f32.z[0]), Dz, M, ptr<float>(m->f32.g1), H, GEMM_EPI_TANH));
     CHK(f32_fwd(m, *d2, ptr<float>(m->f32.g1), H, M, ptr<float>(m->f32.g2), H, GEMM_EPI_TANH));
     // forward-only calls at large row counts (the k = 5000 evaluator): log p(x|z) in the epilogue of the output layer's GEMM -- the float32
@@ -1728,6 +1783,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     CHK(f32_fwd(m, *d3, ptr<float>(m->f32.g2), H, M, ptr<float>(m->f32.logits), X, GEMM_EPI_NONE));
     launch_bern_f32(ptr<float>(m->f32.logits), X, xd, X, M, k, lpxz, st);
     }
+    }      // (!fused_dec)
     if (want && want->logits) {      // reference [k,B,X] order
         CHK(ensure(m->scratch, (size_t)M * X * 4, st));
         launch_export_mat(ptr<float>(m->f32.logits), B, k, X, ptr<float>(m->scratch), st);
@@ -2222,7 +2278,9 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
+    else if (n == "no_f32_dec_fused") m->allow_f32_dec_fused = !on;   // float32 mode: the decoder forward as three GEMM launches
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
+    else if (n == "no_dec_rows") m->allow_dec_rows = !on;             // few data rows: the decoder's weight gradients as the grouped launch on the side stream + deferred reduction
     else if (n == "no_wgrad_rows") m->allow_wgrad_rows = !on;         // few rows: the encoder's weight gradients as the grouped launch + slabs + reduce_grads_kernel
     else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel

@@ -386,7 +386,7 @@ def test_kernel_variants_agree(gpu, B, k):
     for env in ({"out_recompute": 1}, {"dense_g1": 0}, {"no_zin": 1}, {"no_bern_pipe": 1},
                 {"no_dec_fused": 1}, {"no_block_fused": 1}, {"no_early_wout": 1}, {"bern_qw_force": 1},
                 {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"no_lse_fused": 1}, {"no_wg3": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
-                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}):
+                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}, {"no_dec_rows": 1}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
@@ -540,7 +540,8 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu):
 
 
 @pytest.mark.parametrize("nh,nl,opts", [(256, 128, {}), (16, 4, {}), (200, 100, {"no_early_wout": 1}), (200, 100, {"out_recompute": 1}),
-                                        (96, 20, {}), (200, 100, {"no_wg3": 1})])
+                                        (96, 20, {}), (200, 100, {"no_wg3": 1}), (200, 100, {}), (200, 100, {"no_dec_rows": 1}),
+                                        (256, 128, {"no_dec_rows": 1}), (200, 100, {"no_dec_rows": 1, "out_recompute": 1})])
 def test_speculative_noise_draw_is_ordered_on_every_kernel_path(gpu, nh, nl, opts):
     """The next step's noise is drawn a step ahead on a side stream (forward_impl).  Which side stream must follow what the backward
     pass of THAT step uses: hidden widths without a stored-s instantiation (256, 16, 96) and the options out_recompute / no_early_wout
@@ -1031,6 +1032,38 @@ def test_float32_mode_fused_output_layer_matches_exact_oracle(gpu, layers, B, k,
     (r1, g1), (r2, g2) = out
     for key in keys:
         assert abs(r1[key] - r2[key]) <= 2e-6 * abs(r2[key])
+    assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-5
+
+
+@pytest.mark.parametrize("B,k,nh,nl,xd,obj", [(100, 50, 200, 100, 784, "iwae_elbo"), (1433, 3, 200, 100, 784, "iwae_elbo"), (90, 47, 64, 20, 100, "vae_elbo"),
+                                              (4200, 1, 200, 100, 784, "vae_elbo"), (101, 41, 208, 128, 52, "dreg")])
+def test_float32_decoder_forward_in_one_launch_matches_exact_oracle(gpu, B, k, nh, nl, xd, obj):
+    """float32 mode at >= 4 096 rows (round 4): the decoder forward is ONE launch (dec_fwd_f32_kernel: a wave owns 16 rows through the two tanh
+    layers and the output layer, activations in LDS, log p(x|z) whole per row; a training step also keeps g1, g2 and s = x - sigmoid(l)).
+    Shapes: the reference's; k = 3 and k = 1 (a wave's 16 rows span more than three images: x straight from memory instead of through LDS); a
+    ragged row count (4 230 = 66 workgroups + 6 rows) with narrow layers and 100 pixels (one pass of 7 tiles); the widest layers the kernel
+    takes (208 / 128 / 52).  Per-row log p(x|z), the objective values and every gradient tensor against the exact float64 oracle at the float32
+    tolerances, and against the same mode with three GEMM launches (option no_f32_dec_fused)."""
+    from iwae_amd.native import NativeModel
+    x, P, eps = MG.inputs(1, nh, nl, xd, B, k, 770 + B + k)
+    res, g = O.loss_grads_1layer(P, x, eps, 1.0, obj)
+    keys = ("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "iwae_elbo", "iwae_eq14")
+    out = []
+    for opts in ({}, {"no_f32_dec_fused": 1}):
+        m = NativeModel(1, nh, nl, x_dim=xd, seed=123, precision="fp32", options=opts)
+        m.set_params(O.flatten_params(P))
+        r = m.forward_backward(x, k, 1.0, obj, eps=eps, want=("lpxz",))
+        assert np.max(np.abs(r["lpxz"] - res["lpxz"])) < F32_ROW_ATOL, opts
+        for key in keys:
+            assert abs(r[key] - res[key]) <= F32_SCALAR_REL * abs(res[key]) + 2e-4, (opts, key, r[key], res[key])
+        flat = m.get_grads()
+        assert max(_grad_rel_errors(flat, g)) < F32_GRAD_REL, opts
+        r0 = m.forward(x, k, 1.0, eps=eps, want=("lpxz",))          # (forward only: g1, g2, s are not written)
+        np.testing.assert_allclose(r0["lpxz"], r["lpxz"], rtol=1e-6, atol=1e-4)
+        out.append((r, flat.astype(np.float64)))
+        m.close()
+    (r1, g1), (r2, g2) = out
+    np.testing.assert_allclose(r1["lpxz"], r2["lpxz"], rtol=2e-6, atol=2e-4)
     assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-5
 
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Developer script (GPU box): SQ / TCC counter passes over the bench loop WITH a kernel trace in the same run (counter collection
 # serialises the dispatches, so the traced durations are each kernel ALONE on the machine), per-kernel per-launch averages.
-# usage: bash tools/dev/pmc_kernel.sh <tag> [kernel-name-substring ...]      env: BENCH_ARGS (extra bench.py arguments)
+# usage: bash tools/dev/pmc_kernel.sh <tag> [kernel-name-substring ...]      env: BENCH_ARGS (extra bench.py arguments), PK_CMD (profile another command)
 TAG=${1:-x}; shift
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pk_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 30 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS"
+CMD=${PK_CMD:-"python3 $R/bench.py --steps 30 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS"}      # (PK_CMD: another program to profile, e.g. "python3 $GRAFT_REPO_ROOT/tools/dev/eval_only.py fp32 400")
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" \
