@@ -147,7 +147,8 @@ int iwae_grad_devptr(iwae_handle h, void** dev_ptr, size_t* n);
  * library's side stream (*side_stream, a hipStream_t) and NOT joined into the main stream: the caller orders its
  * all-reduce of that segment behind *side_stream and of [0, *side_offset) behind the main stream, makes the main stream
  * wait for both and calls iwae_adam_step.  Models without such a segment return *side_offset = n (nothing left on the
- * side stream).  No reference counterpart (the reference is single-device, main.py:32). */
+ * side stream: float32 mode, and steps on <= 2 048 data rows, whose weight gradients all run on the main stream).  No reference counterpart (the reference is
+ * single-device, main.py:32). */
 int iwae_forward_backward_split(iwae_handle h, const float* x, int32_t B, int32_t k, float beta, int32_t objective,
                                 const float* eps, void** side_stream, size_t* side_offset);
 int iwae_adam_step(iwae_handle h, float lr, float grad_scale);      /* keras Adam(lr, epsilon=1e-4), main.py:93 */

@@ -490,6 +490,7 @@ def test_split_backward_equals_joined_backward(gpu, B, k):
     x = O.synthetic_binarized(B, 31)
     P = O.init_params(1, 200, 100, 37, x_mean=O.synthetic_pixel_means())
     outs = []
+    g_n = O.flatten_params(P).size
     for split in (False, True):
         m = _model(1, 200, 100)
         m.set_params(O.flatten_params(P))
@@ -498,7 +499,9 @@ def test_split_backward_equals_joined_backward(gpu, B, k):
             side, off = m.forward_backward_split_devptr(x.ctypes.data, B, k, 1.0, 1)
             names = [t[0] for t in m.tensor_table()]
             first_dec = [t for t in m.tensor_table() if t[0].startswith("dec")][0]
-            assert off == first_dec[2], (off, names)
+            # (<= 2 048 data rows, round 4: the decoder's weight gradients ride in the encoder's launch on the main stream -- nothing is left
+            # on the side stream, which the ABI reports as an offset of n, include/iwae_amd.h)
+            assert off == (first_dec[2] if B * k > 2048 else g_n), (off, names)
             assert side != 0
         else:
             m.forward_backward(x, k, 1.0, "iwae_elbo")
