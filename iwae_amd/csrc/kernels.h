@@ -36,6 +36,7 @@ struct LseArgs {
     float* logw; float* wn; float* gx; float4* cf; float* per_b;
     int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
     float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
+    float* gx_local; int gx_r0;          // optional: the row weights of rows [gx_r0, gx_r0 + 16) also go to gx_local[row - gx_r0] (a kernel that does lse_image's work for its own 16 rows: dec_bwd_rows_kernel)
 };
 
 struct DenseArgs {
@@ -110,10 +111,31 @@ struct DecBwdRowsArgs {               // dec_bwd_rows_kernel: the decoder's dX c
     const float* gx;                          // [M] row weights
     uint16_t *D2P, *D1P;                      // dpre2, dpre1 out, P-layout [M][32*KT]
     float* DZ; uint16_t* DZH; int ldDZ;       // dz out: float32 or (DZH != null) bf16, [M][ldDZ]
+    // lse_on: the workgroup first does lse_kernel's work (log_w, log-mean-exp over k, row weights, per-image values) for the images its 16 rows
+    // belong to -- a wave per image, beside the first weight fragments' round trip -- and takes its rows' weights from LDS: no lse launch
+    // between the decoder forward and this kernel (few rows: the step is a chain of dependent launches).  Images that straddle workgroups are
+    // done by each of them (identical values).
+    int lse_on;
+    LseArgs lse;
 };
 bool dec_bwd_rows_ok(const DecBwdRowsArgs& a);
 void launch_dec_bwd_rows(const DecBwdRowsArgs& a, hipStream_t st);
 
+struct LatentBwdArgs {
+    const float* dz; int ldDZ;
+    const uint16_t* dzh;              // dz as bf16 [rows][ldDZ] instead of `dz` (dec_bwd_kernel's output), or null
+    const float* dz2; const float* dz3;   // optional further terms of dz (same layout), added on load; both or neither
+    const float* head; int ldH; int D, Dp;
+    const float4* cf;
+    EpsSrc eps;
+    int B, Bp, k;
+    float kmu, ksig;
+    uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp] (or null)
+    float* DHF;                       // float32 mode: dhead as float32 [B][2Dp] (d mu at f, d pre-exp at Dp + f), or null
+    const float* prior_head;          // conditional prior p(z|y) (tasks/task04.py:124-130): per-image head [B][ldH] like `head`, or null = N(0,1)
+    uint16_t* DHP2;                   // its dhead, P-layout [B][2Dp] (written when prior_head != null)
+    float* DHF2;                      // float32 mode: the same as float32 [B][2Dp]
+};
 struct BlockBwdArgs {                 // block_bwd_kernel: the dX chain of a BasicBlock on R <= 4096 rows
     const uint16_t* DH; int ldDH;     // dhead, bf16 P-layout [R][32*KTH]
     const char *imgH, *imgL2;         // backward images (MG-major: out-feature groups over hidden) of the head (KTH k-steps) and of l2 (KT1)
@@ -121,6 +143,11 @@ struct BlockBwdArgs {                 // block_bwd_kernel: the dX chain of a Bas
     int R;
     const uint16_t *H2, *H1; int ldH; // stored tanh activations, P-layout [R][32*KT1]
     uint16_t *D2, *D1;                // outputs: dpre of l2 and of l1, P-layout [R][32*KT1]
+    // lat_on (the image encoder on few rows): the block's dhead rows are MADE here -- latent_bwd_kernel's per-image sums over the k samples
+    // (d mu, d sigma: `lat`), a wave per image in front of the dX chain -- instead of being read from DH; they are also stored to lat.DHP
+    // for the head's weight gradient.  One dependent launch less per step.
+    int lat_on;
+    LatentBwdArgs lat;
 };
 bool block_bwd_ok(const BlockBwdArgs& a);
 void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
@@ -229,21 +256,6 @@ struct GaussLpArgs {
 };
 
 
-struct LatentBwdArgs {
-    const float* dz; int ldDZ;
-    const uint16_t* dzh;              // dz as bf16 [rows][ldDZ] instead of `dz` (dec_bwd_kernel's output), or null
-    const float* dz2; const float* dz3;   // optional further terms of dz (same layout), added on load; both or neither
-    const float* head; int ldH; int D, Dp;
-    const float4* cf;
-    EpsSrc eps;
-    int B, Bp, k;
-    float kmu, ksig;
-    uint16_t* DHP;                    // dhead bf16, P-layout [B][2Dp] (or null)
-    float* DHF;                       // float32 mode: dhead as float32 [B][2Dp] (d mu at f, d pre-exp at Dp + f), or null
-    const float* prior_head;          // conditional prior p(z|y) (tasks/task04.py:124-130): per-image head [B][ldH] like `head`, or null = N(0,1)
-    uint16_t* DHP2;                   // its dhead, P-layout [B][2Dp] (written when prior_head != null)
-    float* DHF2;                      // float32 mode: the same as float32 [B][2Dp]
-};
 
 struct GaussBwdArgs {
     int mode;

@@ -826,7 +826,70 @@ __global__ __launch_bounds__(1024, ((AD > 6 || OUT) ? 2 : 5)) void block_fwd_ker
 // second layer's are requested before the first product starts), the data operands sit in LDS as 1 KiB k-step blocks.
 // As two dense_kernel<EPI_DX> launches this was 6.5 + 6.4 us alone and 20 - 35 us beside the weight gradients.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
+// latent_bwd_kernel's sums for ONE image by ONE wave (block_bwd_kernel with lat_on: the image encoder's backward on few rows): lanes = 32 feature
+// quads x 2 sample groups, four samples' loads in flight per lane; on return lanes < 32 hold d mu and d sigma -> pre-activation of the exp
+// for features 4 lane .. 4 lane + 3 (zeros beyond D).  The same arithmetic as latent_bwd_kernel, another summation order; no
+// conditional prior (the caller keeps the separate kernel for that).
+__device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const int b, const int lane, float (&dmu)[4], float (&dsg)[4]) {
+    const int f4 = lane & 31, sg = lane >> 5, f0 = 4 * f4;
+    float mu[4] = {0, 0, 0, 0}, sgm[4] = {1, 1, 1, 1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+    if (f0 < a.D) {
+        float rs2[4], rsg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = f0 + i < a.D;
+            mu[i] = ok ? a.head[(size_t)b * a.ldH + f0 + i] : 0.0f;
+            sgm[i] = ok ? a.head[(size_t)b * a.ldH + a.Dp + f0 + i] : 1.0f;
+            const float s2 = sgm[i] + 1e-6f;
+            rs2[i] = 1.0f / (s2 * s2);
+            rsg[i] = 1.0f / sgm[i];
+        }
+        constexpr int UN = 4;
+        for (int s0 = sg; s0 < a.k; s0 += 2 * UN) {
+            float4 dz[UN], cf[UN];
+            float e[UN][4];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int s = s0 + 2 * u, sc = s < a.k ? s : a.k - 1, row = b * a.k + sc;      // clamped, weighted by 0 below
+                if (a.dzh) { const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0); dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y)); }
+                else dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
+                if (a.dz2) {
+                    const float4 t2 = *(const float4*)(a.dz2 + (size_t)row * a.ldDZ + f0), t3 = *(const float4*)(a.dz3 + (size_t)row * a.ldDZ + f0);
+                    dz[u] = make_float4(dz[u].x + t2.x + t3.x, dz[u].y + t2.y + t3.y, dz[u].z + t2.z + t3.z, dz[u].w + t2.w + t3.w);
+                }
+                cf[u] = a.cf[row];
+                eps4(a.eps, b, sc, row, f4, a.D, e[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (s0 + 2 * u >= a.k) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const float dzv[4] = {dz[u].x, dz[u].y, dz[u].z, dz[u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (f0 + i < a.D) {
+                        const float z = mu[i] + sgm[i] * e[u][i];
+                        const float t = cf[u].x * dzv[i] + cf[u].y * z + cf[u].z * (z - mu[i]) * rs2[i];      // (N(0,1) prior: up = z, 1/sigma_p = 1)
+                        dmu[i] += t;
+                        dsg[i] += t * e[u][i] + cf[u].w * rsg[i];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dmu[i] += __shfl_xor(dmu[i], 32); dsg[i] += __shfl_xor(dsg[i], 32); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (f0 + i < a.D) {
+            dmu[i] += a.kmu * mu[i];
+            dsg[i] += a.ksig * (sgm[i] - 1.0f / sgm[i]);
+            dsg[i] *= (sgm[i] - 1e-6f);
+        } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+    }
+}
+__global__ __launch_bounds__(1024, 4) void block_bwd_kernel(BlockBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
@@ -836,6 +899,26 @@ __global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     char* act0 = smem;                                   // dhead tile: KTH blocks
     char* act1 = smem + (size_t)a.KTH * 1024;            // d2 tile: KT1 blocks
+    if (a.lat_on) {      // the dhead tile is MADE here: wave w = image r0 + w (latent_bwd_kernel's job, without its launch)
+        float dmu[4], dsg[4];
+        const int b = r0 + wave, Dp = a.lat.Dp;
+        if (b < a.R) latent_image_wave(a.lat, b, lane, dmu, dsg);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+        }
+        if (lane < Dp / 4 && wave < 16) {
+            const int f0 = 4 * lane;
+            const uint2 vm = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3])), vs = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
+            const int pm = p_pos(f0), ps = p_pos(Dp + f0);
+            *(uint2*)(act0 + (pm >> 5) * 1024 + wave * 64 + ((((pm & 31) >> 3) ^ hperm(wave >> 2)) * 16) + ((pm >> 2) & 1) * 8) = vm;
+            *(uint2*)(act0 + (ps >> 5) * 1024 + wave * 64 + ((((ps & 31) >> 3) ^ hperm(wave >> 2)) * 16) + ((ps >> 2) & 1) * 8) = vs;
+            if (b < a.R && a.lat.DHP) {
+                *(uint2*)(a.lat.DHP + (size_t)b * (2 * Dp) + pm) = vm;
+                *(uint2*)(a.lat.DHP + (size_t)b * (2 * Dp) + ps) = vs;
+            }
+        }
+    } else
     for (int c = threadIdx.x; c < a.KTH * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
         const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -882,106 +965,6 @@ __global__ __launch_bounds__(1024, 5) void block_bwd_kernel(BlockBwdArgs a) {
     if (has && valid) *(uint2*)(a.D1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = dtanh(acc, y1);
 }
 
-// ---------------------------------------------------------------------------------
-// dec_bwd_rows_kernel: the decoder's dX chain (dec_bwd_kernel's three products) on FEW rows, in block_bwd_kernel's form: a 16-wave
-// workgroup owns 16 rows, wave w owns hidden tile w of the first two products (latent tile w of the third), the weight fragments
-// come straight from the L2-resident images -- for dg2 = s W3^T the K-major image of W3 (rows = hidden tile, k = pixels), streamed
-// AD deep over the 25 pixel k-steps -- and s / dpre2 / dpre1 sit in LDS as 1 KiB k-step blocks.  dec_bwd_kernel streams every weight
-// unit through ONE workgroup's LDS per 128 rows: at 20 rows that is a single workgroup walking 19 units in turn (27 us).
-// ---------------------------------------------------------------------------------
-template <int AD>
-__global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(DecBwdRowsArgs a) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rho = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.x * 16;
-    const int row = r0 + rho;
-    const bool valid = row < a.M;
-    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
-    char* act0 = smem;                                   // s tile: KTX blocks
-    char* act1 = smem + (size_t)a.KTX * 1024;            // dpre2: KT blocks
-    char* act2 = act1 + (size_t)a.KT * 1024;             // dpre1: KT blocks
-    for (int c = threadIdx.x; c < a.KTX * 64; c += 1024) {
-        const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + rr < a.M) v = *(const uint4*)(a.SP + (size_t)(r0 + rr) * a.ldS + ks * 32 + qq * 8);
-        *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
-    }
-    const int mg = wave >> 2, tg = wave & 3;
-    const bool has = wave < a.NT1, has3 = wave < a.NT3;
-    const char* w3 = a.imgK3 + (size_t)wave * 1024 + a_off;                    // block (pixel k-step ks, hidden tile wave) = (ks*MT + wave) KiB
-    const char* w2 = a.imgB2 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
-    const char* w1 = a.imgB1 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
-    uint4 A2[BLOCKFWD_MAX_KT], A1[BLOCKFWD_MAX_KT];
-#pragma unroll
-    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
-        A2[ks] = make_uint4(0, 0, 0, 0);
-        if (ks < a.KT && has) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
-    }
-    const int kso = wave >> 1, hh = wave & 1;
-    uint2 y2 = make_uint2(0, 0), y1 = make_uint2(0, 0);
-    float gxr = 0.0f;
-    if (valid && has) {
-        y2 = *(const uint2*)(a.G2 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
-        y1 = *(const uint2*)(a.G1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
-        gxr = a.gx[row];
-    }
-    auto dtanh = [&](const f32x4& acc, const uint2& y, float sc) {
-        const float ya = bflo(y.x), yb = bfhi(y.x), yc = bflo(y.y), yd = bfhi(y.y);
-        return make_uint2(pack2(sc * acc[0] * (1.0f - ya * ya), sc * acc[1] * (1.0f - yb * yb)), pack2(sc * acc[2] * (1.0f - yc * yc), sc * acc[3] * (1.0f - yd * yd)));
-    };
-    // ---- product 1: dg2 = s W3^T over the KTX pixel k-steps, A fragments streamed AD deep
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    {
-        const size_t kstride = (size_t)a.MT3 * 1024;
-        uint4 av[AD];
-#pragma unroll
-        for (int i = 0; i < AD; ++i) av[i] = (i < a.KTX && has) ? *(const uint4*)(w3 + (size_t)i * kstride) : make_uint4(0, 0, 0, 0);
-        __syncthreads();                         // s tile staged
-        for (int k0 = 0; k0 < a.KTX; k0 += AD) {
-#pragma unroll
-            for (int i = 0; i < AD; ++i) {
-                const int ks = k0 + i;
-                if (ks < a.KTX) {
-                    acc = mfma16(av[i], *(const uint4*)(act0 + ks * 1024 + a_off), acc);
-                    if (ks + AD < a.KTX && has) av[i] = *(const uint4*)(w3 + (size_t)(ks + AD) * kstride);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
-        A1[ks] = make_uint4(0, 0, 0, 0);
-        if (ks < a.KT && has3) A1[ks] = *(const uint4*)(w1 + (size_t)ks * 4096);
-    }
-    if (has) {
-        const uint2 v = valid ? dtanh(acc, y2, gxr) : make_uint2(0, 0);      // dpre2 = g_r * dg2 * (1 - g2^2)
-        *(uint2*)(act1 + kso * 1024 + a_off + 8 * hh) = v;
-        if (valid) *(uint2*)(a.D2P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
-    }
-    __syncthreads();
-    // ---- product 2: dpre1 = (dpre2 V2^T) * (1 - g1^2)
-    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
-        if (ks < a.KT) acc = mfma16(A2[ks], *(const uint4*)(act1 + ks * 1024 + a_off), acc);
-    if (has) {
-        const uint2 v = valid ? dtanh(acc, y1, 1.0f) : make_uint2(0, 0);
-        *(uint2*)(act2 + kso * 1024 + a_off + 8 * hh) = v;
-        if (valid) *(uint2*)(a.D1P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
-    }
-    __syncthreads();
-    // ---- product 3: dz = dpre1 V1^T (latent tile `wave`)
-    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
-        if (ks < a.KT) acc = mfma16(A1[ks], *(const uint4*)(act2 + ks * 1024 + a_off), acc);
-    if (has3 && valid) {
-        const int f0 = 16 * wave + 4 * q;
-        if (a.DZH) *(uint2*)(a.DZH + (size_t)row * a.ldDZ + f0) = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
-        else *(float4*)(a.DZ + (size_t)row * a.ldDZ + f0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-}
 
 // Wave-wide sum / max through the DPP path (row_shr 1, 2, 4, 8, then row_bcast 15 and 31: the total arrives in lane 63 and is handed to
 // every lane through an SGPR): six vector instructions of ~10 cycles each, where the ds_bpermute butterfly of __shfl_xor is six LDS
@@ -1120,6 +1103,7 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
         }
         if (a.lq_dreg) dreg += wn * wn * (src.term(a, 1, s, r) + src.px_total(a, s, r) - src.lq_dreg(a, s, r));   // tasks/task02.py:70-73
         a.gx[r] = G;
+        if (a.gx_local && r >= a.gx_r0 && r < a.gx_r0 + 16) a.gx_local[r - a.gx_r0] = G;
         a.cf[r] = cf;
     }
     eq14 = red.sum(eq14); dreg = red.sum(dreg);
@@ -1151,6 +1135,118 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
         pb[PB_T1 * B + b] = sum_t1 / (float)k;
         pb[PB_T2 * B + b] = sum_t2 / (float)k;
         pb[PB_DREG * B + b] = dreg;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dec_bwd_rows_kernel: the decoder's dX chain (dec_bwd_kernel's three products) on FEW rows, in block_bwd_kernel's form: a 16-wave
+// workgroup owns 16 rows, wave w owns hidden tile w of the first two products (latent tile w of the third), the weight fragments
+// come straight from the L2-resident images -- for dg2 = s W3^T the K-major image of W3 (rows = hidden tile, k = pixels), streamed
+// AD deep over the 25 pixel k-steps -- and s / dpre2 / dpre1 sit in LDS as 1 KiB k-step blocks.  dec_bwd_kernel streams every weight
+// unit through ONE workgroup's LDS per 128 rows: at 20 rows that is a single workgroup walking 19 units in turn (27 us).
+// ---------------------------------------------------------------------------------
+template <int AD>
+__global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(DecBwdRowsArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rho = lane & 15, q = lane >> 4;
+    const int r0 = blockIdx.x * 16;
+    const int row = r0 + rho;
+    const bool valid = row < a.M;
+    const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
+    char* act0 = smem;                                   // s tile: KTX blocks
+    char* act1 = smem + (size_t)a.KTX * 1024;            // dpre2: KT blocks
+    char* act2 = act1 + (size_t)a.KT * 1024;             // dpre1: KT blocks
+    float* gx_lds = (float*)(smem + (size_t)(a.KTX + 2 * a.KT) * 1024);      // 16 floats behind the three activation tiles (lse_on)
+    if (a.lse_on) {       // wave w: image b0 + w of the (<= 16) images this workgroup's rows belong to (lse_kernel's job, iwae1.py:113-139).
+                          // First thing in the kernel: beside the weight fragments' loads it cost 15 spilled registers in the <= 96-register shape.
+        const int b0 = r0 / a.lse.k, b1 = min(r0 + 15, a.M - 1) / a.lse.k;
+        if (b0 + wave <= b1) {
+            LseArgs la = a.lse;
+            la.gx_local = gx_lds; la.gx_r0 = r0;
+            lse_image(la, b0 + wave, lane, LseGlobalSrc{});
+        }
+    }
+    for (int c = threadIdx.x; c < a.KTX * 64; c += 1024) {
+        const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + rr < a.M) v = *(const uint4*)(a.SP + (size_t)(r0 + rr) * a.ldS + ks * 32 + qq * 8);
+        *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
+    }
+    const int mg = wave >> 2, tg = wave & 3;
+    const bool has = wave < a.NT1, has3 = wave < a.NT3;
+    const char* w3 = a.imgK3 + (size_t)wave * 1024 + a_off;                    // block (pixel k-step ks, hidden tile wave) = (ks*MT + wave) KiB
+    const char* w2 = a.imgB2 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
+    const char* w1 = a.imgB1 + (size_t)mg * img_mg_group_bytes(a.KT) + tg * 1024 + a_off;
+    uint4 A2[BLOCKFWD_MAX_KT], A1[BLOCKFWD_MAX_KT];
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A2[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT && has) A2[ks] = *(const uint4*)(w2 + (size_t)ks * 4096);
+    }
+    const int kso = wave >> 1, hh = wave & 1;
+    uint2 y2 = make_uint2(0, 0), y1 = make_uint2(0, 0);
+    float gxr = 0.0f;
+    if (valid && has) {
+        y2 = *(const uint2*)(a.G2 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+        y1 = *(const uint2*)(a.G1 + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh);
+        if (!a.lse_on) gxr = a.gx[row];
+    }
+    auto dtanh = [&](const f32x4& acc, const uint2& y, float sc) {
+        const float ya = bflo(y.x), yb = bfhi(y.x), yc = bflo(y.y), yd = bfhi(y.y);
+        return make_uint2(pack2(sc * acc[0] * (1.0f - ya * ya), sc * acc[1] * (1.0f - yb * yb)), pack2(sc * acc[2] * (1.0f - yc * yc), sc * acc[3] * (1.0f - yd * yd)));
+    };
+    // ---- product 1: dg2 = s W3^T over the KTX pixel k-steps, A fragments streamed AD deep
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const size_t kstride = (size_t)a.MT3 * 1024;
+        uint4 av[AD];
+#pragma unroll
+        for (int i = 0; i < AD; ++i) av[i] = (i < a.KTX && has) ? *(const uint4*)(w3 + (size_t)i * kstride) : make_uint4(0, 0, 0, 0);
+        __syncthreads();                         // s tile staged (and the row weights in LDS)
+        for (int k0 = 0; k0 < a.KTX; k0 += AD) {
+#pragma unroll
+            for (int i = 0; i < AD; ++i) {
+                const int ks = k0 + i;
+                if (ks < a.KTX) {
+                    acc = mfma16(av[i], *(const uint4*)(act0 + ks * 1024 + a_off), acc);
+                    if (ks + AD < a.KTX && has) av[i] = *(const uint4*)(w3 + (size_t)(ks + AD) * kstride);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks) {
+        A1[ks] = make_uint4(0, 0, 0, 0);
+        if (ks < a.KT && has3) A1[ks] = *(const uint4*)(w1 + (size_t)ks * 4096);
+    }
+    if (a.lse_on && valid) gxr = gx_lds[rho];      // (written in front of the s-tile barrier above)
+    if (has) {
+        const uint2 v = valid ? dtanh(acc, y2, gxr) : make_uint2(0, 0);      // dpre2 = g_r * dg2 * (1 - g2^2)
+        *(uint2*)(act1 + kso * 1024 + a_off + 8 * hh) = v;
+        if (valid) *(uint2*)(a.D2P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
+    }
+    __syncthreads();
+    // ---- product 2: dpre1 = (dpre2 V2^T) * (1 - g1^2)
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT) acc = mfma16(A2[ks], *(const uint4*)(act1 + ks * 1024 + a_off), acc);
+    if (has) {
+        const uint2 v = valid ? dtanh(acc, y1, 1.0f) : make_uint2(0, 0);
+        *(uint2*)(act2 + kso * 1024 + a_off + 8 * hh) = v;
+        if (valid) *(uint2*)(a.D1P + (size_t)row * a.ldH + kso * 32 + q * 8 + 4 * hh) = v;
+    }
+    __syncthreads();
+    // ---- product 3: dz = dpre1 V1^T (latent tile `wave`)
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BLOCKFWD_MAX_KT; ++ks)
+        if (ks < a.KT) acc = mfma16(A1[ks], *(const uint4*)(act2 + ks * 1024 + a_off), acc);
+    if (has3 && valid) {
+        const int f0 = 16 * wave + 4 * q;
+        if (a.DZH) *(uint2*)(a.DZH + (size_t)row * a.ldDZ + f0) = make_uint2(pack2(acc[0], acc[1]), pack2(acc[2], acc[3]));
+        else *(float4*)(a.DZ + (size_t)row * a.ldDZ + f0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -4409,8 +4505,9 @@ bool dec_bwd_rows_ok(const DecBwdRowsArgs& a) {
     return a.KT <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT && a.NT3 <= 16 && (size_t)(a.KTX + 2 * a.KT) * 1024 <= 150 * 1024;
 }
 void launch_dec_bwd_rows(const DecBwdRowsArgs& a, hipStream_t st) {
-    if (a.M <= 512 && a.KTX > 8) LAUNCH_EV((dec_bwd_rows_kernel<13>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
-    else LAUNCH_EV((dec_bwd_rows_kernel<6>), dim3((a.M + 15) / 16), dim3(1024), (size_t)(a.KTX + 2 * a.KT) * 1024, st, a);
+    const size_t lds = (size_t)(a.KTX + 2 * a.KT) * 1024 + 64;      // (+ the 16 row weights of lse_on)
+    if (a.M <= 512 && a.KTX > 8) LAUNCH_EV((dec_bwd_rows_kernel<13>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a);
+    else LAUNCH_EV((dec_bwd_rows_kernel<6>), dim3((a.M + 15) / 16), dim3(1024), lds, st, a);
 }
 bool block_bwd_ok(const BlockBwdArgs& a) {
     return a.R <= 4096 && a.KTH <= BLOCKFWD_MAX_KT && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT1;

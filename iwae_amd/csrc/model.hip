@@ -175,6 +175,9 @@ struct iwae_model {
     bool allow_dec_rows = true;                      // ... and, with <= 2 048 DATA rows, the decoder's in the same launch (dec_rows_step; option no_dec_rows)
     bool allow_wgrad_rows = true;                    // few rows (<= 2 048): the image encoder's weight gradients + Adam in ONE launch, whole row reduction per workgroup (wgrad_rows_kernel; option no_wgrad_rows)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
+    bool allow_lat_in_block = true;                  // few images: latent_bwd_kernel's sums inside the encoder's block_bwd_kernel (option no_lat_in_block)
+    bool lse_pending = false, allow_lse_in_bwd = true;      // few rows: this step's lse_kernel work was left to dec_bwd_rows_kernel (lse_saved; option no_lse_in_bwd)
+    LseArgs lse_saved;
     bool lse_dup = false, allow_lse_dup = true;      // IWAE_NO_LSE_DUP=1: one lse_kernel, the side stream forks behind it (A/B measurements)
     BlockWs wenc1, wenc2, wdec2, wprior;
     MlpWs wdec1;
@@ -619,8 +622,11 @@ int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint1
 // backward of one BasicBlock over R rows: the dX chain first, then the three weight gradients -- they only feed the
 // slab reduction, so for small R (latency-bound 8-wave kernels) they go out as ONE grouped launch
 // dx_done: the dX chain (dhead -> d2 -> d1 -> dx) has been computed already (gblock_bwd_kernel): only the weight gradients are left
+// lat != null: the block's dhead rows are made inside block_bwd_kernel (latent_bwd_kernel's sums, a wave per image) -- *lat_taken says whether
+// that happened (else the caller launches latent_bwd_kernel first and calls again without it)
 int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R, bool need_dx, bool wgrad_on_side, bool dx_done = false, hipStream_t side_st = nullptr,
-              bool skip_wgrad = false) {
+              bool skip_wgrad = false, const LatentBwdArgs* lat = nullptr, bool* lat_taken = nullptr) {
+    if (lat_taken) *lat_taken = false;
     bool chain_fused = dx_done;
     if (dx_done) need_dx = false;
     if (!dx_done && m->allow_block_fused && !blk[2].kmajor && !blk[1].kmajor && blk[1].Np32 == blk[0].Np32 && blk[1].Kp32 == blk[0].Np32 && blk[2].Kp32 == blk[0].Np32) {
@@ -630,8 +636,12 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
         b.KTH = blk[2].KT_B; b.KT1 = blk[1].KT_B; b.NT1 = blk[0].Np32 / 16; b.R = R;
         b.H2 = ptr<uint16_t>(w.h2P); b.H1 = ptr<uint16_t>(w.h1P); b.ldH = blk[0].Np32;
         b.D2 = ptr<uint16_t>(w.d2P); b.D1 = ptr<uint16_t>(w.d1P);
-        if (block_bwd_ok(b)) { launch_block_bwd(b, m->stream); chain_fused = true; }
-    }
+        if (block_bwd_ok(b)) {
+            if (lat && lat->Dp <= 128 && lat->Dp == blk[2].Np32 / 2 && !lat->prior_head && !lat->DHF) { b.lat_on = 1; b.lat = *lat; if (lat_taken) *lat_taken = true; }
+            else if (lat) return IWAE_OK;      // (not taken: nothing launched)
+            launch_block_bwd(b, m->stream); chain_fused = true;
+        } else if (lat) return IWAE_OK;
+    } else if (lat) return IWAE_OK;
     if (!chain_fused) {
         CHK(dense_dx(m, blk[2], ptr<uint16_t>(w.dheadP), R, ptr<uint16_t>(w.h2P), ptr<uint16_t>(w.d2P), nullptr));
         CHK(dense_dx(m, blk[1], ptr<uint16_t>(w.d2P), R, ptr<uint16_t>(w.h1P), ptr<uint16_t>(w.d1P), nullptr));
@@ -746,6 +756,16 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
 hipStream_t eps_draw_stream(const iwae_model* m, int M) {
     if (dec_rows_step(m, M, m->B)) return m->stream;      // (that backward pass touches no side stream at all: the draw stays in stream order)
     return (m->allow_wg3 && m->use_side2 && m->side2 && M <= 4096 && m->early_wout) ? m->side2 : m->side;
+}
+
+// will this step's backward pass run the decoder's dX chain as dec_bwd_rows_kernel (few rows)?  Mirrors backward_impl's choice (which
+// copes with a wrong answer: a pending log-mean-exp is then launched as lse_kernel after all); m->s_mode must be decided.
+bool dec_bwd_rows_planned(const iwae_model* m, int M) {
+    const Linear& L = m->dec1[2];
+    if (!(m->s_mode && m->allow_dec_bwd && m->small_dec_bwd && M <= m->small_rows && out_bwd_has_s_mode(L.KT) && !m->want_stamps)) return false;
+    if (!(L.kmajor && L.imgB && m->dec1[1].KT_B == L.KT && m->dec1[1].MG_B == (L.KT + 1) / 2 && m->dec1[0].KT_B == L.KT && m->dec1[1].Kp32 == L.Kp32 &&
+          m->dec1[0].Np32 == L.Kp32)) return false;
+    return M <= m->dec_rows_max && m->allow_block_fused && m->cfg.n_layers == 1;
 }
 
 int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const float* eps, int objective, bool bwd,
@@ -1089,8 +1109,12 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights lse_kernel leaves -- not
         // out_bwd -- so the side stream forks here (ev_lse on this kernel's dispatch packet), one kernel earlier, and the
         // gradient runs beside out_bwd (both read s)
+        // Few rows (round 4): the training step's log-mean-exp is done by the backward pass's first kernel (dec_bwd_rows_kernel, a wave per
+        // image in front of its own work): one dependent launch less on a chain of ~10 us launches
+        m->lse_pending = bwd && m->allow_lse_in_bwd && !m->lse_dup && !m->early_wout && dec_bwd_rows_planned(m, M);
+        if (m->lse_pending) m->lse_saved = a;
         if (m->early_wout && !m->lse_dup) set_launch_stop_event(m->ev_lse);
-        launch_lse(a, st);
+        if (!m->lse_pending) launch_lse(a, st);
         if (m->lse_dup) {       // the side stream's copy: same inputs, its own outputs
             CHK(ensure(m->logw2, (size_t)Mp * 4, st));
             CHK(ensure(m->wn2, (size_t)Mp * 4, st));
@@ -1175,12 +1199,14 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 dz_half = !two && m->allow_dz_half;
                 r.DZ = ptr<float>(w.dz); r.DZH = dz_half ? (uint16_t*)w.dz.p : nullptr;
                 if (dec_bwd_rows_ok(r)) {
+                    if (m->lse_pending) { r.lse_on = 1; r.lse = m->lse_saved; m->lse_pending = false; }      // (forward_impl left the log-mean-exp to this kernel)
                     ScopedTimer tm(m, T_DEC_BWD);
                     if (!dec_rows) set_launch_stop_event(m->ev_fork2);
                     launch_dec_bwd_rows(r, st);
                     rows_kernel = true;
                 }
             }
+            if (m->lse_pending) { launch_lse(m->lse_saved, st); m->lse_pending = false; }      // (the plan did not hold: lse_kernel after all, in front of everything that reads the row weights)
             if (rows_kernel) {
             } else if (fused_dx) {
                 DecBwdArgs d;
@@ -1353,6 +1379,8 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         dz1_b = ptr<float>(m->dzdir); dz1_c = ptr<float>(m->wenc2.dx);     // summed inside latent_bwd_kernel
         }
     }
+    LatentBwdArgs lat_args;
+    bool lat_fuse = false;
     {
         LatentBwdArgs a;
         memset(&a, 0, sizeof(a));
@@ -1365,12 +1393,26 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         a.kmu = a.ksig = (objective == OBJ_VAE_ELBO_KL) ? m->beta / (float)B : 0.f;
         a.DHP = ptr<uint16_t>(m->wenc1.dheadP);
         if (m->has_prior) { a.prior_head = ptr<float>(m->wprior.head); a.DHP2 = ptr<uint16_t>(m->wprior.dheadP); }
-        { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
+        // Few images and samples (round 4): these per-image sums are made inside the encoder's block_bwd_kernel (a wave per image in front of
+        // its dX chain) -- one dependent launch less; the separate kernel (256 threads per image) stays for many samples per image
+        lat_args = a;
+        // (measured, end-to-end us per step with / without: B = 20, k = 1: 67.7 / 70.0; B = 20, k = 5: 67.5 / 69.3; B = 100, k = 5: 72.1 / 73.4; B = 20, k = 50: 88.2 / 78.5 --
+        // one wave walking 50 samples is slower than latent_bwd_kernel's 256 threads: up to 16 samples per image)
+        lat_fuse = m->allow_lat_in_block && !m->has_prior && B <= 1024 && k <= 16 && m->allow_block_fused;
+        if (!lat_fuse) { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     // Round 4: on few rows the image encoder's weight gradients, their sum over ALL rows and (fused step) the Adam update are one launch
     // (wgrad_rows_kernel) -- the encoder's layers (the head of the table) then need no slabs and no share of reduce_grads_kernel
     const bool rows_enc = wgrad_rows_ok(m, m->enc1, B);
+    if (lat_fuse) {
+        bool taken = false;
+        CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false, false, nullptr, rows_enc, &lat_args, &taken));
+        if (!taken) {      // (shapes block_bwd_kernel does not cover: the separate kernel after all, then the block's backward pass)
+            { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(lat_args, st); }
+            CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false, false, nullptr, rows_enc));
+        }
+    } else
     CHK(block_bwd(m, m->enc1, m->wenc1, ptr<uint16_t>(m->xP), B, false, false, false, nullptr, rows_enc));
     if (m->descs_dirty) CHK(build_descs(m));      // (the encoder's splits were planned after the first build)
     const int enc_end = m->enc1[2].sub[m->enc1[2].nsub - 1] + 1;      // first table entry behind the image encoder's layers
@@ -2283,6 +2325,8 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_dec_rows") m->allow_dec_rows = !on;             // few data rows: the decoder's weight gradients as the grouped launch on the side stream + deferred reduction
     else if (n == "no_wgrad_rows") m->allow_wgrad_rows = !on;         // few rows: the encoder's weight gradients as the grouped launch + slabs + reduce_grads_kernel
     else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
+    else if (n == "no_lat_in_block") m->allow_lat_in_block = !on;     // few images: latent_bwd_kernel as its own launch in front of the encoder's backward pass
+    else if (n == "no_lse_in_bwd") m->allow_lse_in_bwd = !on;         // few rows: lse_kernel as its own launch between decoder forward and backward
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
     else if (n == "no_lse_dup") m->allow_lse_dup = !on;               // one lse_kernel, the side stream forks behind it
     else if (n == "dz_f32") m->allow_dz_half = !on;                   // dec_bwd_kernel leaves dz as float32

@@ -386,7 +386,7 @@ def test_kernel_variants_agree(gpu, B, k):
     for env in ({"out_recompute": 1}, {"dense_g1": 0}, {"no_zin": 1}, {"no_bern_pipe": 1},
                 {"no_dec_fused": 1}, {"no_block_fused": 1}, {"no_early_wout": 1}, {"bern_qw_force": 1},
                 {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"no_lse_fused": 1}, {"no_wg3": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
-                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}, {"no_dec_rows": 1}):
+                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}, {"no_dec_rows": 1}, {"no_lse_in_bwd": 1}, {"no_lat_in_block": 1}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env
@@ -544,7 +544,8 @@ def test_deferred_decoder_update_is_bitwise_equivalent(gpu):
 
 @pytest.mark.parametrize("nh,nl,opts", [(256, 128, {}), (16, 4, {}), (200, 100, {"no_early_wout": 1}), (200, 100, {"out_recompute": 1}),
                                         (96, 20, {}), (200, 100, {"no_wg3": 1}), (200, 100, {}), (200, 100, {"no_dec_rows": 1}),
-                                        (256, 128, {"no_dec_rows": 1}), (200, 100, {"no_dec_rows": 1, "out_recompute": 1})])
+                                        (256, 128, {"no_dec_rows": 1}), (200, 100, {"no_dec_rows": 1, "out_recompute": 1}),
+                                        (200, 100, {"no_lse_in_bwd": 1}), (200, 100, {"no_lat_in_block": 1})])
 def test_speculative_noise_draw_is_ordered_on_every_kernel_path(gpu, nh, nl, opts):
     """The next step's noise is drawn a step ahead on a side stream (forward_impl).  Which side stream must follow what the backward
     pass of THAT step uses: hidden widths without a stored-s instantiation (256, 16, 96) and the options out_recompute / no_early_wout
