@@ -36,7 +36,7 @@ struct LseArgs {
     float* logw; float* wn; float* gx; float4* cf; float* per_b;
     int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
     float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
-    float* gx_local; int gx_r0;          // optional: the row weights of rows [gx_r0, gx_r0 + 16) also go to gx_local[row - gx_r0] (a kernel that does lse_image's work for its own 16 rows: dec_bwd_rows_kernel)
+    float* gx_local; int gx_r0, gx_n;    // optional: the row weights of rows [gx_r0, gx_r0 + gx_n) also go to gx_local[row - gx_r0] (kernels that do lse_image's work for their own rows: dec_bwd_rows_kernel, bern_pipe_kernel)
 };
 
 struct DenseArgs {
@@ -72,6 +72,10 @@ struct DenseArgs {
     // forward and the backward pass (lse.term[0] is ignored: log p(x|z) comes from the kernel's own sums)
     int lse_on;
     LseArgs lse;
+    // ... and with the row weights in hand it leaves g2w = bf16(g_r * g2) [M][32*KT] (P-layout) for the output layer's weight gradient, which then
+    // needs NO row weighting (dW3 = g2w^T s; feature g2w_feat -- a pad column of the hidden width -- carries g_r itself: its product row is the
+    // bias gradient).  null: not wanted.
+    uint16_t* G2W; int g2w_feat;
 };
 
 struct SampleArgs {
@@ -275,6 +279,7 @@ struct LayerDesc {
     char* imgF; int KT_F;             // forward image (rows = out-features)
     char* imgB; int KT_B; int MT_B; int imgB_kmajor;   // backward image (rows = in-features) or null
     const float* slabW; const float* slabB; int nsplit; int slab_ld; size_t slab_stride;
+    size_t slabB_stride;              // distance between the row splits' bias sums (0: slab_ld, the usual [nsplit][slab_ld] array; the pre-weighted output layer keeps them as a row of slabW)
     int block_begin;                  // first block of this layer in the flat elementwise grid (256 elements per block)
     int rblock_begin;                 // same for the slab-reduce grid (64 elements per block)
 };

@@ -1103,7 +1103,7 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
         }
         if (a.lq_dreg) dreg += wn * wn * (src.term(a, 1, s, r) + src.px_total(a, s, r) - src.lq_dreg(a, s, r));   // tasks/task02.py:70-73
         a.gx[r] = G;
-        if (a.gx_local && r >= a.gx_r0 && r < a.gx_r0 + 16) a.gx_local[r - a.gx_r0] = G;
+        if (a.gx_local && r >= a.gx_r0 && r < a.gx_r0 + a.gx_n) a.gx_local[r - a.gx_r0] = G;
         a.cf[r] = cf;
     }
     eq14 = red.sum(eq14); dreg = red.sum(dreg);
@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(1024, (AD > 6 ? 2 : 5)) void dec_bwd_rows_kernel(De
         const int b0 = r0 / a.lse.k, b1 = min(r0 + 15, a.M - 1) / a.lse.k;
         if (b0 + wave <= b1) {
             LseArgs la = a.lse;
-            la.gx_local = gx_lds; la.gx_r0 = r0;
+            la.gx_local = gx_lds; la.gx_r0 = r0; la.gx_n = 16;
             lse_image(la, b0 + wave, lane, LseGlobalSrc{});
         }
     }
@@ -1736,7 +1736,31 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                     }
                     __device__ __forceinline__ float lq_dreg(const LseArgs& la, int s, int r) const { return made_lqd ? lz[416 + l0 + s] : la.lq_dreg[r]; }
                 };
-                lse_image(a.lse, b, lane, Src{lz, wave * a.k, a.zhead != nullptr, a.zhead != nullptr && a.zlq_dreg != nullptr});
+                LseArgs la = a.lse;
+                la.gx_local = lz + 832; la.gx_r0 = blockIdx.x * ROWS; la.gx_n = ROWS;      // (the rows' weights also into LDS: g2w below)
+                lse_image(la, b, lane, Src{lz, wave * a.k, a.zhead != nullptr, a.zhead != nullptr && a.zlq_dreg != nullptr});
+            }
+            if (a.G2W) {
+                // round 4: g2w = bf16(g_r * g2) of the tile's rows, from the g2 fragments this wave still holds -- the output layer's weight gradient
+                // then runs without row weighting (its loaders' 870 cycles of weighting per stage were what a stage took); pad feature g2w_feat = g_r
+                __syncthreads();
+                if (valid && storer) {
+                    const float gr = lz[832 + tile * 16 + rho];
+                    const int pp = p_pos(a.g2w_feat), ksf = pp >> 5, qf = (pp & 31) >> 3, ef = pp & 7;
+#pragma unroll
+                    for (int ks = 0; ks < KTC; ++ks) {
+                        const uint4 f = bfr[ks];
+                        uint32_t w[4] = {pack2(bflo(f.x) * gr, bfhi(f.x) * gr), pack2(bflo(f.y) * gr, bfhi(f.y) * gr),
+                                         pack2(bflo(f.z) * gr, bfhi(f.z) * gr), pack2(bflo(f.w) * gr, bfhi(f.w) * gr)};
+                        if (ks == ksf && q == qf) {
+                            const uint32_t gb = pack2(gr, 0.0f) & 0xffffu;
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; ++e2)
+                                if (e2 == (ef >> 1)) w[e2] = (ef & 1) ? ((w[e2] & 0x0000ffffu) | (gb << 16)) : ((w[e2] & 0xffff0000u) | gb);
+                        }
+                        *(uint4*)(a.G2W + (size_t)row * (32 * KTC) + ks * 32 + q * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                }
             }
         }
     }
@@ -3559,11 +3583,12 @@ __global__ __launch_bounds__((8 + NLW) * 64, NLW == 8 ? 4 : 3) void wgradws_kern
     int bx = blockIdx.x, bz = blockIdx.z;
     wgradws_block(bx, bz, gridDim.x, gridDim.z);
     const int sid = bz * (int)gridDim.x + bx;
-    if constexpr (SC && BJ == 4) {
+    if constexpr (BJ == 4) {
         // a last column block of <= 64 real out-features (the reference's 784 pixels = 3 x 256 + 64, padded to 832): its workgroups
         // take the 64-wide strip shape -- 4 instead of 16 G pieces per stage, 7 instead of 28 MFMAs per wave -- instead of fetching and
         // multiplying 192 columns of zeros (workgroup-uniform branch)
-        if (bx == (int)gridDim.x - 1 && a.JT - bx * 16 <= 4) { wgradws_body<SC, 1, NLW>(a, bx * 16, bz, sid); return; }
+        // (round 4: the unweighted kernel too, where it is a remainder block of a wider layer: the pre-weighted output layer)
+        if (bx == (int)gridDim.x - 1 && a.JT - bx * 16 <= 4 && (SC || gridDim.x > 1)) { wgradws_body<SC, 1, NLW>(a, bx * 16, bz, sid); return; }
     }
     wgradws_body<SC, BJ, NLW>(a, bx * 4 * BJ, bz, sid);
 }
@@ -4094,7 +4119,7 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(const LayerDesc* laye
         j = (g - i * n4) * 4;
         const bool is_b = i == L.Kin;
         const float* p = is_b ? (L.slabB + L.joff + j) : (L.slabW + (size_t)i * L.slab_ld + L.joff + j);
-        const size_t stride = is_b ? (size_t)L.slab_ld : L.slab_stride;
+        const size_t stride = is_b ? (L.slabB_stride ? L.slabB_stride : (size_t)L.slab_ld) : L.slab_stride;
         // slab rows start 16-byte aligned (joff, slab_ld multiples of 16 floats): float4 loads; columns >= Nout are pads (zeros / ignored)
         // 8 slabs' loads in flight per thread, summed in slab order (a 64-split layer was 4 round trips of 4 loads: the kernel's time
         // was this chain, not its bytes)
@@ -4543,7 +4568,7 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
         if (a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8) {       // 16-wave / 200-row shape (see QW)
-            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024 + 4096;      // (last 4 KiB: the rows' terms for the in-kernel lse_image)
+            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024 + 4096 + 1024;      // (last 5 KiB: the rows' terms for the in-kernel lse_image, 208 floats each, and its row weights)
             if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
             else LAUNCH_EV((bern_pipe_kernel<7, false, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
         } else if (a.pre_img1) {       // the whole decoder in one launch

@@ -67,6 +67,7 @@ struct BlockWs {   // activations / gradients of one BasicBlock applied to R row
 };
 struct MlpWs {     // decode_z_to_x applied to M rows
     DevBuf g1P, g2P, dlP, d2P, d1P, dz;
+    DevBuf g2wP;      // g2 times the row weight (bf16, P-layout; pad feature H = the row weight): the pre-weighted operand of the output layer's weight gradient
 };
 
 }  // namespace
@@ -175,6 +176,11 @@ struct iwae_model {
     bool allow_dec_rows = true;                      // ... and, with <= 2 048 DATA rows, the decoder's in the same launch (dec_rows_step; option no_dec_rows)
     bool allow_wgrad_rows = true;                    // few rows (<= 2 048): the image encoder's weight gradients + Adam in ONE launch, whole row reduction per workgroup (wgrad_rows_kernel; option no_wgrad_rows)
     bool lse_fused = false, allow_lse_fused = true;  // the decoder kernel does lse_kernel's work for its rows (option no_lse_fused)
+    // Option g2w (round 4, measured and NOT the default): the decoder kernel leaves g2w = bf16(g_r g2) and the output layer's weight gradient runs
+    // unweighted on it (no 870 cycles of row weighting per loader stage).  That kernel got faster (107 -> 97 us in the step) and the step SLOWER
+    // (0.2044 -> 0.2154 ms, interleaved A/B): the decoder kernel pays 4 us for 23 MB more writes and the backward phase is bound by its bytes, not
+    // by that kernel's instruction stream.
+    bool allow_g2w = false, g2w = false, g2w_descs = false;
     bool allow_lat_in_block = true;                  // few images: latent_bwd_kernel's sums inside the encoder's block_bwd_kernel (option no_lat_in_block)
     bool lse_pending = false, allow_lse_in_bwd = true;      // few rows: this step's lse_kernel work was left to dec_bwd_rows_kernel (lse_saved; option no_lse_in_bwd)
     LseArgs lse_saved;
@@ -402,6 +408,11 @@ int build_descs(iwae_model* m) {
             d.imgB = L->imgB; d.KT_B = L->KT_B; d.MT_B = L->MT_B; d.imgB_kmajor = L->kmajor;
             d.slabW = ptr<float>(L->slabW); d.slabB = ptr<float>(L->slabB);
             d.nsplit = L->nsplit; d.slab_ld = L->JT * 16; d.slab_stride = (size_t)L->IT * 16 * L->JT * 16;
+            d.slabB_stride = 0;
+            if (m->g2w && L == &m->dec1[2]) {      // pre-weighted output layer: the bias gradient is product row H (the pad feature that carries g_r) of every slab
+                d.slabB = ptr<float>(L->slabW) + (size_t)kl.Kin * d.slab_ld;
+                d.slabB_stride = d.slab_stride;
+            }
         }
     }
     int blocks = 0, rblocks = 0;
@@ -425,6 +436,7 @@ int build_descs(iwae_model* m) {
     if (m->side) HIPCHK(hipStreamSynchronize(m->side));      // a deferred decoder update may still be reading the old table
     if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
     m->descs_dirty = false;
+    m->g2w_descs = m->g2w;
     return IWAE_OK;
 }
 
@@ -1076,6 +1088,14 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
                 if (bern_lse_ok(a)) m->lse_fused = true;
                 else { a.lse_on = 0; memset(&a.lse, 0, sizeof(a.lse)); }
             }
+            // round 4: with the row weights made inside the decoder kernel, it also leaves g2w = bf16(g_r g2) -- the output layer's weight gradient
+            // (forked right behind this kernel) then needs no row weighting.  Needs a pad column in the hidden width for g_r itself (the bias gradient).
+            const bool g2w_now = m->lse_fused && m->early_wout && m->allow_g2w && m->s_mode && m->dec1[2].Kin < m->dec1[2].Kp32 && !two;
+            if (g2w_now) {
+                CHK(ensure(w.g2wP, (size_t)Mp * Hp * 2, st));
+                a.G2W = ptr<uint16_t>(w.g2wP); a.g2w_feat = m->dec1[2].Kin;
+            }
+            if (bwd && g2w_now != m->g2w) { m->g2w = g2w_now; m->descs_dirty = true; }      // (the layer table says where the output layer's bias sums are)
             // s-mode training step: the output layer's weight gradient needs s, g2 and the row weights -- not out_bwd -- so the
             // side stream forks early.  Round 2: it forks behind THIS kernel (event on its dispatch packet) and runs its own copy of
             // lse_kernel (7 us, a few waves) for the row weights, instead of forking behind the main stream's lse_kernel: the ~12 us
@@ -1274,7 +1294,8 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
         ScopedTimer tm(m, T_WGRAD_OUT, sd);
         if (m->early_wout && m->use_side2) set_launch_stop_event(m->ev_s2);
-        CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->lse_dup ? m->gx2 : m->gx) : nullptr));
+        if (m->g2w) CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2wP), ptr<uint16_t>(w.dlP), M, sd, nullptr));      // (pre-weighted X operand: the unweighted kernel)
+        else CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->lse_dup ? m->gx2 : m->gx) : nullptr));
     }
     if (!fused_dx) {
         { ScopedTimer tm(m, T_DX_HID); CHK(dense_dx(m, m->dec1[1], ptr<uint16_t>(w.d2P), M, ptr<uint16_t>(w.g1P), ptr<uint16_t>(w.d1P), nullptr)); }
@@ -2325,6 +2346,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_dec_rows") m->allow_dec_rows = !on;             // few data rows: the decoder's weight gradients as the grouped launch on the side stream + deferred reduction
     else if (n == "no_wgrad_rows") m->allow_wgrad_rows = !on;         // few rows: the encoder's weight gradients as the grouped launch + slabs + reduce_grads_kernel
     else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
+    else if (n == "g2w") m->allow_g2w = on;                           // the decoder kernel leaves bf16(g_r g2); the output layer's weight gradient runs unweighted on it (measured slower)
     else if (n == "no_lat_in_block") m->allow_lat_in_block = !on;     // few images: latent_bwd_kernel as its own launch in front of the encoder's backward pass
     else if (n == "no_lse_in_bwd") m->allow_lse_in_bwd = !on;         // few rows: lse_kernel as its own launch between decoder forward and backward
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel
