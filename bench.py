@@ -93,9 +93,9 @@ def kernel_models(cfg):
         "wgrad_out": dict(name="wgradws_kernel<true,4,4> (output-layer weight gradient dV3 = g2^T (g_r s): 8 compute + 4 loader waves, s weighted on its way through the loaders' registers, side stream)" if big else
                                "wgradp_kernel<8,4,4,4,true> (output-layer weight gradient, side stream)",
                           bytes=M * (2 * H + 2 * X + 4) + 4 * (H * X + X), flop=2 * M * H * X, match="wgradws_kernel<true" if big else "wgradp_kernel<8, 4, 4, 4, true",
-                          note=("NOT on the loop that sets the step: it runs on the side stream beside dec_bwd_kernel and the hidden layers' gradients with ~40 us of slack, on "
-                                "96 one-per-CU workgroups by choice (DESIGN.md section 3, item 49: 128 workgroups make THIS kernel faster -- 51 us alone instead of 65, 95 us in the "
-                                "step instead of 105 -- and the step slower, 0.218 vs 0.213 ms; the two kernels running side by side move 5.1 TB/s of measured traffic between them)"
+                          note=("runs on the side stream beside dec_bwd_kernel and the hidden layers' gradients, on 96 one-per-CU workgroups by choice (DESIGN.md section 3, items 49 "
+                                "and 57: on 128 workgroups THIS kernel is faster -- 52.5 us alone instead of 66, 94 us in the step instead of 108 -- and the step slower, 0.2142 vs "
+                                "0.2042 ms; the backward phase of the step moves ~580 MB at 4.2 TB/s, 88 % of the copy rate of this pool: what one kernel gains the kernels beside it lose)"
                                 if big and cfg["layers"] == 1 else None)),
         "dx_hidden": dict(name="dense_kernel<EPI_DX,7> (dpre1 = (dpre2 V2^T) * (1 - g1^2))", bytes=M * 6 * H, flop=2 * M * H * H, match="dense_kernel<2, 7"),
         "dx_latent": dict(name="dense_kernel<EPI_F32,7> (dz = dpre1 V1^T, fp32)", bytes=M * (2 * H + 4 * D), flop=2 * M * H * D, match="dense_kernel<3, 7"),
@@ -107,7 +107,14 @@ def kernel_models(cfg):
                            bytes=M * ((2 if (big and cfg["layers"] == 1) else 4) * D + 4 * D + 16), flop=0, match="latent_bwd_kernel"),
         "encoder_fwd": dict(name="block_fwd_kernel (encoder BasicBlock on the B images, one launch)",
                             bytes=cfg["B"] * (4 * X + 4 * H + 8 * D) + 2 * (X * H + H * H + 2 * H * D), flop=2 * cfg["B"] * (X * H + H * H + 2 * H * D), match="block_fwd_kernel"),
-        "reduce_adam": dict(name="reduce_grads_kernel (main-stream slab reduction + fused Adam + weight-image refresh)", bytes=0, flop=0, match="reduce_grads_kernel"),
+        # round 4: the main stream's last kernel is wgrad_rows_kernel -- the image encoder's three weight gradients over ALL rows, Keras Adam and the weight-image
+        # refresh in its epilogue (on <= 2 048 data rows the decoder's three layers too); bytes: operands read once, theta / m / v read and written, gradient + images written
+        "reduce_adam": dict(name="wgrad_rows_kernel (encoder weight gradients, whole row reduction per workgroup, + fused Adam + weight-image refresh"
+                                 + (", + the decoder's three layers" if M <= 2048 and cfg["layers"] == 1 else "") + ")",
+                            bytes=cfg["B"] * 2 * (X + 2 * H + 2 * H + 2 * D + H) + 30 * (X * H + H * H + 2 * H * D)
+                                  + (M * 2 * (2 * H + X + H + D + 2 * H) + 30 * (D * H + H * H + H * X) if M <= 2048 and cfg["layers"] == 1 else 0),
+                            flop=2 * cfg["B"] * (X * H + H * H + 2 * H * D) + (2 * M * (D * H + H * H + H * X) if M <= 2048 and cfg["layers"] == 1 else 0),
+                            match="wgrad_rows_kernel"),
     }
     return out
 
@@ -159,7 +166,7 @@ def load_profile_traffic(kernel_match, config):
     """HBM bytes per launch of the kernel whose device-side name contains `kernel_match`, from the PMC passes of
     tools/profile_bench.sh kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: MI355X_MICROARCH.md, HBM).  Returned WITH its
     source, or None when no kept profile holds that instantiation (the number is a profile artefact, not a live measurement)."""
-    for tag in ("r03", "r03_c2"):
+    for tag in ("r04", "r04_c2", "r03", "r03_c2"):      # (newest kept profile of this configuration first)
         path = os.path.join(ROOT, "profiles", "%s_kernel_traffic.json" % tag)
         if not os.path.exists(path):
             continue
