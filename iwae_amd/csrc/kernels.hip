@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                     }
                     const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
                     zf[ks] = valid ? frag : make_uint4(0, 0, 0, 0);
-                    if (valid && storer) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
+                    if (valid && storer && a.ZPout) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
                 }
             }
             lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);

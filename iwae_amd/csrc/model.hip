@@ -249,6 +249,9 @@ struct iwae_model {
     bool allow_chain2 = true;   // option no_chain2: the 2-layer model's per-sample blocks as dense_kernel launches + sample_kernel + gauss_lp_kernel (A/B measurements, variant tests)
     bool allow_dec_bwd = true;  // IWAE_NO_DEC_BWD=1: out_bwd_s + the two dX kernels stay three launches (A/B measurements)
     bool allow_zin = true;      // IWAE_NO_ZIN=1: always the separate sampling kernel (A/B measurements)
+    bool allow_zin_eval = false; // option zin_eval (round 4, measured and NOT the default): forward-only calls on many rows take their draws from eps_gen_kernel and let the decoder
+                                 // kernel make z in its prologue instead of sample_kernel (inline Philox) in front of it -- bf16 evaluator 146 k vs 158 k images/s: the prologue's 20 MB of
+                                 // float32 draws cost the vector-issue-bound kernel more than the separate pass
     bool allow_out_in_block = true;  // IWAE_NO_OUT_IN_BLOCK=1: the output layer of a few-row decoder stays a dense_kernel<EPI_BERN> launch (A/B measurements)
     bool allow_block_fused = true;   // IWAE_NO_BLOCK_FUSED=1: a BasicBlock on few rows stays three dense_kernel launches (A/B measurements)
     int num_cus = 256;               // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -799,7 +802,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     }
     m->user_eps = eps != nullptr;
     // ---- the step's N(0,1) draws: normally already there (prefetched by the previous training step), else drawn now
-    const bool keep_eps = !eps && (bwd || two);
+    // (round 4: a forward-only call on many rows -- the k = 5000 evaluator on bf16 operands -- also takes its draws from eps_gen_kernel, so that the
+    // decoder kernel makes z itself in its prologue instead of sample_kernel drawing inline and writing z out: option zin_eval, off by default -- measured slower)
+    const bool zin_eval = !bwd && !two && m->C == 0 && m->allow_zin && m->allow_zin_eval && (int64_t)B * k >= 8192 && m->allow_dec_fused && m->allow_bern_pipe;
+    const bool keep_eps = !eps && (bwd || two || zin_eval);
     m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
     if (keep_eps) {
         const int np = (m->epsc_par + 1) % 3;
@@ -886,7 +892,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.lq_dreg = want_dreg ? lqd : nullptr;
         // 1-layer training step on the device's own noise: the first decoder layer makes z itself (dense_kernel ZIN mode)
         // (the DReG step too: the decoder kernel's prologue also sums the second log q; if that kernel turns out not to apply, sample_kernel runs after all)
-        fuse_z = m->allow_zin && !two && m->C == 0 && bwd && s.eps.cache != nullptr && M >= 8192 &&
+        fuse_z = m->allow_zin && !two && m->C == 0 && (bwd || zin_eval) && s.eps.cache != nullptr && M >= 8192 &&
                  (m->dec1[0].KT == 4 || m->dec1[0].KT == 2) && m->dec1[0].Kp32 == m->Dp[0];
         // few rows: block_fwd_kernel (the decoder's two tanh layers in one launch, below) makes z itself -- one latency-bound launch less
         sample_in_block = m->allow_block_fused && m->allow_zin && !two && !fuse_z && M <= 4096 && !s.ZF && m->dec1[0].Kp32 == m->Dp[0];
@@ -1038,7 +1044,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.pre_G1 = bwd ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = bwd ? ptr<uint16_t>(w.g2P) : nullptr;
             if (fuse_z) {
                 a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zldE = zin.eps.ldC; a.zD = zin.D; a.zDp = zin.Dp;
-                a.ZPout = zin.ZP; a.zlp = zin.lp_prior; a.zlq = zin.lq; a.zlq_dreg = zin.lq_dreg;
+                a.ZPout = bwd ? zin.ZP : nullptr; a.zlp = zin.lp_prior; a.zlq = zin.lq; a.zlq_dreg = zin.lq_dreg;      // (a forward-only call never reads z back)
             }
             fuse_dec = bern_pipe_ok(a);
             if (!fuse_dec) {
@@ -2335,6 +2341,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     if (n == "out_recompute") m->allow_s_mode = !on;                  // recompute the logits in out_bwd instead of keeping s
     else if (n == "no_defer") m->allow_defer = !on;                   // join the decoder update at the end of every step
     else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
+    else if (n == "zin_eval") m->allow_zin_eval = on;                 // forward-only calls: z made in the decoder kernel's prologue (measured slower)
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
     else if (n == "no_chain2") m->allow_chain2 = !on;                 // 2-layer model: the per-sample blocks unfused
     else if (n == "no_dec_bwd") m->allow_dec_bwd = !on;               // the decoder's dX chain as three launches
