@@ -790,6 +790,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
+    m->lse_pending = false;      // (set again below if this step leaves its log-mean-exp to the backward pass)
     m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X, Xp = m->Xp32, Xinp = m->Xinp;

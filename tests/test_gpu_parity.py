@@ -456,7 +456,13 @@ def test_in_library_data_parallel_step_world1_is_bitwise_the_single_gpu_step(gpu
         m = _model(layers, nh, nl)
         m.set_params(O.flatten_params(P))
         if dp:
-            m.comm_init(NativeModel.comm_unique_id(), 1, 0)
+            blob = NativeModel.comm_unique_id()
+            m.comm_preflight(blob, 1, 0)                                 # the non-collective checks pass ...
+            with pytest.raises(ValueError):
+                m.comm_preflight(blob, 2, 1)                             # ... and refuse what comm_init would refuse, without entering the rendezvous
+            m.comm_init(blob, 1, 0)
+            with pytest.raises(RuntimeError):
+                m.comm_preflight(NativeModel.comm_unique_id(), 1, 0)     # communicators already there
             with pytest.raises(RuntimeError):
                 m.comm_init(NativeModel.comm_unique_id(), 1, 0)          # already initialised: call order error, not a second communicator
         for t in range(12):
