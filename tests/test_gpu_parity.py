@@ -1492,9 +1492,14 @@ def test_bf16_training_reaches_the_float32_trained_llh(gpu, data):
         assert bf.min() >= f32.min() - spread and bf.max() <= f32.max() + spread, (bf, f32)
 
 
-def test_training_reduces_loss_and_matches_oracle_trajectory(gpu):
-    """20 Adam steps with explicit noise: the device parameters track the float64 oracle trajectory."""
-    nh, nl, xd, B, k = 16, 4, 48, 16, 5
+@pytest.mark.parametrize("nh,nl,xd,B,k,steps,lr", [(16, 4, 48, 16, 5, 20, 1e-2), (200, 100, 784, 20, 5, 8, 1e-3), (200, 100, 784, 20, 1, 8, 1e-3),
+                                                  (200, 100, 784, 170, 50, 5, 1e-3)])
+def test_training_reduces_loss_and_matches_oracle_trajectory(gpu, nh, nl, xd, B, k, steps, lr):
+    """Adam steps with explicit noise: the device tracks the oracle's trajectory -- every step's objective is computed from the weights the PREVIOUS
+    step's epilogue wrote into the bf16 images (a misplaced image chunk would show here), the parameters at the end against the oracle's.
+    Round 4: the reference's dims at B = 20 with k = 5 and k = 1 (wgrad_rows_kernel updates all seven layers and writes forward, MG-major and K-major
+    backward images; log-mean-exp and latent sums inside the backward kernels) and at 8 500 rows (that kernel for the encoder, the deferred slab
+    reduction for the decoder)."""
     x, P, _ = MG.inputs(1, nh, nl, xd, B, k, 77)
     m = _model(1, nh, nl, xd)
     m.set_params(O.flatten_params(P))
@@ -1502,17 +1507,20 @@ def test_training_reduces_loss_and_matches_oracle_trajectory(gpu):
     mo = vo = 0.0
     rng = np.random.default_rng(5)
     first = last = None
-    for t in range(1, 21):
+    exact = nh == 16
+    for t in range(1, steps + 1):
         eps = rng.standard_normal((k, B, nl)).astype(np.float32)
-        r = m.train_step(x, k, 1.0, 1e-2, "iwae_elbo", eps=eps)
+        r = m.train_step(x, k, 1.0, lr, "iwae_elbo", eps=eps)
         Pt = O.unflatten_params(flat, 1, nh, nl, xd)
-        res, g = O.loss_grads_1layer(Pt, x, eps, 1.0, "iwae_elbo")
-        flat, mo, vo = O.adam_update(flat, O.flatten_grads(g), mo, vo, t, 1e-2)
+        res, g = O.loss_grads_1layer(Pt, x, eps, 1.0, "iwae_elbo", rnd=None if exact else O.bf16_round)
+        flat, mo, vo = O.adam_update(flat, O.flatten_grads(g), mo, vo, t, lr)
         first = r["iwae_elbo"] if first is None else first
         last = r["iwae_elbo"]
-        assert abs(r["iwae_elbo"] - res["iwae_elbo"]) < 0.05
-    assert last > first + 0.5
-    assert np.max(np.abs(m.get_params() - flat)) < 5e-3
+        assert abs(r["iwae_elbo"] - res["iwae_elbo"]) < 0.05, (t, r["iwae_elbo"], res["iwae_elbo"])
+    assert last > first + (0.5 if exact else 0.2)
+    # Adam's step is ~lr whatever the gradient's size: an element whose gradient is near zero may take another sign on the device -- at most one lr per step
+    d = np.abs(m.get_params() - flat)
+    assert d.max() < (5e-3 if exact else 2.0 * lr * steps) and np.mean(d) < (1e-3 if exact else 0.05 * lr * steps), (d.max(), np.mean(d))
     m.close()
 
 
