@@ -76,6 +76,7 @@ struct DenseArgs {
     // needs NO row weighting (dW3 = g2w^T s; feature g2w_feat -- a pad column of the hidden width -- carries g_r itself: its product row is the
     // bias gradient).  null: not wanted.
     uint16_t* G2W; int g2w_feat;
+    int dbg;                          // DIAG builds only (option fake_s): 32 = the Bernoulli epilogue does not store s
 };
 
 struct SampleArgs {
@@ -171,6 +172,7 @@ struct OutBwdArgs {
     float* part; int gpb;             // SP mode, small row counts: block row y handles gpb pixel groups, fp32 partial dg2 in part[y][M][ldG]
     uint16_t* DPP;                    // dpre of the last hidden layer, P-layout [M][32*KT]
     unsigned long long* stamps;       // diagnostic build only: [blocks*4 waves][8] phase cycle sums, else null
+    int dbg;                          // DIAG builds only (option fake_s; timing only -- results are wrong): 32 = s rows read from the first 32 rows (no HBM stream)
 };
 
 struct DecBwdArgs {                  // dec_bwd_kernel: out_bwd_s + dX of the two tanh layers in one launch

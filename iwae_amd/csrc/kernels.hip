@@ -16,6 +16,11 @@
 #include "kernels.h"
 #include "layout.h"
 
+#ifdef IWAE_DIAG
+#define WG_DBG(a, bit) (((a).dbg & (bit)) != 0)
+#else
+#define WG_DBG(a, bit) false
+#endif
 namespace iwae {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -1491,7 +1496,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     uint4 st[2];
     float rowacc = 0.0f;
     auto store_s = [&](int h, const uint4& v) {
-        if (KEEP && valid) *(uint4*)(a.YP + (size_t)row * a.ldYP + 32 * h + 8 * q) = v;
+        if (KEEP && valid && !WG_DBG(a, 32)) *(uint4*)(a.YP + (size_t)row * a.ldYP + 32 * h + 8 * q) = v;
     };
     // One pipeline stage: the 2*KTC MFMAs of half hN = h+1 (tile pair tbN of the group in buffer bufN, accumulators accN,
     // started from the bias block) are issued in four chunks between the epilogue arithmetic of half h (accC, two logits
@@ -2832,7 +2837,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
                 sf[kk][g] = make_uint4(0, 0, 0, 0);
                 const int fbase = 64 * ng + 32 * kk;      // wave-uniform guard
                 if (fbase < a.Xp32) {
-                    const uint4 v = *(const uint4*)(a.SP + (size_t)rowc[g] * a.Xp32 + fbase + 8 * q);
+                    const uint4 v = *(const uint4*)(a.SP + (size_t)(WG_DBG(a, 32) ? (rowc[g] & 31) : rowc[g]) * a.Xp32 + fbase + 8 * q);
                     sf[kk][g] = valid[g] ? v : make_uint4(0, 0, 0, 0);
                 }
             }
@@ -3053,11 +3058,7 @@ __device__ __forceinline__ void wait_vmem_but(int n) {      // n wave-uniform, 0
 #define WG_NST 4
 // diagnostic ablations of the weight-gradient kernels (WgradPArgs.dbg: timing only, results are wrong) exist in DIAG=1 builds only;
 // in the shipped kernels the conditions fold to false at compile time
-#ifdef IWAE_DIAG
-#define WG_DBG(a, bit) (((a).dbg & (bit)) != 0)
-#else
-#define WG_DBG(a, bit) false
-#endif
+// (WG_DBG: defined at the top of the file)
 // Shapes <NW waves, IGC i-groups, AI x BJ accumulator tiles per wave>: the waves form an IGC x (NW/IGC) grid, the workgroup's
 // output tile is IGC*AI i-tiles x (NW/IGC)*BJ j-tiles.  A 32-row stage costs a wave AI + BJ fragment reads for AI*BJ MFMAs:
 //   <16, 4, 4, 4>  256 x 256 features, 0.50 reads per MFMA (round 1's shape; the hidden layers at large row counts)
@@ -3340,7 +3341,7 @@ __device__ __forceinline__ void wgradws_body(const WgradPArgs& a, const int jt0,
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - NCW;
         const char* zsrc = a.zero + (lane & 31) * 16;
-        const int xstride = WG_SR * a.ldX * 2, gstride = WG_SR * a.ldG * 2;
+        const int xstride = WG_SR * a.ldX * 2, gstride = WG_DBG(a, 32) ? 0 : WG_SR * a.ldG * 2;
         const char* xbase[XPL]; int xlim[XPL];
 #pragma unroll
         for (int i = 0; i < XPL; ++i) {
@@ -3725,12 +3726,18 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             *(uint4*)(a.ZP + (size_t)row * a.Dp + 8 * (4 * t + q)) = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
         if (valid && a.ZF) {       // float32 mode: z in natural feature order, unrounded
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                const int f0 = 32 * t + 16 * h + 4 * q;
+                // (one 16-byte store per lane where the row pitch allows it: as four dword stores under four conditions the evaluator's sampling
+                // kernel took 225 us for 416 k rows -- 64 scattered 4-byte pieces per instruction)
+                if ((a.ldZF & 3) == 0 && f0 + 3 < a.ldZF) {
+                    *(float4*)(a.ZF + (size_t)row * a.ldZF + f0) = make_float4(z8[4 * h], z8[4 * h + 1], z8[4 * h + 2], z8[4 * h + 3]);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int f = 32 * t + 16 * h + 4 * q + i;
-                    if (f < a.ldZF) a.ZF[(size_t)row * a.ldZF + f] = z8[4 * h + i];
+                    for (int i = 0; i < 4; ++i)
+                        if (f0 + i < a.ldZF) a.ZF[(size_t)row * a.ldZF + f0 + i] = z8[4 * h + i];
                 }
+            }
         }
     }
     lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);

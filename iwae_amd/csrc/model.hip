@@ -139,7 +139,8 @@ struct iwae_model {
     struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat; } f32;
     int eval_tag_kill = -1;
     int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
-    int eval_rows = 1 << 19;                  // data rows per evaluator launch (IWAE_EVAL_ROWS): images x samples, k chunked beyond it
+    DevBuf eval_x, eval_lme;                  // iwae_eval_llh: the images (uploaded once) and the per-image log-mean-exps of every launch
+    int eval_rows = 0;                        // data rows per evaluator launch (option eval_rows): images x samples, k chunked beyond it; 0 = eval_rows_auto()
     int eval_precision = IWAE_PREC_FP32;      // arithmetic of iwae_eval_llh (iwae_set_eval_precision)
     bool fwd_was_f32 = false;                 // the last forward ran in float32 mode (its backward must too)
     const float* f32_x = nullptr;             // device x [B][X] of the last float32 forward
@@ -239,6 +240,7 @@ struct iwae_model {
     bool dec_pending = false;
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
+    int fake_s = 0;             // DIAG builds: byte ablations of s (option fake_s)
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
     int dec_rows_max = 1024;    // dec_bwd_rows_kernel up to this many rows (IWAE_DEC_ROWS), dec_bwd_kernel beyond
@@ -607,6 +609,7 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
     int nsplit = 1, nw = 8;
     CHK(wgradp_plan(m, L, XP, GP, rows, a, nsplit, nw));
     a.rowscale = rowscale;
+    if (rowscale && (m->fake_s & 2)) a.dbg |= 32;
 #ifdef IWAE_DENSE_STAMPS
     if (m->dstamp_epi == 10 && rowscale && nw == 7) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 10): phase stamps of the output layer's weight gradient
         m->dstamp_waves = ((L.JT + 15) / 16) * nsplit * 12;
@@ -1022,6 +1025,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         if (m->s_mode) {
             CHK(ensure(m->wdec1.dlP, (size_t)Mp * Xp * 2, st));
             a.YP = ptr<uint16_t>(m->wdec1.dlP); a.ldYP = Xp;
+            if (m->fake_s & 4) a.dbg = 32;
         }
         a.logits_out = nullptr;
         a.pipe = m->allow_bern_pipe ? 1 : 0;
@@ -1200,6 +1204,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         a.M = M; a.KT = L.KT; a.NG = L.MG;
         a.DPP = ptr<uint16_t>(w.d2P);
         if (m->s_mode) a.SP = ptr<uint16_t>(w.dlP);     // dlP holds s: one product, no recompute
+        if (m->fake_s & 1) a.dbg = 32;
         const bool small_fused = m->small_dec_bwd && m->allow_dec_bwd && m->s_mode && M <= m->small_rows && out_bwd_has_s_mode(L.KT) && !m->want_stamps;      // dec_bwd_kernel at small row counts too
         if (m->s_mode && M < 8192 && L.MG > 1 && !small_fused) {         // small row counts: one pixel group per block, partial sums + finish kernel
             a.gpb = 1;
@@ -2127,7 +2132,7 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->logw2, &m->wn2, &m->gx2, &m->cf2, &m->per_b2,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1]};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1], &m->eval_x, &m->eval_lme};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2, &m->wprior};
     for (BlockWs* w : bw) {
@@ -2365,7 +2370,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "dec_rows") m->dec_rows_max = iv;                   // dec_bwd_rows_kernel up to this many rows
     else if (n == "no_wg7") m->allow_wg7 = !on;                       // the 16-wave weight-gradient shapes everywhere
     else if (n == "wg9") m->wg_shape9 = iv;                           // bit mask: layers that take the 8 + 8-wave / 128-feature wgradws shape
-    else if (n == "eval_rows") m->eval_rows = std::max(64, iv);       // data rows per evaluator launch
+    else if (n == "eval_rows") m->eval_rows = iv > 0 ? std::max(64, iv) : 0;       // data rows per evaluator launch
     else if (n == "no_bern_pipe") m->allow_bern_pipe = !on;           // the Bernoulli forward on dense_kernel<EPI_BERN>
     else if (n == "no_block_fused") m->allow_block_fused = !on;       // a BasicBlock on few rows as three dense_kernel launches
     else if (n == "no_out_in_block") m->allow_out_in_block = !on;     // the few-row decoder's output layer as its own launch
@@ -2388,6 +2393,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "dense_stamps_epi") m->dstamp_epi = iv;
     else if (n == "dense_stamps_kt") m->dstamp_kt = iv;
     else if (n == "wg_debug") m->wg_debug = iv;
+    else if (n == "fake_s") m->fake_s = iv;          // byte ablations (timing only): 1 dec_bwd_kernel reads s from 32 rows, 2 the output layer's gradient likewise, 4 the decoder kernel does not store s
 #endif
     else return fail(IWAE_ERR_ARG, "set_option: unknown option '" + n + "'");
     return IWAE_OK;
@@ -2533,45 +2539,59 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
     // Launches of at most eval_rows data rows: `chunk` images x kc samples.  k <= eval_rows: whole images (kc = k).  Larger k: the
     // samples of an image are walked in chunks of kc and the per-chunk log-mean-exps are merged with a running log-sum-exp
     // (src/utils.py:6-8 is associative in that form) -- the activations of ALL k samples never exist at once.
-    const int kc = std::min(k, m->eval_rows);
-    if (chunk <= 0) chunk = std::max(1, m->eval_rows / kc);
+    // (2^21 rows per launch at the reference's hidden width -- the single-launch decoder kernels keep nothing per pixel, ~0.4 KiB of HBM per row, and
+    // the per-launch costs (image encoder on ~100 images, log-mean-exp, launch boundaries) are a quarter of what they are at 2^19: bf16 186 -> 205 k
+    // images/s, float32 35.0 -> 36.7 k; other shapes, whose fallback paths may keep float32 logits, stay at 2^19)
+    const int eval_rows = m->eval_rows > 0 ? m->eval_rows : ((m->dec1[2].KT == 7 && m->C == 0 && !m->has_prior) ? 1 << 21 : 1 << 19);
+    const int kc = std::min(k, eval_rows);
+    if (chunk <= 0) chunk = std::max(1, eval_rows / kc);
     chunk = std::min(chunk, N);
-    std::vector<float> lme(chunk);
-    std::vector<double> run(chunk);
-    double total = 0.0;
+    // Round 4: no host round trip per launch.  The images go to the device once, every launch leaves its per-image log-mean-exps in one device
+    // array [k-chunks][N], and ONE copy + synchronisation at the end feeds the same host arithmetic in the same order (the results are bitwise
+    // what the per-launch copies gave); the k = 5000 evaluator's launches used to sit ~50 us apart (10 % of the bf16 evaluator's time).
+    const int ns = (k + kc - 1) / kc;
+    const float* xd = x;
+    const size_t xbytes = (size_t)N * m->X * 4;
+    if (!is_device_ptr(x, m->cfg.device) && xbytes <= ((size_t)1 << 31)) { CHK(copy_in(m, m->eval_x, x, xbytes)); xd = ptr<float>(m->eval_x); }
+    CHK(ensure(m->eval_lme, (size_t)ns * N * 4, m->stream));
     const uint32_t saved_off = m->batch_offset;
     int rc = IWAE_OK;
     for (int i0 = 0; i0 < N && rc == IWAE_OK; i0 += chunk) {
         const int nb = std::min(chunk, N - i0);
         m->batch_offset = saved_off + (uint32_t)i0;
         m->cond_row0 = i0;
-        for (int s0 = 0; s0 < k && rc == IWAE_OK; s0 += kc) {
-            const int kn = std::min(kc, k - s0);
+        for (int si = 0; si < ns && rc == IWAE_OK; ++si) {
+            const int s0 = si * kc, kn = std::min(kc, k - s0);
             m->eval_k_total = (kc < k) ? k : 0;
             m->eval_s_off = s0;
             const bool f32 = m->eval_precision == IWAE_PREC_FP32;
-            rc = f32 ? forward_f32(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
-                     : forward_impl(m, x + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
+            rc = f32 ? forward_f32(m, xd + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
+                     : forward_impl(m, xd + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
             m->eval_k_total = 0; m->eval_s_off = 0;
             if (rc != IWAE_OK) break;
-            if (hipMemcpyAsync(lme.data(), ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-                hipStreamSynchronize(m->stream) != hipSuccess) { rc = fail(IWAE_ERR_HIP, "eval_llh: copying the per-image estimates failed"); break; }
-            for (int i = 0; i < nb; ++i) {
-                const double part = (double)lme[i] + log((double)kn);       // log sum_s exp(log_w) over this chunk
-                if (s0 == 0) run[i] = part;
-                else { const double hi = std::max(run[i], part), lo = std::min(run[i], part); run[i] = hi + log1p(exp(lo - hi)); }
-            }
+            if (hipMemcpyAsync(ptr<float>(m->eval_lme) + (size_t)si * N + i0, ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToDevice,
+                               m->stream) != hipSuccess) { rc = fail(IWAE_ERR_HIP, "eval_llh: keeping the per-image estimates failed"); break; }
         }
         m->cond_row0 = 0;
-        if (rc != IWAE_OK) break;
-        for (int i = 0; i < nb; ++i) {
-            const double v = run[i] - log((double)k);
-            total += v;                    // MyMetric: sum / count (src/utils.py:39-41)
-            if (per_image) per_image[i0 + i] = (float)v;
-        }
     }
     m->batch_offset = saved_off;
-    if (rc != IWAE_OK) return rc;
+    if (rc != IWAE_OK) { (void)hipStreamSynchronize(m->stream); return rc; }
+    std::vector<float> lme((size_t)ns * N);
+    if (hipMemcpyAsync(lme.data(), m->eval_lme.p, lme.size() * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess)
+        return fail(IWAE_ERR_HIP, "eval_llh: copying the per-image estimates failed");
+    double total = 0.0;
+    for (int i = 0; i < N; ++i) {
+        double run = 0.0;
+        for (int si = 0; si < ns; ++si) {
+            const int kn = std::min(kc, k - si * kc);
+            const double part = (double)lme[(size_t)si * N + i] + log((double)kn);       // log sum_s exp(log_w) over this chunk of samples
+            if (si == 0) run = part;
+            else { const double hi = std::max(run, part), lo = std::min(run, part); run = hi + log1p(exp(lo - hi)); }
+        }
+        const double v = run - log((double)k);
+        total += v;                    // MyMetric: sum / count (src/utils.py:39-41)
+        if (per_image) per_image[i] = (float)v;
+    }
     m->noise_step += 1;
     *llh = total / (double)N;
     return IWAE_OK;

@@ -953,6 +953,36 @@ def test_eval_llh_k_chunking_is_invisible(gpu, layers):
         assert abs(a - b) < 1e-3
 
 
+def test_eval_llh_images_per_launch_are_invisible(gpu):
+    """The k = 5000 evaluator (main.py:170-184) packs as many images into a launch as the row cap allows -- 419 at the reference's dims since round 4
+    (2^21 rows), 104 before (2^19) -- and keeps every launch's per-image estimates on the device until ONE copy at the end.  The draws are keyed by the
+    global image index, so an image's estimate must not depend on which launch it rode in or on its neighbours: 450 images (two launches, the second
+    ragged) against launches of 104 and of 7 images, per image, both arithmetics.  Bitwise, except bf16 at 7 images per launch: 35 000 rows take the
+    kernel family that samples z inside the decoder kernel (another summation order of the 100 density terms per row): within 2 float32 ulps there."""
+    P = O.init_params(1, 200, 100, 78, x_mean=O.synthetic_pixel_means())
+    x = O.synthetic_binarized(450, 9)
+    outs = {}
+    for rows in (0, 1 << 19, 7 * 5000):
+        m = _model(1, 200, 100, options={"eval_rows": rows} if rows else None)
+        m.set_params(O.flatten_params(P))
+        for prec in ("fp32", "bf16"):
+            m.set_eval_precision(prec)
+            m.set_step(3, 0)
+            outs[(rows, prec)] = m.eval_llh(x, k=5000, per_image=True)
+        m.close()
+    for prec in ("fp32", "bf16"):
+        a, pa = outs[(0, prec)]
+        assert np.all(np.isfinite(pa)) and pa.shape == (450,)
+        for rows in (1 << 19, 7 * 5000):
+            b, pb = outs[(rows, prec)]
+            if prec == "bf16" and rows < 1 << 19:
+                np.testing.assert_allclose(pa, pb, rtol=0, atol=7e-5, err_msg="%s rows %d" % (prec, rows))
+                assert abs(a - b) < 1e-5
+            else:
+                np.testing.assert_array_equal(pa, pb, err_msg="%s rows %d" % (prec, rows))
+                assert a == b
+
+
 # ---------------------------------------------------------------- float32 mode (iwae_config.precision = IWAE_PREC_FP32)
 # SURVEY.md 8(c): "fp32 kernels rel 1e-5 on scalars / 1e-4 on grads vs fp64 oracle".  The reference computes in float32
 # (Keras Dense defaults, src/iwae1.py:31-34,72-75); every GEMM of this mode is an exact-f32 MFMA (v_mfma_f32_16x16x4_f32).
