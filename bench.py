@@ -308,7 +308,7 @@ def run():
     elbo = net.forward(x_np[lo:lo + B], K)["iwae_elbo"]
     llh_eval = None
     if world == 1 and not args.no_llh_eval and cfg["layers"] == 1:      # the other half of BASELINE's metric: the test-LLH protocol of main.py:170-184 (k = 5000 per image), untimed extra
-        n_eval = 1000
+        n_eval = 4190      # ten full launches of the evaluator (419 images x 5000 samples = 2^21 rows each at the reference's dims)
         xe = np.tile(x_np, (n_eval // x_np.shape[0] + 1, 1))[:n_eval]
         llh_eval = {"k": 5000, "images": n_eval}
         for prec in ("fp32", "bf16"):      # the evaluator's default arithmetic (float32, as the reference's) and the fast path
