@@ -10,7 +10,7 @@ x = O.synthetic_binarized(n, 1)
 opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in sys.argv[3:])
 m = NativeModel(1, 200, 100, seed=5, options=opts)
 m.set_eval_precision(prec)
-m.eval_llh(x[:32], 5000)
+m.eval_llh(x[:min(n, 500)], 5000)      # (warm-up on full-size launches: the buffers grow here, not in the timed call)
 m.sync()
 t = time.perf_counter()
 llh = m.eval_llh(x, 5000)
