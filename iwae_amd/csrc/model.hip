@@ -1046,10 +1046,10 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.pre_img1 = m->dec1[0].imgF; a.pre_KT1 = m->dec1[0].KT; a.pre_img2 = m->dec1[1].imgF;
             a.pre_Z = ptr<uint16_t>(m->zP[0]);
             // g1, g2 are kept for the backward pass only: a forward-only call (val_step, the k = 5000 evaluator) never reads them back
-            a.pre_G1 = bwd ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = bwd ? ptr<uint16_t>(w.g2P) : nullptr;
+            a.pre_G1 = (bwd && !(m->fake_s & 8)) ? ptr<uint16_t>(w.g1P) : nullptr; a.pre_G2 = (bwd && !(m->fake_s & 8)) ? ptr<uint16_t>(w.g2P) : nullptr;      // (fake_s & 8, DIAG builds: timing without the activation stores)
             if (fuse_z) {
                 a.zhead = zin.head; a.ldZH = zin.ldH; a.zeps = zin.eps.cache; a.zldE = zin.eps.ldC; a.zD = zin.D; a.zDp = zin.Dp;
-                a.ZPout = bwd ? zin.ZP : nullptr; a.zlp = zin.lp_prior; a.zlq = zin.lq; a.zlq_dreg = zin.lq_dreg;      // (a forward-only call never reads z back)
+                a.ZPout = (bwd && !(m->fake_s & 8)) ? zin.ZP : nullptr; a.zlp = zin.lp_prior; a.zlq = zin.lq; a.zlq_dreg = zin.lq_dreg;      // (a forward-only call never reads z back)
             }
             fuse_dec = bern_pipe_ok(a);
             if (!fuse_dec) {
@@ -2393,7 +2393,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "dense_stamps_epi") m->dstamp_epi = iv;
     else if (n == "dense_stamps_kt") m->dstamp_kt = iv;
     else if (n == "wg_debug") m->wg_debug = iv;
-    else if (n == "fake_s") m->fake_s = iv;          // byte ablations (timing only): 1 dec_bwd_kernel reads s from 32 rows, 2 the output layer's gradient likewise, 4 the decoder kernel does not store s
+    else if (n == "fake_s") m->fake_s = iv;          // byte ablations (timing only): 1 dec_bwd_kernel reads s from 32 rows, 2 the output layer's gradient likewise, 4 the decoder kernel does not store s, 8 ... nor z / g1 / g2
 #endif
     else return fail(IWAE_ERR_ARG, "set_option: unknown option '" + n + "'");
     return IWAE_OK;
