@@ -183,6 +183,7 @@ struct DecBwdArgs {                  // dec_bwd_kernel: out_bwd_s + dX of the tw
     const char* imgB1; int MG1;       // backward image of the first decoder layer (out = latent groups, k = hidden)
     float* DZ; int ldDZ;              // dz fp32 [M][ldDZ] (or null)
     uint16_t* DZH;                    // dz as bf16 [M][ldDZ], natural feature order (1-layer model: latent_bwd_kernel is its only reader), or null
+    int nw;                           // 8: the 8-wave x 16-row shape (KT = 7 only), else 4 waves x 32 rows
 };
 
 struct WgradPArgs {

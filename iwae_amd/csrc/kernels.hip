@@ -2796,8 +2796,11 @@ __global__ __launch_bounds__(256, 2) void out_bwd_s_kernel(OutBwdArgs a) {
 // through the transposing ds_read_b64_tr_b16, then the 4 + 2 out-feature groups of the backward images of V2 and V1).
 // 4 waves x 32 rows, two workgroups per CU (<= 256 registers): dg2 accumulators 112, then dpre2 / dpre1 fragments 56 each.
 // ---------------------------------------------------------------------------------
-template <int KTC>
-__global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
+// <KTC, NW, G>: NW waves per workgroup, G row groups of 16 rows per wave.  <.., 4, 2> (round 2): 4 waves x 32 rows, two workgroups per CU = 2 waves per SIMD at <= 256
+// registers.  <.., 8, 1> (round 4, DESIGN item 69): 8 waves x 16 rows, two workgroups per CU = 4 waves per SIMD at <= 128 registers -- the same 128 rows per weight unit,
+// half the accumulators per wave, twice the waves to hide each other's latencies (the kernel's units take 3.8 k cycles for 0.9 k cycles of MFMAs per wave).
+template <int KTC, int NW = 4, int G = 2>
+__global__ __launch_bounds__(64 * NW, 2) void dec_bwd_kernel(DecBwdArgs d) {
 #ifdef IWAE_DENSE_STAMPS       // diagnostic build: cycles per phase and wave -> d.o.stamps[wave][8] (p1 wait | p1 multiply | dpre2 | p2/p3 wait | p2/p3 multiply + epilogue | - | end)
     unsigned long long ds_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ds_prev = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ds_prev)::"memory");
@@ -2808,18 +2811,18 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     constexpr int unit = KT * 4096 + 1024;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int r0 = (blockIdx.x * 4 + wave) * 32;
-    int row[2], rowc[2];
-    bool valid[2];
+    const int r0 = (blockIdx.x * NW + wave) * (16 * G);
+    int row[G], rowc[G];
+    bool valid[G];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) { row[g] = r0 + 2 * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
+    for (int g = 0; g < G; ++g) { row[g] = r0 + G * rho + g; valid[g] = row[g] < a.M; rowc[g] = min(row[g], a.M - 1); }
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     constexpr int MG2 = (KTC + 1) / 2;                             // 64-feature groups of the hidden width (32*KTC features)
     const int U1 = a.NG, U2 = U1 + MG2, U3 = U2 + d.MG1;          // unit ranges of the three products
 
-    constexpr int NP = unit / 1024, NIDX = (NP + 3) / 4;
+    constexpr int NP = unit / 1024, NIDX = (NP + NW - 1) / NW;
     auto dma_piece = [&](int u, int idx) {
-        const int p = wave + 4 * idx;                 // wave-uniform
+        const int p = wave + NW * idx;                // wave-uniform
         if (p >= NP) return;
         // product 1 reads W3 from its K-MAJOR image (blocks [pixel k-step][hidden tile]: a pixel group is 2 * MT contiguous 1 KiB blocks, each
         // ALREADY the A fragment of dg2 = s W3^T): plain conflict-free ds_read_b128, where the MG-major image of W3^T needed two transposing
@@ -2829,11 +2832,11 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
         glds16(src + (size_t)p * 1024 + lane * 16,
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_addr_of(smem + (u & 1) * unit) + (uint32_t)p * 1024u)));
     };
-    auto load_s = [&](int ng, uint4 (&sf)[2][2]) {   // clamped rows, zeroed by a select: no branch per load
+    auto load_s = [&](int ng, uint4 (&sf)[2][G]) {   // clamped rows, zeroed by a select: no branch per load
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 sf[kk][g] = make_uint4(0, 0, 0, 0);
                 const int fbase = 64 * ng + 32 * kk;      // wave-uniform guard
                 if (fbase < a.Xp32) {
@@ -2844,16 +2847,16 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     };
 #pragma unroll
     for (int idx = 0; idx < NIDX; ++idx) dma_piece(0, idx);
-    uint4 d2f[KT][2], d1f[KT][2];
+    uint4 d2f[KT][G], d1f[KT][G];
     {
         // ---------------- product 1: dg2 = s W3^T over the pixel groups
-        uint4 sf[2][2], sf_n[2][2];
+        uint4 sf[2][G], sf_n[2][G];
         load_s(0, sf);
-        f32x4 acc2[MT][2];
+        f32x4 acc2[MT][G];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int g = 0; g < G; ++g) acc2[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         for (int ng = 0; ng < U1; ++ng) {
             const int buf = ng & 1;
             DS_STAMP(1);
@@ -2866,7 +2869,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
                 [&](int i) { return *(const uint4*)(l2 + i * 1024); },      // A fragment (pixel k-step kk = i / MT, hidden tile mt = i % MT): block kk * MT + mt of the unit
                 [&](int i, const uint4& av) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc2[i % MT][g] = mfma16(av, (i / MT) ? sf[1][g] : sf[0][g], acc2[i % MT][g]);
+                    for (int g = 0; g < G; ++g) acc2[i % MT][g] = mfma16(av, (i / MT) ? sf[1][g] : sf[0][g], acc2[i % MT][g]);
                 },
                 [&](int i) { if ((i & 1) == 0 && (i >> 1) < NIDX) dma_piece(ng + 1, i >> 1); });      // unit U1 (first group of V2's image) follows the last pixel group
 #pragma unroll
@@ -2874,28 +2877,28 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) sf[kk][g] = sf_n[kk][g];
+                for (int g = 0; g < G; ++g) sf[kk][g] = sf_n[kk][g];
         }
         // dpre2 = gx * dg2 * (1 - g2^2); the lane's 8 features of hidden k-step ks are tiles 2ks (j < 4) and 2ks+1 (j >= 4)
         DS_STAMP(1);
-        float gxv[2];
+        float gxv[G];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) gxv[g] = valid[g] ? a.gx[row[g]] : 0.0f;
+        for (int g = 0; g < G; ++g) gxv[g] = valid[g] ? a.gx[row[g]] : 0.0f;
         // the stored g2 of the wave's rows: ALL fragments requested before the first is used (one round trip; as a load per use the
         // 14 of them came back one after the other: 18.6k of the kernel's 107k cycles per wave)
-        uint4 y8a[KT][2];
+        uint4 y8a[KT][G];
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) y8a[ks][g] = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
+            for (int g = 0; g < G; ++g) y8a[ks][g] = *(const uint4*)(a.G2 + (size_t)rowc[g] * a.ldG + ks * 32 + q * 8);
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) asm volatile("" : "+v"(y8a[ks][g].x), "+v"(y8a[ks][g].y), "+v"(y8a[ks][g].z), "+v"(y8a[ks][g].w));
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(y8a[ks][g].x), "+v"(y8a[ks][g].y), "+v"(y8a[ks][g].z), "+v"(y8a[ks][g].w));
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 const uint4 y8 = y8a[ks][g];
                 float v[8];
 #pragma unroll
@@ -2912,7 +2915,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     DS_STAMP(2);
     // ---------------- products 2 and 3: Y^T = backward image x X^T with X in registers, one 64-out-feature group per unit
     constexpr int NF = KT * 4, STEP = (NF / NIDX > 0) ? NF / NIDX : 1;
-    auto group_mfma = [&](int u, const uint4 (&xin)[KT][2], f32x4 (&acc)[4][2]) {
+    auto group_mfma = [&](int u, const uint4 (&xin)[KT][G], f32x4 (&acc)[4][G]) {
         const int buf = u & 1;
         DS_STAMP(4);
         wait_all_vmem();
@@ -2922,13 +2925,13 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            for (int g = 0; g < G; ++g) acc[t][g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         const char* lb = smem + buf * unit + a_off;
         lds_pipeline<NF, 8>(
             [&](int i) { return *(const uint4*)(lb + i * 1024); },
             [&](int i, const uint4& av) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) acc[i & 3][g] = mfma16(av, xin[i >> 2][g], acc[i & 3][g]);
+                for (int g = 0; g < G; ++g) acc[i & 3][g] = mfma16(av, xin[i >> 2][g], acc[i & 3][g]);
             },
             [&](int i) { if (more && i % STEP == 0 && i / STEP < NIDX) dma_piece(u + 1, i / STEP); });
         if (more) {
@@ -2939,26 +2942,26 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
 #pragma unroll
     for (int ks = 0; ks < KT; ++ks)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) d1f[ks][g] = make_uint4(0, 0, 0, 0);
+        for (int g = 0; g < G; ++g) d1f[ks][g] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int mg = 0; mg < MG2; ++mg) {
         // stored g1 of this group's 64 features: requested before the MFMAs, used after them
-        uint4 y8[2][2];
+        uint4 y8[2][G];
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < G; ++g) {
                 y8[p][g] = make_uint4(0, 0, 0, 0);
                 if (2 * mg + p < KT) y8[p][g] = *(const uint4*)(d.G1 + (size_t)rowc[g] * a.ldG + (2 * mg + p) * 32 + q * 8);
             }
-        f32x4 acc[4][2];
+        f32x4 acc[4][G];
         group_mfma(U1 + mg, d2f, acc);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int kso = 2 * mg + p;
             if (kso < KT) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < G; ++g) {
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -2973,14 +2976,14 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
         }
     }
     for (int mg = 0; mg < d.MG1; ++mg) {
-        f32x4 acc[4][2];
+        f32x4 acc[4][G];
         group_mfma(U2 + mg, d1f, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int f0 = 64 * mg + 16 * t + 4 * q;
             if (64 * mg + 16 * t < d.ldDZ) {       // wave-uniform
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
+                for (int g = 0; g < G; ++g) {
                     if (valid[g] && d.DZH) *(uint2*)(d.DZH + (size_t)row[g] * d.ldDZ + f0) = make_uint2(pack2(acc[t][g][0], acc[t][g][1]), pack2(acc[t][g][2], acc[t][g][3]));
                     else if (valid[g]) *(float4*)(d.DZ + (size_t)row[g] * d.ldDZ + f0) = make_float4(acc[t][g][0], acc[t][g][1], acc[t][g][2], acc[t][g][3]);
                 }
@@ -2992,7 +2995,7 @@ __global__ __launch_bounds__(256, 2) void dec_bwd_kernel(DecBwdArgs d) {
     wait_all_vmem();
     DS_STAMP(6);
     if (a.stamps && lane == 0)
-        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ds_sum[i];
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + i] = ds_sum[i];
 #endif
 }
 
@@ -4609,6 +4612,7 @@ bool out_bwd_has_s_mode(int KT) { return KT == 7 || KT == 4 || KT == 2; }
 void launch_dec_bwd(const DecBwdArgs& d, hipStream_t st) {
     const size_t lds = 2 * ((size_t)d.o.KT * 4096 + 1024);
     dim3 grid((d.o.M + 127) / 128);
+    if (d.nw == 8 && d.o.KT == 7) { LAUNCH_EV((dec_bwd_kernel<7, 8, 1>), grid, dim3(512), lds, st, d); return; }
     switch (d.o.KT) {
         case 7: LAUNCH_EV(dec_bwd_kernel<7>, grid, dim3(256), lds, st, d); break;
         case 4: LAUNCH_EV(dec_bwd_kernel<4>, grid, dim3(256), lds, st, d); break;

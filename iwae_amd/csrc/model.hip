@@ -230,6 +230,7 @@ struct iwae_model {
     hipEvent_t ev_ar = nullptr;        // data-parallel step: recorded behind the encoder segment's all-reduce (dp_finish)
     bool dp_concurrent = false;        // option dp_concurrent: the two all-reduces of a step may run at the same time (see dp_finish)
     bool use_side2 = true;
+    int dec_bwd_nw = 8;         // option dec_bwd_nw: dec_bwd_kernel's shape (8 waves x 16 rows, round 4 | 4 waves x 32 rows)
     hipEvent_t ev_lse = nullptr;
     bool early_wout = false, allow_early_wout = true;    // IWAE_NO_EARLY_WOUT=1: the output layer's weight gradient forks behind out_bwd with the others (A/B measurements)
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_blk = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_dec = nullptr;
@@ -1250,6 +1251,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 // float32 terms to it there and keeps float32)
                 dz_half = !two && m->allow_dz_half;
                 if (dz_half) d.DZH = (uint16_t*)w.dz.p;
+                d.nw = m->dec_bwd_nw;
                 if (m->dstamp_epi == 9) {      // diagnostic (STAMPS=1 build, IWAE_DENSE_STAMPS=9:0): phase stamps of dec_bwd_kernel
                     m->dstamp_waves = ((M + 127) / 128) * 4;
                     CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st));
@@ -2383,6 +2385,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "wg16") m->wg_target16 = std::max(1, iv);
     else if (n == "wg16_1") m->wg_target16_1 = std::max(1, iv);
     else if (n == "eps_blocks") m->eps_blocks = std::max(0, iv);      // blocks of the ahead-of-time noise draw
+    else if (n == "dec_bwd_nw") m->dec_bwd_nw = iv == 8 ? 8 : 4;
     else if (n == "no_side2") m->use_side2 = !on;                     // the hidden layers' weight gradients behind the output layer's
     else if (n == "wg_group") m->allow_wg_group = on;                 // ... as one grouped launch
     else if (n == "no_early_wout") m->allow_early_wout = !on;         // the output layer's weight gradient forks behind out_bwd
