@@ -1322,6 +1322,7 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         int npc = NPC;
         if (u < MGH) { src = a.pre_img1 + (size_t)u * img_mg_group_bytes(a.pre_KT1); npc = 4 * a.pre_KT1 + 1; }
         else if (u < 2 * MGH) src = a.pre_img2 + (size_t)(u - MGH) * gbytes;
+        if (WG_DBG(a, 64) && u < 2 * MGH) return;      // (DIAG ablation, timing only: the tanh layers without their weight stream)
 #pragma unroll
         for (int idx = 0; idx < NIDX; ++idx) {
             const int p = wave + NWV * idx;

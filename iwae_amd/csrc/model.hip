@@ -1027,6 +1027,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             CHK(ensure(m->wdec1.dlP, (size_t)Mp * Xp * 2, st));
             a.YP = ptr<uint16_t>(m->wdec1.dlP); a.ldYP = Xp;
             if (m->fake_s & 4) a.dbg = 32;
+            if (m->fake_s & 16) a.dbg |= 64;      // (the decoder kernel's tanh layers without their weight DMA)
         }
         a.logits_out = nullptr;
         a.pipe = m->allow_bern_pipe ? 1 : 0;
