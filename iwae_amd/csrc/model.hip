@@ -824,7 +824,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             if (m->eval_k_total > 0) m->eval_tag_kill = np;      // (a k-chunk's draws: the tag does not describe them)
         }
         if (m->eval_tag_kill >= 0) { m->eps_tag[m->eval_tag_kill].valid = false; m->eval_tag_kill = -1; }
-        m->epsc_par = np;
+        if (bwd) m->epsc_par = np;      // (forward-only calls -- the evaluator's launches -- reuse ONE slot: stream order protects it, and three slots of 2^21 rows are 2.5 GB grown inside the first calls)
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     }
     if (eps) CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
@@ -1724,7 +1724,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));      // (a bf16 step's speculative draw may sit on either side stream)
         CHK(draw_eps(m, np, m->noise_step, M, st));
         if (m->eval_k_total > 0) m->eps_tag[np].valid = false;      // a k-chunk's draws: the tag (step, offset, rows) does not describe them
-        m->epsc_par = np;
+        if (bwd) m->epsc_par = np;      // (forward-only calls reuse one slot, as in forward_impl)
         for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsc[np][l]);
     } else {
         CHK(copy_in(m, m->epsbuf, eps, (size_t)M * (m->D[0] + (two ? m->D[1] : 0)) * 4));
