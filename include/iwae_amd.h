@@ -187,7 +187,11 @@ int iwae_comm_destroy(iwae_handle h);
 int iwae_comm_info(iwae_handle h, int32_t* world_size, int32_t* rank);
 
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
- * batched `chunk` at a time on the device.  llh_per_image may be NULL. */
+ * batched `chunk` at a time on the device (chunk <= 0: as many as the row cap per launch allows -- option eval_rows, 2^21 rows at the
+ * reference's dims, 2^19 otherwise; beyond it an image's k samples are walked in chunks and merged with a running log-sum-exp).
+ * x: host or device pointer, [N, x_dim]; a host batch is uploaded once.  The launches' per-image estimates stay on the device until one
+ * copy at the end: the call returns after one synchronisation.  An image's estimate does not depend on the launch it rode in (the draws are
+ * keyed by the global image index: iwae_set_step).  llh_per_image may be NULL. */
 int iwae_eval_llh(iwae_handle h, const float* x, int32_t N, int32_t k, int32_t chunk, double* llh, float* llh_per_image);
 /* arithmetic of iwae_eval_llh, independent of iwae_config.precision: IWAE_PREC_FP32 by default (the reference evaluates in
  * float32, main.py:176; 10 000 images x k = 5000 take well under a second either way), IWAE_PREC_BF16 for the fast path. */
