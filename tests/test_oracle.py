@@ -246,3 +246,61 @@ def test_forward_dict_matches_a_torch_distributions_restatement(beta):
     }
     for key, v in want.items():
         np.testing.assert_allclose(res[key], v.numpy(), rtol=1e-10, atol=1e-10, err_msg=key)
+
+
+def test_log_densities_and_logmeanexp_match_scipy():
+    """A second independent implementation of the same semantics (after torch.distributions above): scipy.stats / scipy.special.  tfd.Normal.log_prob =
+    norm.logpdf, tfd.Bernoulli(logits).log_prob = bernoulli.logpmf at p = expit(logits) (in the range where p is representable), utils.logmeanexp =
+    logsumexp - log k (/root/reference/src/utils.py:6-8, src/iwae1.py:105-125)."""
+    import scipy.special as sp
+    import scipy.stats as st
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((4, 7, 11)) * 2.5
+    loc = rng.standard_normal((7, 11))
+    scale = np.exp(rng.standard_normal((7, 11)) * 0.7) + 1e-6
+    np.testing.assert_allclose(O.normal_log_prob(x, loc[None], scale[None]), st.norm.logpdf(x, loc[None], scale[None]), rtol=1e-12, atol=1e-12)
+    logits = rng.standard_normal(300) * 6.0
+    xb = (rng.random(300) < 0.5).astype(np.float64)
+    np.testing.assert_allclose(O.bernoulli_log_prob(xb, logits), st.bernoulli.logpmf(xb, sp.expit(logits)), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(O.softplus(logits), np.logaddexp(0.0, logits), rtol=1e-13, atol=1e-15)
+    lw = rng.standard_normal((37, 5)) * 40.0 - 250.0
+    np.testing.assert_allclose(O.logmeanexp(lw, 0), sp.logsumexp(lw, axis=0) - np.log(37.0), rtol=1e-13)
+    # KL(N(mu, sigma) || N(0, 1)) as the expectation it is: Gauss-Hermite quadrature of q (log q - log p), no closed form involved (iwae1.py:116)
+    xs, ws = np.polynomial.hermite_e.hermegauss(80)
+    mu, sg = loc[:3, :4], scale[:3, :4]
+    zq = mu[..., None] + sg[..., None] * xs
+    kl_quad = ((st.norm.logpdf(zq, mu[..., None], sg[..., None]) - st.norm.logpdf(zq)) * ws).sum(-1) / np.sqrt(2.0 * np.pi)
+    np.testing.assert_allclose(O.kl_normal_std(mu, sg), kl_quad, rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("objective", ["iwae_elbo", "vae_elbo", "iwae_eq14", "vae_elbo_kl"])
+def test_closed_form_gradients_match_autograd_through_torch_distributions(objective):
+    """The oracle's closed-form backward (oracle/iwae_np.py: loss_grads_1layer, the derivation SURVEY 3.3 writes out) against autograd through the
+    torch.distributions restatement of the forward above -- tfd objects' semantics from an independent library AND the gradient from an independent
+    differentiator (the reference: tape.gradient of -res[objective], src/iwae1.py:153-162).  iwae_eq14's normalised weights are constants of the differentiation
+    (tf.stop_gradient, iwae1.py:132) -- .detach() here."""
+    import torch.distributions as D
+    beta = 0.7 if objective == "vae_elbo_kl" else 1.0
+    x, P, eps = MG.inputs(1, 16, 4, 48, 6, 9, 23)
+    res, g = O.loss_grads_1layer(P, x, eps, beta, objective)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).requires_grad_(True)
+    Pt = [(t(W), t(b)) for W, b in P]
+    (W1, b1), (W2, b2), (Wm, bm), (Ws, bs), (V1, c1), (V2, c2), (V3, c3) = Pt
+    xt, et = torch.from_numpy(x.astype(np.float64)), torch.from_numpy(eps.astype(np.float64))
+    h = torch.tanh(torch.tanh(xt @ W1 + b1) @ W2 + b2)
+    qzx = D.Normal(h @ Wm + bm, torch.exp(h @ Ws + bs) + 1e-6)
+    z = qzx.loc + qzx.scale * et
+    pxz = D.Bernoulli(logits=torch.tanh(torch.tanh(z @ V1 + c1) @ V2 + c2) @ V3 + c3)
+    pz = D.Normal(torch.zeros_like(qzx.loc), torch.ones_like(qzx.loc))
+    lpxz = pxz.log_prob(xt.expand(eps.shape[0], *xt.shape)).sum(-1)
+    log_w = lpxz + beta * (pz.log_prob(z).sum(-1) - qzx.log_prob(z).sum(-1))
+    k = eps.shape[0]
+    val = {"vae_elbo": log_w.mean(0).mean(),
+           "vae_elbo_kl": (lpxz.mean(0) - beta * D.kl_divergence(qzx, pz).sum(-1)).mean(),
+           "iwae_elbo": (torch.logsumexp(log_w, 0) - np.log(k)).mean(),
+           "iwae_eq14": (torch.softmax(log_w, 0).detach() * log_w).sum(0).mean()}[objective]      # iwae1.py:128-134: the weights are stop_gradient'ed (:132)
+    (-val).backward()
+    np.testing.assert_allclose(res[objective], val.item(), rtol=1e-10)
+    for (dW, db), (Wt, bt) in zip(g, Pt):
+        np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
