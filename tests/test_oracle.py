@@ -304,3 +304,82 @@ def test_closed_form_gradients_match_autograd_through_torch_distributions(object
     for (dW, db), (Wt, bt) in zip(g, Pt):
         np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("beta", [1.0, 0.5])
+def test_dreg_gradients_match_autograd_through_torch_distributions(beta):
+    """The DReG estimator (/root/reference/tasks/task02.py:34-101): encoder gradients from inference_loss = -mean_b sum_s stop(w~)^2 (lpz + lpxz - lqzx_stopped), where lqzx_stopped
+    evaluates z under Normal(stop(mu), stop(sigma) + 1e-6) -- z itself keeps its dependence on the encoder through the reparameterisation -- and decoder gradients from
+    -iwae_elbo.  The oracle differentiates this in closed form (its own derivation of dz); here the same construction is written with torch.distributions objects and .detach()
+    and differentiated by autograd, the two parameter groups by the two losses as the reference's train_step does (:86-93)."""
+    import torch.distributions as D
+    x, P, eps = MG.inputs(1, 16, 4, 48, 6, 9, 29)
+    res, g = O.loss_grads_1layer(P, x, eps, beta, "dreg")
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).requires_grad_(True)
+    Pt = [(t(W), t(b)) for W, b in P]
+    (W1, b1), (W2, b2), (Wm, bm), (Ws, bs), (V1, c1), (V2, c2), (V3, c3) = Pt
+    xt, et = torch.from_numpy(x.astype(np.float64)), torch.from_numpy(eps.astype(np.float64))
+    h = torch.tanh(torch.tanh(xt @ W1 + b1) @ W2 + b2)
+    qzx = D.Normal(h @ Wm + bm, torch.exp(h @ Ws + bs) + 1e-6)
+    z = qzx.loc + qzx.scale * et
+    pxz = D.Bernoulli(logits=torch.tanh(torch.tanh(z @ V1 + c1) @ V2 + c2) @ V3 + c3)
+    lpz = D.Normal(torch.zeros_like(qzx.loc), torch.ones_like(qzx.loc)).log_prob(z).sum(-1)
+    lqzx = qzx.log_prob(z).sum(-1)
+    lpxz = pxz.log_prob(xt.expand(eps.shape[0], *xt.shape)).sum(-1)
+    log_w = lpxz + beta * (lpz - lqzx)
+    iwae_elbo = (torch.logsumexp(log_w, 0) - np.log(eps.shape[0])).mean()
+    al = torch.softmax(log_w, 0)
+    lqzx_stopped = D.Normal(qzx.loc.detach(), qzx.scale.detach() + 1e-6).log_prob(z).sum(-1)
+    inference_loss = -((al.detach() ** 2) * (lpz + lpxz - lqzx_stopped)).sum(0).mean()
+    enc = [p for pair in Pt[:4] for p in pair]
+    dec = [p for pair in Pt[4:] for p in pair]
+    g_enc = torch.autograd.grad(inference_loss, enc, retain_graph=True)
+    g_dec = torch.autograd.grad(-iwae_elbo, dec)
+    np.testing.assert_allclose(res["iwae_elbo"], iwae_elbo.item(), rtol=1e-10)
+    np.testing.assert_allclose(res["inference_loss"], inference_loss.item(), rtol=1e-10)
+    flat_oracle = [a for pair in g for a in pair]
+    for got, ref in zip(flat_oracle, list(g_enc) + list(g_dec)):
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("objective", ["iwae_elbo", "vae_elbo", "iwae_eq14"])
+def test_two_layer_gradients_match_autograd_through_torch_distributions(objective):
+    """The hierarchical model (/root/reference/src/iwae2.py:58-167): q(z1|x) q(z2|z1), p(z2) p(z1|z2) p(x|z1), log_w = lpxz1 + lpz1z2 + lpz2 - lqz1x - lqz2z1 (:128, no beta
+    inside), written with torch.distributions objects and differentiated by autograd, against the oracle's closed-form backward of the same step."""
+    import torch.distributions as D
+    nh, nl = [16, 8], [6, 3]
+    x, P, eps = MG.inputs(2, nh, nl, 48, 5, 7, 31)
+    res, g = O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, objective)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).requires_grad_(True)
+    Pt = [(t(W), t(b)) for W, b in P]
+    xt = torch.from_numpy(x.astype(np.float64))
+    e1, e2 = torch.from_numpy(eps[0].astype(np.float64)), torch.from_numpy(eps[1].astype(np.float64))
+
+    def block(inp, p4):      # BasicBlock: two tanh layers, mu head, sigma = exp(.) + 1e-6 head (iwae2.py:24-44)
+        (A1, a1), (A2, a2), (Am, am), (As, a_s) = p4
+        hh = torch.tanh(torch.tanh(inp @ A1 + a1) @ A2 + a2)
+        return D.Normal(hh @ Am + am, torch.exp(hh @ As + a_s) + 1e-6)
+
+    # parameter order of the oracle / the flat vector: enc1 (4 layers), enc2 (4), dec2 (4), dec1 (3)
+    qz1x = block(xt, Pt[0:4])
+    z1 = qz1x.loc + qz1x.scale * e1                                   # [k, B, D1]
+    qz2z1 = block(z1, Pt[4:8])
+    z2 = qz2z1.loc + qz2z1.scale * e2
+    pz1z2 = block(z2, Pt[8:12])
+    (V1, c1), (V2, c2), (V3, c3) = Pt[12:15]
+    pxz1 = D.Bernoulli(logits=torch.tanh(torch.tanh(z1 @ V1 + c1) @ V2 + c2) @ V3 + c3)
+    lpz2 = D.Normal(torch.zeros_like(z2), torch.ones_like(z2)).log_prob(z2).sum(-1)
+    lpz1z2 = pz1z2.log_prob(z1).sum(-1)
+    lqz1x = qz1x.log_prob(z1).sum(-1)
+    lqz2z1 = qz2z1.log_prob(z2).sum(-1)
+    lpxz1 = pxz1.log_prob(xt.expand(e1.shape[0], *xt.shape)).sum(-1)
+    log_w = lpxz1 + lpz1z2 + lpz2 - lqz1x - lqz2z1
+    k = e1.shape[0]
+    val = {"vae_elbo": log_w.mean(0).mean(),
+           "iwae_elbo": (torch.logsumexp(log_w, 0) - np.log(k)).mean(),
+           "iwae_eq14": (torch.softmax(log_w, 0).detach() * log_w).sum(0).mean()}[objective]
+    (-val).backward()
+    np.testing.assert_allclose(res[objective], val.item(), rtol=1e-10)
+    for (dW, db), (Wt, bt) in zip(g, Pt):
+        np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
