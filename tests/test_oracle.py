@@ -383,3 +383,37 @@ def test_two_layer_gradients_match_autograd_through_torch_distributions(objectiv
     for (dW, db), (Wt, bt) in zip(g, Pt):
         np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("cond_prior", [False, True])
+def test_conditional_model_gradients_match_autograd_through_torch_distributions(cond_prior):
+    """The conditional models: tasks/task05.py:108-135 (encoder on concat(x, y), decoder on concat(z, y), N(0, 1) prior) and tasks/task04.py:100-135 (the same plus the learned
+    prior p(z|y) = BasicBlock(y), whose four layers sit AFTER the decoder's in the weight order), beta = 0.5 -- torch.distributions objects + autograd against the oracle's
+    closed-form backward (the prior block's gradient included)."""
+    import torch.distributions as D
+    beta = 0.5
+    x, P, eps, y = MG.inputs(1, 16, 4, 48, 6, 9, 37, cond=5, cond_prior=cond_prior)
+    res, g = O.loss_grads_1layer(P, x, eps, beta, "iwae_elbo", y=y)
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64)).requires_grad_(True)
+    Pt = [(t(W), t(b)) for W, b in P]
+    xt, et, yt = (torch.from_numpy(a.astype(np.float64)) for a in (x, eps, y))
+
+    def block(inp, p4):
+        (A1, a1), (A2, a2), (Am, am), (As, a_s) = p4
+        hh = torch.tanh(torch.tanh(inp @ A1 + a1) @ A2 + a2)
+        return D.Normal(hh @ Am + am, torch.exp(hh @ As + a_s) + 1e-6)
+
+    qzxy = block(torch.cat([xt, yt], -1), Pt[0:4])
+    z = qzxy.loc + qzxy.scale * et
+    zy = torch.cat([z, yt.expand(eps.shape[0], *yt.shape)], -1)
+    (V1, c1), (V2, c2), (V3, c3) = Pt[4:7]
+    pxzy = D.Bernoulli(logits=torch.tanh(torch.tanh(zy @ V1 + c1) @ V2 + c2) @ V3 + c3)
+    pz = block(yt, Pt[7:11]) if cond_prior else D.Normal(torch.zeros_like(qzxy.loc), torch.ones_like(qzxy.loc))
+    log_w = pxzy.log_prob(xt.expand(eps.shape[0], *xt.shape)).sum(-1) + beta * (pz.log_prob(z).sum(-1) - qzxy.log_prob(z).sum(-1))
+    val = (torch.logsumexp(log_w, 0) - np.log(eps.shape[0])).mean()
+    (-val).backward()
+    np.testing.assert_allclose(res["iwae_elbo"], val.item(), rtol=1e-10)
+    assert len(g) == len(Pt) == (11 if cond_prior else 7)
+    for (dW, db), (Wt, bt) in zip(g, Pt):
+        np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
