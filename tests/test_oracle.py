@@ -417,3 +417,22 @@ def test_conditional_model_gradients_match_autograd_through_torch_distributions(
     for (dW, db), (Wt, bt) in zip(g, Pt):
         np.testing.assert_allclose(dW, Wt.grad.numpy(), rtol=1e-8, atol=1e-11)
         np.testing.assert_allclose(db, bt.grad.numpy(), rtol=1e-8, atol=1e-11)
+
+
+def test_keras_adam_matches_torch_adam_with_the_epsilon_moved():
+    """Keras Adam (main.py:56, epsilon = 1e-4): theta -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps) -- epsilon OUTSIDE the bias correction of v.  torch.optim.Adam
+    divides by sqrt(v / (1 - b2^t)) + eps', i.e. the same update with eps' = eps / sqrt(1 - b2^t): an independent implementation of the moment recurrences and both bias
+    corrections, driven for 25 steps with that epsilon set per step."""
+    rng = np.random.default_rng(3)
+    n, lr = 257, 1e-3
+    th = rng.standard_normal(n)
+    p = torch.nn.Parameter(torch.from_numpy(th.copy()))
+    opt = torch.optim.Adam([p], lr=lr, betas=(0.9, 0.999), eps=1e-4)
+    m = v = 0.0
+    for t in range(1, 26):
+        gr = rng.standard_normal(n) * 10.0 ** rng.integers(-4, 1)
+        th, m, v = O.adam_update(th, gr, m, v, t, lr)
+        opt.param_groups[0]["eps"] = 1e-4 / np.sqrt(1.0 - 0.999 ** t)
+        p.grad = torch.from_numpy(gr.copy())
+        opt.step()
+        np.testing.assert_allclose(th, p.detach().numpy(), rtol=1e-12, atol=1e-14)
