@@ -86,7 +86,7 @@ def kernel_models(cfg):
             match="bern_pipe_kernel" if big else "block_fwd_kernel<6, true" if M <= 4096 else "dense_kernel<4"),
         "out_bwd": dict(name="out_bwd_s_kernel<7> (output-layer backward from the stored s: dg2 = s W^T, dpre2)",
                         bytes=M * (2 * X + 2 * H + 4 + 2 * H), flop=2 * M * H * X, match="out_bwd_s_kernel"),
-        "decoder_bwd": dict(name=("dec_bwd_rows_kernel (<= 1 024 rows: 16-row workgroups, weights straight from L2)" if M <= 1024 else "dec_bwd_kernel<7>") +
+        "decoder_bwd": dict(name=("dec_bwd_rows_kernel (<= 1 024 rows: 16-row workgroups, weights straight from L2)" if M <= 1024 else "dec_bwd_kernel<7,8,1> (8 waves x 16 rows)") +
                                  " (decoder dX chain in one launch: dg2 = s W3^T -> dpre2 -> dpre1 -> dz; s, g2, g1 in, dpre2, dpre1, dz out)",
                             bytes=M * (2 * X + 2 * H + 4 + 2 * H + 2 * H + 2 * H + (2 if cfg["layers"] == 1 else 4) * D), flop=2 * M * (H * X + H * H + H * D),
                             match="dec_bwd_rows_kernel" if M <= 1024 else "dec_bwd_kernel"),
