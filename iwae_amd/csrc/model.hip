@@ -1254,7 +1254,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                 if (dz_half) d.DZH = (uint16_t*)w.dz.p;
                 d.nw = m->dec_bwd_nw;
                 if (m->dstamp_epi == 9) {      // diagnostic (STAMPS=1 build, IWAE_DENSE_STAMPS=9:0): phase stamps of dec_bwd_kernel
-                    m->dstamp_waves = ((M + 127) / 128) * 4;
+                    m->dstamp_waves = ((M + 127) / 128) * (L.KT == 7 ? m->dec_bwd_nw : 4);
                     CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st));
                     d.o.stamps = ptr<unsigned long long>(m->dstamps);
                 }
