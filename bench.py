@@ -221,6 +221,7 @@ def run():
     ap.add_argument("--no-kernel-times", action="store_true", help="skip the per-kernel event pass behind the timed region (profiling)")
     ap.add_argument("--timing-every", type=int, default=TIMING_EVERY, help="the per-kernel event pass brackets the kernels of every n-th step")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="iwae_set_option switch for A/B measurements (repeatable; tools/README.md)")
+    ap.add_argument("--lib", default=None, metavar="PATH", help="developer A/B only: load this build of libiwae_amd.so instead of the in-tree one (recorded in config.lib)")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the data-parallel code path with ONE rank (trivial collectives)")
     ap.add_argument("--dp-torch", action="store_true", help="data-parallel exchange through torch.distributed.all_reduce instead of the library's own RCCL calls")
     args = ap.parse_args()
@@ -246,6 +247,13 @@ def run():
                 os.environ.setdefault(key, val)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.lib:      # (an older build may lack newer symbols: bind what it has)
+        import ctypes
+        from iwae_amd import _capi
+        _capi.LIB_PATH = os.path.abspath(args.lib)
+        probe = ctypes.CDLL(_capi.LIB_PATH)
+        for name in [n for n in _capi.SYMBOLS if not hasattr(probe, n)]:
+            del _capi.SYMBOLS[name]
     from iwae_amd.native import NativeModel
     from iwae_amd.parallel import DataParallelStep
     from iwae_amd import utils

@@ -105,6 +105,10 @@ typedef struct {
 
 const char* iwae_last_error(void);
 int iwae_version(void);
+/* 16 hex digits of the sha256 over the sources this binary was built from (iwae_amd/csrc/build.sh; "-diag" appended for diagnostic
+ * builds): ties a shipped .so to a source tree -- the test suite rebuilds on mismatch, bench.py stamps its line with it and drops
+ * profile artefacts (profiles/ *_kernel_traffic.json) taken on another build.  No reference counterpart. */
+const char* iwae_build_id(void);
 
 /* model construction: iwae1.IWAE(...) / iwae2.IWAE(...) ; weights glorot-uniform / zero-bias
  * (Keras Dense defaults, src/iwae1.py:31-34,72-75) drawn from `seed`; set the data-mean output
@@ -179,7 +183,7 @@ int iwae_comm_unique_id(void* id_out, size_t cap, size_t* id_bytes);
 int iwae_comm_init(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
 /* The checks of iwae_comm_init that need no other rank (arguments, handle state, RCCL loadable), without the rendezvous: ncclCommInitRank
  * blocks until every rank has entered it, so a multi-process caller runs this first, agrees on the outcome over its own channel, and only
- * then lets every rank call iwae_comm_init (no reference counterpart: the reference is single-device, /root/reference/main.py:24,32). */
+ * then lets every rank call iwae_comm_init (no reference counterpart: the reference is single-device, main.py:24,32). */
 int iwae_comm_preflight(iwae_handle h, const void* unique_id, size_t id_bytes, int32_t world_size, int32_t rank);
 int iwae_comm_destroy(iwae_handle h);
 /* what RCCL itself reports for the handle's communicators (ncclCommCount / ncclCommUserRank): *world_size = 0, *rank = -1 when
@@ -187,8 +191,10 @@ int iwae_comm_destroy(iwae_handle h);
 int iwae_comm_info(iwae_handle h, int32_t* world_size, int32_t* rank);
 
 /* test-set LLH loop of main.py:170-184: mean over N images of iwae_elbo(k samples, B=1), images
- * batched `chunk` at a time on the device (chunk <= 0: as many as the row cap per launch allows -- option eval_rows, 2^21 rows at the
- * reference's dims, 2^19 otherwise; beyond it an image's k samples are walked in chunks and merged with a running log-sum-exp).
+ * batched `chunk` at a time on the device (chunk <= 0: as many as the row cap per launch allows -- option eval_rows; by default 2^21 rows
+ * where the whole decoder forward is ONE launch for the evaluator's precision (1-layer model, hidden width 200, unconditional, the fused
+ * decoder kernels not switched off), 2^19 otherwise; beyond it an image's k samples are walked in chunks and merged with a running
+ * log-sum-exp).
  * x: host or device pointer, [N, x_dim]; a host batch is uploaded once.  The launches' per-image estimates stay on the device until one
  * copy at the end: the call returns after one synchronisation.  An image's estimate does not depend on the launch it rode in (the draws are
  * keyed by the global image index: iwae_set_step).  llh_per_image may be NULL. */

@@ -40,6 +40,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "iwae_last_error": (C.c_char_p, []),
     "iwae_version": (C.c_int, []),
+    "iwae_build_id": (C.c_char_p, []),
     "iwae_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "iwae_destroy": (None, [_P]),
     "iwae_set_stream": (C.c_int, [_P, _P]),
@@ -82,6 +83,40 @@ SYMBOLS = {
 }
 
 _lib = None
+
+_ID_SOURCES = ("build.sh", "fp32_kernels.hip", "kernels.h", "kernels.hip", "layout.h", "model.hip", os.path.join("..", "..", "include", "iwae_amd.h"))
+
+
+def source_build_id():
+    """What csrc/build.sh would stamp into a library built from THIS tree (same files, order and framing): sha256, 16 hex digits."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for f in _ID_SOURCES:
+        h.update(("== %s\n" % os.path.basename(f)).encode())
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def library_build_id():
+    """iwae_build_id() of the loaded library ("unknown": built without csrc/build.sh)."""
+    return load().iwae_build_id().decode()
+
+
+def file_build_id(path=None):
+    """The id stamped into the library FILE, read from its bytes (no dlopen: a process that has already loaded an older build of the
+    same path would be handed that one again).  None: no file; "unknown": no stamp."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    i = blob.find(b"IWAE_BUILD_ID=")
+    if i < 0:
+        return "unknown"
+    j = blob.find(b"\0", i)
+    return blob[i + 14:j].decode("ascii", "replace")
 
 
 def load():

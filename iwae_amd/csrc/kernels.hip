@@ -1338,6 +1338,39 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     char* lx = smem + 2 * UNIT;
     const int blk_r0 = blockIdx.x * ROWS;
     const int b0 = blk_r0 / a.k, b1 = min(blk_r0 + ROWS - 1, a.M - 1) / a.k;
+    // Round 5, the 16-wave shape's sampling prologue (z = mu + sigma*eps, iwae1.py:59,107,109).  Counters of round 4's form (per-phase exits,
+    // profiles/r05_bern_pipe_phases.txt): 971 vector instructions per wave and 13.8 of the kernel's 63.8 us for 25 z values per lane -- every
+    // 4 elements a basic block of its own (masks, a 12-instruction __logf per element) whose three loads were waited for right behind their
+    // issue: eight dependent round trips to memory per wave.  Now: the lane's 8 float4 of draws are requested FIRST, all at once (the only
+    // HBM stream of the prologue, 20 MB chip-wide); the heads of the workgroup's <= 8 images are staged in LDS once (zero beyond D, so pad
+    // features need no masks), sum_d log sigma_d is made ONCE per image by one wave instead of per row and element, and a row's densities are
+    //   log p(z) = -1/2 sum z^2 - D/2 log 2pi,   log q(z|x) = -1/2 sum eps^2 - D/2 log 2pi - sum log sigma      ((z - mu)/sigma = eps)
+    // -- three fused multiply-adds per element.
+    constexpr bool ZQ = PRE && QW;
+    constexpr int HZ_OFF = 2 * UNIT + 128 + 4096 + 2 * KTC * 1024 + 4096 + 1024;      // + 8 * ldXB * 4: behind the in-kernel lse_image's area
+    float4 ze[8];
+    if constexpr (PRE) {
+        if (a.zhead) {
+            const float* er = a.zeps + (size_t)rowc * a.zldE;
+            const int flast = a.zldE - 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ze[i] = *(const float4*)(er + min(32 * (i >> 1) + 16 * (i & 1) + 4 * q, flast));      // (chunks beyond the row: a valid address, masked below)
+        }
+    }
+    if constexpr (ZQ) {
+        if (a.zhead) {
+            float* hzf = (float*)(smem + HZ_OFF + (size_t)8 * a.ldXB * 4);
+            const int zDp = a.zDp, c4 = zDp >> 2, nimg = b1 - b0 + 1;
+            for (int o = threadIdx.x; o < nimg * 2 * c4; o += 64 * NWV) {
+                const int img = o / (2 * c4), r = o - img * 2 * c4, arr = r >= c4 ? 1 : 0, c = r - arr * c4;
+                const float4 v = *(const float4*)(a.zhead + (size_t)(b0 + img) * a.ldZH + arr * zDp + 4 * c);
+                float w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = (4 * c + i < a.zD) ? w[i] : 0.0f;
+                *(float4*)(hzf + (size_t)(img * 3 + arr) * zDp + 4 * c) = make_float4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    }
     const int xchunks = (b1 - b0 + 1) * a.ldXB / 8;           // 16-byte pieces of bf16 x (the rows of XB are contiguous)
     for (int o = threadIdx.x; o < xchunks; o += 64 * NWV) {
         const uint4 v = *(const uint4*)(a.XB + (size_t)b0 * a.ldXB + (size_t)o * 8);
@@ -1358,10 +1391,50 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
     } else {
         const int KT1 = a.pre_KT1, ldZ = 32 * KT1;       // <= 4 k-steps of latent features
         uint4 zf[4];
-        if (a.zhead) {      // z = mu + sigma*eps of this row, its prior and posterior log-densities (iwae1.py:59,107,109)
-            float lp = 0.0f, lq = 0.0f, lq2 = 0.0f;
-            const float* hd = a.zhead + (size_t)(rowc / a.k) * a.ldZH;
-            const float* er = a.zeps + (size_t)rowc * a.zldE;
+        if (a.zhead) {
+            // z = mu + sigma*eps of this row and its prior / posterior log-densities (iwae1.py:59,107,109).  ONE arithmetic for both workgroup
+            // shapes -- a row's densities must not depend on the shape its batch took (two half batches take the 8-wave shape, the full
+            // batch the 16-wave one: test_full_size_batch_permutation_and_shard_equivalence) -- they differ in where the heads come from:
+            // the 16-wave shape reads its <= 8 images' heads and log-sigma sums from LDS (staged above), the 8-wave shape (80 KiB of LDS
+            // for two workgroups per CU: no room) reads the heads from L2 and every wave sums log sigma of its rows' <= 2 images itself.
+            const int zDp = a.zDp;
+            const int bimg = min(rowc / a.k, b1);      // (the shared 13th tile's rows beyond the workgroup's 200 belong to the next one: any staged image will do, nothing of them is kept)
+            const bool dreg = a.zlq_dreg != nullptr;
+            auto logsig = [&](const float* sgp, float& s1, float& s2) {      // sum_d log2 sigma_d (and of sigma_d + 1e-6) by one wave: the same reduction wherever it runs
+                s1 = 0.0f; s2 = 0.0f;
+                for (int d = lane; d < a.zD; d += 64) {
+                    const float sg = sgp[d];
+                    s1 += log2_raw(sg);
+                    if (dreg) s2 += log2_raw(sg + 1e-6f);
+                }
+                s1 = LN2_F * wave_sum(s1); s2 = LN2_F * wave_sum(s2);
+            };
+            float hs1 = 0.0f, hs2 = 0.0f;
+            const float* hm;                // the row's image: mu at [0, D), sigma at [zDp, zDp + D)
+            if constexpr (ZQ) {
+                float* hzf = (float*)(smem + HZ_OFF + (size_t)8 * a.ldXB * 4);
+                float* hsum = hzf + 8 * 3 * zDp;
+                __syncthreads();                  // the images' heads are in LDS
+                if (wave <= b1 - b0) {
+                    float s1, s2;
+                    logsig(hzf + (size_t)(wave * 3 + 1) * zDp, s1, s2);
+                    if (lane == 0) { hsum[2 * wave] = s1; hsum[2 * wave + 1] = s2; }
+                }
+                __syncthreads();
+                hm = hzf + (size_t)(bimg - b0) * 3 * zDp;
+                hs1 = hsum[2 * (bimg - b0)]; hs2 = hsum[2 * (bimg - b0) + 1];
+            } else {
+                hm = a.zhead + (size_t)bimg * a.ldZH;
+                const int ilo = __builtin_amdgcn_readlane(bimg, 0), ihi = __builtin_amdgcn_readlane(bimg, 15);      // (k >= 32: a tile's 16 rows span <= 2 images)
+                float s1, s2;
+                logsig(a.zhead + (size_t)ilo * a.ldZH + zDp, s1, s2);
+                hs1 = s1; hs2 = s2;
+                if (ihi != ilo) {
+                    logsig(a.zhead + (size_t)ihi * a.ldZH + zDp, s1, s2);
+                    if (bimg != ilo) { hs1 = s1; hs2 = s2; }
+                }
+            }
+            float sz = 0.0f, se = 0.0f, su = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 zf[ks] = make_uint4(0, 0, 0, 0);
@@ -1370,26 +1443,27 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int f0 = 32 * ks + 16 * h + 4 * q;
-                        float4 e4 = make_float4(0.f, 0.f, 0.f, 0.f), mu4 = e4, sg4 = make_float4(1.f, 1.f, 1.f, 1.f);
-                        if (f0 < a.zD) {
-                            e4 = *(const float4*)(er + f0);
-                            mu4 = *(const float4*)(hd + f0);
-                            sg4 = *(const float4*)(hd + a.zDp + f0);
+                        const float4 mu4 = *(const float4*)(hm + f0), sg4 = *(const float4*)(hm + zDp + f0);
+                        const float4 e4 = ze[2 * ks + h];
+                        float ev[4] = {e4.x, e4.y, e4.z, e4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+                        const float sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+                        if (32 * ks + 16 * h + 16 > a.zD) {      // (wave-uniform: the one or two chunks that straddle or lie beyond D -- pad features are exactly 0)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { const bool in = f0 + i < a.zD; ev[i] = in ? ev[i] : 0.0f; muv[i] = in ? muv[i] : 0.0f; }
                         }
-                        const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float z = 0.0f;
-                            if (f0 + i < a.zD) {
-                                z = fmaf(sgv[i], ev[i], muv[i]);
-                                lp += -0.5f * z * z - 0.5f * LOG2PI_F;
-                                lq += -0.5f * ev[i] * ev[i] - 0.5f * LOG2PI_F - __logf(sgv[i]);
-                                if (a.zlq_dreg) {                                    // tasks/task02.py:63-65 (sample_kernel's arithmetic)
-                                    const float s2 = sgv[i] + 1e-6f, u2 = (z - muv[i]) * __builtin_amdgcn_rcpf(s2);
-                                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
-                                }
-                            }
+                            const float z = fmaf(sgv[i], ev[i], muv[i]);
+                            sz = fmaf(z, z, sz);
+                            se = fmaf(ev[i], ev[i], se);
                             z8[4 * h + i] = z;
+                        }
+                        if (dreg) {      // tasks/task02.py:63-65: (z - mu)/(sigma + 1e-6) = eps * sigma/(sigma + 1e-6)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float u2 = (sgv[i] * __builtin_amdgcn_rcpf(sgv[i] + 1e-6f)) * ev[i];
+                                su = fmaf(u2, u2, su);
+                            }
                         }
                     }
                     const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
@@ -1397,10 +1471,12 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
                     if (valid && storer && a.ZPout) *(uint4*)(a.ZPout + (size_t)row * ldZ + ks * 32 + q * 8) = frag;
                 }
             }
-            lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
-            lq += __shfl_xor(lq, 16); lq += __shfl_xor(lq, 32);
-            lq2 += __shfl_xor(lq2, 16); lq2 += __shfl_xor(lq2, 32);
-            if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; if (a.zlq_dreg) a.zlq_dreg[row] = lq2; }
+            sz += __shfl_xor(sz, 16); sz += __shfl_xor(sz, 32);
+            se += __shfl_xor(se, 16); se += __shfl_xor(se, 32);
+            su += __shfl_xor(su, 16); su += __shfl_xor(su, 32);
+            const float cD = 0.5f * LOG2PI_F * (float)a.zD;
+            const float lp = -0.5f * sz - cD, lq = -0.5f * se - cD - hs1, lq2 = -0.5f * su - cD - hs2;
+            if (q == 0 && valid && storer) { a.zlp[row] = lp; a.zlq[row] = lq; if (dreg) a.zlq_dreg[row] = lq2; }
             if constexpr (QW) {      // (kept in LDS for the in-kernel lse_image at the end: an area nothing else touches)
                 if (a.lse_on && q == 0 && storer) {
                     float* lz = (float*)(smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * KTC * 1024);
@@ -1432,7 +1508,9 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
             for (int p2 = 0; p2 < 2; ++p2)
                 if (2 * mg + p2 < KTC) *(uint4*)(Gout + (size_t)row * (32 * KTC) + (2 * mg + p2) * 32 + q * 8) = bout[2 * mg + p2];
         };
-        auto hidden = [&](auto nb_tag, uint4* bin, int KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout, const char* xch_in, char* xch_out, auto&& first) {
+        // (KTin: an int, or an integral_constant -- the layer's k-step count known at compile time: the run-time form puts a scalar branch
+        // around every MFMA and LDS read of the layer, one basic block each)
+        auto hidden = [&](auto nb_tag, uint4* bin, auto KTin, int ubase, uint4 (&bout)[KTC], uint16_t* Gout, const char* xch_in, char* xch_out, auto&& first) {
             constexpr int NB = decltype(nb_tag)::value;
             const bool quarter = QW && qw >= 0;
 #pragma unroll
@@ -1479,7 +1557,9 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
                         const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-                        bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);      // (stored one unit later: store_group; forward-only calls keep nothing, Gout = null)
+                        // (rows beyond M / beyond the tile's share carry finite values of a clamped row: a data row is a COLUMN of every product
+                        // here, nothing mixes rows, and nothing of such a row is stored -- zeroing them was 8 v_cndmask per group)
+                        bout[kso] = frag;      // (stored one unit later: store_group; forward-only calls keep nothing, Gout = null)
                     }
                 }
             }
@@ -1487,10 +1567,14 @@ __global__ __launch_bounds__(QW ? 1024 : 512, 4) void bern_pipe_kernel(DenseArgs
         char* xch1 = smem + 2 * UNIT + (size_t)8 * a.ldXB * 4 + 128 + 4096;      // g1 / g2 of the shared tile: 7 KiB each
         char* xch2 = xch1 + KTC * 1024;
         DS_STAMP(0);
-        hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1, [] {});
+        if (WG_DBG(a, 128)) { wait_all_vmem(); return; }      // (DIAG phase exits, counters only: behind the prologue + z ...
+        if (KT1 == 4) hidden(std::integral_constant<int, 4>{}, zf, std::integral_constant<int, 4>{}, 0, g1f, a.pre_G1, nullptr, xch1, [] {});      // (the reference's latent: 100 -> 128 = 4 k-steps)
+        else hidden(std::integral_constant<int, 4>{}, zf, KT1, 0, g1f, a.pre_G1, nullptr, xch1, [] {});
         DS_STAMP(1);
-        hidden(std::integral_constant<int, KTC>{}, g1f, KTC, MGH, bfr, a.pre_G2, xch1, xch2, [&] { store_group(a.pre_G1, g1f, MGH - 1); });
+        if (WG_DBG(a, 512)) { wait_all_vmem(); return; }      // ... behind the first tanh layer ...
+        hidden(std::integral_constant<int, KTC>{}, g1f, std::integral_constant<int, KTC>{}, MGH, bfr, a.pre_G2, xch1, xch2, [&] { store_group(a.pre_G1, g1f, MGH - 1); });
         DS_STAMP(2);
+        if (WG_DBG(a, 256)) { wait_all_vmem(); return; }      // ... behind both)
     }
 
     f32x4 accA[2], accB[2];      // the two tile pairs swap roles every stage (multiply into one, epilogue from the other)
@@ -4579,7 +4663,8 @@ void launch_dense(int epi, const DenseArgs& a, hipStream_t st) {
     if (epi == EPI_BERN && a.pipe && bern_pipe_ok(a)) {
         const size_t ldsb = 2 * (7 * 4096 + 1024) + (size_t)BERN_XIMG_MAX * a.ldXB * 4 + 128;
         if (a.pre_img1 && a.pipe >= 2 && (198 + a.k) / a.k + 1 <= 8) {       // 16-wave / 200-row shape (see QW)
-            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024 + 4096 + 1024;      // (last 5 KiB: the rows' terms for the in-kernel lse_image, 208 floats each, and its row weights)
+            const size_t ldsq = 2 * (7 * 4096 + 1024) + (size_t)8 * a.ldXB * 4 + 128 + 4096 + 2 * 7 * 1024 + 4096 + 1024      // (last 5 KiB: the rows' terms for the in-kernel lse_image, 208 floats each, and its row weights)
+                                + (a.zhead ? (size_t)8 * 3 * a.zDp * 4 + 256 : 0);      // (the sampling prologue's heads of <= 8 images: mu | sigma | sigma/(sigma + 1e-6), + their log-sigma sums)
             if (a.YP) LAUNCH_EV((bern_pipe_kernel<7, true, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
             else LAUNCH_EV((bern_pipe_kernel<7, false, true, true>), dim3((a.M + 199) / 200), dim3(1024), ldsq, st, a);
         } else if (a.pre_img1) {       // the whole decoder in one launch

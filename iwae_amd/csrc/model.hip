@@ -242,6 +242,8 @@ struct iwae_model {
     size_t split_offset = 0;    // iwae_forward_backward_split: first float of the flat gradient that was left on the side stream
     int wg_shape9 = 0;          // IWAE_WG9 (bit mask, see wgradp_plan): layers that take the 8 + 8-wave / 128-feature shape of wgradws_kernel
     int fake_s = 0;             // DIAG builds: byte ablations of s (option fake_s)
+    int abl_skip = 0;           // DIAG builds: launch ablations of the full-size step (option abl_skip; timing only, results wrong): 1 no output-layer weight gradient,
+                                // 2 no hidden-layer weight gradients, 4 no deferred decoder reduction + update, 8 no latent_bwd_kernel, 16 no noise draw ahead
     int wg_debug = 0;           // IWAE_WG_DEBUG: diagnostic ablations of wgradp_kernel (kernels.h)
     bool allow_wg7 = true;      // IWAE_NO_WG7=1: the 16-wave weight-gradient shapes also where the 8-wave 7 x 4 shape exists (A/B measurements)
     int dec_rows_max = 1024;    // dec_bwd_rows_kernel up to this many rows (IWAE_DEC_ROWS), dec_bwd_kernel beyond
@@ -263,6 +265,9 @@ struct iwae_model {
     bool allow_dec_fused = true;     // IWAE_NO_DEC_FUSED=1: the two tanh layers of the decoder stay dense_kernel launches (A/B measurements)
     bool allow_bern_pipe = true;   // IWAE_NO_BERN_PIPE=1: the Bernoulli forward stays on dense_kernel<EPI_BERN> (A/B measurements)
     bool allow_defer = true;    // IWAE_NO_DEFER=1: always join at the end of the step (A/B measurements)
+    int wout_split = 0, wout_wg1 = 56, wout_wg2 = 128;      // option wout_split (percent of the rows, 0 = off; round 5): the output layer's weight gradient as an EARLY launch on few
+                                // workgroups beside dec_bwd_kernel (rows [0, R1)) and a LATE one behind it (the rest, beside the hidden layers' gradients)
+    bool defer_split = false;   // option defer_split (round 5): 1-layer step, each side stream sums + updates the decoder layers whose gradients IT carried
     int early_first2 = -1;      // 2-layer model: first reduce block behind the image encoder's layers (everything whose weight gradients run on the side streams)
     bool allow_defer2 = true;   // option no_defer2
     bool allow_defer2_split = true, dec2_pending = false;      // ... one deferred update per side stream (option no_defer2_split: one, on `tail`)
@@ -624,6 +629,33 @@ int wgradp(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int
 }
 
 // dX (times tanh' of the stored activation, or raw fp32) of a layer: X = dpre of the layer's outputs
+// The output layer's gradient in two launches over disjoint row ranges (option wout_split): slabs [0, n1) come from rows [0, R1), slabs
+// [n1, n1 + n2) from the rest -- the reduction sums them in that fixed order whichever launch ends first.
+int wgradp_two_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP, int rows, const float* rowscale, WgradPArgs& a1, int& n1, WgradPArgs& a2, int& n2) {
+    const int blocks = (L.JT + 15) / 16;
+    const int chunks = (rows + 63) / 64;
+    const int c1 = std::min(chunks - 1, std::max(1, (int)((long)chunks * m->wout_split / 100)));
+    const int c2 = chunks - c1;
+    auto split = [&](int ch, int target, int& n, int& cps) { n = std::max(1, std::min(ch, target / std::max(1, blocks))); cps = (ch + n - 1) / n; n = (ch + cps - 1) / cps; };
+    int cps1, cps2;
+    split(c1, m->wout_wg1, n1, cps1);
+    split(c2, m->wout_wg2, n2, cps2);
+    const int ns = n1 + n2;
+    const size_t stride = (size_t)L.IT * 16 * L.JT * 16;
+    void* oldW = L.slabW.p; void* oldB = L.slabB.p;
+    CHK(ensure(L.slabW, (size_t)ns * stride * 4, m->stream));
+    CHK(ensure(L.slabB, (size_t)ns * L.JT * 16 * 4, m->stream));
+    if (oldW != L.slabW.p || oldB != L.slabB.p || ns != L.nsplit) { L.nsplit = ns; m->descs_dirty = true; }
+    const int R1 = c1 * 64;
+    memset(&a1, 0, sizeof(a1));
+    a1.X = XP; a1.ldX = L.Kp32; a1.IT = L.IT; a1.G = GP; a1.ldG = L.Np32; a1.JT = L.JT; a1.M = R1; a1.rows_per_split = cps1 * 64;
+    a1.slabW = ptr<float>(L.slabW); a1.slabB = ptr<float>(L.slabB); a1.zero = m->d_zero; a1.rowscale = rowscale;
+    a2 = a1;
+    a2.X = XP + (size_t)R1 * L.Kp32; a2.G = GP + (size_t)R1 * L.Np32; a2.M = rows - R1; a2.rows_per_split = cps2 * 64;
+    a2.slabW = a1.slabW + (size_t)n1 * stride; a2.slabB = a1.slabB + (size_t)n1 * L.JT * 16; a2.rowscale = rowscale + R1;
+    return IWAE_OK;
+}
+
 int dense_dx(iwae_model* m, Linear& L, const uint16_t* GP, int rows, const uint16_t* ACT, uint16_t* YP, float* YF) {
     DenseArgs a;
     memset(&a, 0, sizeof(a));
@@ -763,7 +795,7 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
         CHK(ensure(m->epsc[par][l], (size_t)Mp * m->Dp[l] * 4, m->stream));
         EpsSrc e = eps_src(m, l);
         e.user = nullptr; e.cache = nullptr; e.step = step;
-        launch_eps_gen(e, M, m->D[l], eps_ld(m, l), ptr<float>(m->epsc[par][l]), gs, max_blocks);
+        if (!(m->abl_skip & 16)) launch_eps_gen(e, M, m->D[l], eps_ld(m, l), ptr<float>(m->epsc[par][l]), gs, max_blocks);
     }
     HIPCHK(hipGetLastError());
     tg.valid = true; tg.step = step; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
@@ -1028,6 +1060,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.YP = ptr<uint16_t>(m->wdec1.dlP); a.ldYP = Xp;
             if (m->fake_s & 4) a.dbg = 32;
             if (m->fake_s & 16) a.dbg |= 64;      // (the decoder kernel's tanh layers without their weight DMA)
+            if (m->fake_s & 32) a.dbg |= 128;     // (phase exits of the decoder kernel, for instruction counters: behind the prologue,
+            if (m->fake_s & 64) a.dbg |= 256;     //  behind both tanh layers,
+            if (m->fake_s & 128) a.dbg |= 512;    //  behind the first)
         }
         a.logits_out = nullptr;
         a.pipe = m->allow_bern_pipe ? 1 : 0;
@@ -1273,7 +1308,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     hipStream_t sd = m->side;
     // Few rows (round 3): the decoder's three weight gradients as ONE grouped launch behind the dX chain (the B = 20 step is bound by the host's
     // launches and the streams' hand-offs, not by these kernels: 13 -> 11 launches, two events less)
-    bool group3 = false;
+    bool group3 = false, split_upd = false;
     WgradPGroup g3;
     if (!dec_rows && m->allow_wg3 && M <= 4096 && fused_dx && m->early_wout && m->use_side2 && m->s_mode) {
         memset(&g3, 0, sizeof(g3));
@@ -1308,8 +1343,22 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     else HIPCHK(hipStreamWaitEvent(m->side, fused_dx ? m->ev_fork2 : m->ev_fork, 0));  // the event rode on out_bwd's / dec_bwd's dispatch packet
     {   // (its completion event ev_s2 rides on the dispatch packet: the stream that later picks `side` up waits ~8 us less than behind a record)
         ScopedTimer tm(m, T_WGRAD_OUT, sd);
-        if (m->early_wout && m->use_side2) set_launch_stop_event(m->ev_s2);
-        if (m->g2w) CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2wP), ptr<uint16_t>(w.dlP), M, sd, nullptr));      // (pre-weighted X operand: the unweighted kernel)
+        const bool two_part = m->wout_split > 0 && m->s_mode && !m->g2w && m->early_wout && m->use_side2 && fused_dx && M >= 8192 && m->dec1[2].IT <= 14 && m->allow_wg7 && !(m->abl_skip & 1);
+        if (two_part) {
+            WgradPArgs a1, a2;
+            int n1 = 1, n2 = 1;
+            CHK(wgradp_two_plan(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, ptr<float>(m->lse_dup ? m->gx2 : m->gx), a1, n1, a2, n2));
+            launch_wgradp(a1, n1, 7, sd);
+            HIPCHK(hipStreamWaitEvent(sd, m->ev_fork2, 0));      // (the late part starts behind dec_bwd_kernel, beside the hidden layers' gradients)
+            set_launch_stop_event(m->ev_s2);
+            launch_wgradp(a2, n2, 7, sd);
+            HIPCHK(hipGetLastError());
+        } else
+        if (m->abl_skip & 1) { if (m->early_wout && m->use_side2) HIPCHK(hipEventRecord(m->ev_s2, sd)); }
+        else if (m->early_wout && m->use_side2) set_launch_stop_event(m->ev_s2);
+        if (two_part) {} else
+        if (m->abl_skip & 1) { WgradPArgs a0; int n0 = 1, w0 = 8; CHK(wgradp_plan(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, a0, n0, w0)); }      // (slabs allocated: the reduction still reads them)
+        else if (m->g2w) CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2wP), ptr<uint16_t>(w.dlP), M, sd, nullptr));      // (pre-weighted X operand: the unweighted kernel)
         else CHK(wgradp(m, m->dec1[2], ptr<uint16_t>(w.g2P), ptr<uint16_t>(w.dlP), M, sd, m->s_mode ? ptr<float>(m->lse_dup ? m->gx2 : m->gx) : nullptr));
     }
     if (!fused_dx) {
@@ -1347,13 +1396,15 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
             ScopedTimer tm(m, T_WGRAD_HID, ws);
             launch_wgradws_group(g, ws);
         } else {
-            { ScopedTimer tm(m, T_WGRAD_HID, ws); launch_wgradp(ah, nsh, shh, ws); }
+            if (!(m->abl_skip & 2)) { ScopedTimer tm(m, T_WGRAD_HID, ws); launch_wgradp(ah, nsh, shh, ws); }
             if (!m->early_wout && !fused_dx) HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
-            { ScopedTimer tm(m, T_WGRAD_LAT, ws); launch_wgradp(al, nsl, shl, ws); }
+            if (!(m->abl_skip & 2)) { ScopedTimer tm(m, T_WGRAD_LAT, ws); launch_wgradp(al, nsl, shl, ws); }
         }
         HIPCHK(hipGetLastError());
     }
-    if (ws == m->side2) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
+    if (m->defer_split && m->descs_dirty) CHK(build_descs(m));      // (early_first comes from the table)
+    split_upd = m->defer_split && fused_lr >= 0.0f && m->allow_defer && m->early_first > 0 && !two && ws == m->side2 && m->early_wout;
+    if (ws == m->side2 && !split_upd) HIPCHK(hipStreamWaitEvent(m->side2, m->ev_s2, 0));
     }      // (!group3)
     const bool fuse = fused_lr >= 0.0f;
     const float alpha = fuse ? adam_alpha(m, fused_lr) : 0.0f;
@@ -1435,7 +1486,7 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         // (measured, end-to-end us per step with / without: B = 20, k = 1: 67.7 / 70.0; B = 20, k = 5: 67.5 / 69.3; B = 100, k = 5: 72.1 / 73.4; B = 20, k = 50: 88.2 / 78.5 --
         // one wave walking 50 samples is slower than latent_bwd_kernel's 256 threads: up to 16 samples per image)
         lat_fuse = m->allow_lat_in_block && !m->has_prior && B <= 1024 && k <= 16 && m->allow_block_fused;
-        if (!lat_fuse) { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
+        if (!lat_fuse && !(m->abl_skip & 8)) { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
     // Round 4: on few rows the image encoder's weight gradients, their sum over ALL rows and (fused step) the Adam update are one launch
@@ -1521,14 +1572,31 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
                             m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
         m->dec_pending = true;
     }
-    if (defer) {
+    if (defer && split_upd && m->early_first > 0) {
+        // Round 5: one deferred update per side stream, each behind the weight gradients it carried -- no hand-off between the two side
+        // streams in front of the update, and the output layer's share (54 % of the decoder's slabs) is done ~20 us before the hidden layers'
+        // gradients end.  The output layer's gradient forked behind the decoder FORWARD: its update rewrites the W3 image dec_bwd_kernel
+        // reads, so `side` waits for that kernel's event first (long complete by then).
+        const int b_out = m->descs[m->dec1[2].sub[0]].rblock_begin;
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0));
+        set_launch_stop_event(m->ev_dec2);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), b_out, m->reduce_blocks - b_out, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1,
+                            m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side);
+        set_launch_stop_event(m->ev_dec);
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, b_out - m->early_first, m->grad, m->param, m->mom, m->vel, alpha, m->adam_b1,
+                            m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->side2);
+        m->dec_pending = true; m->dec2_pending = true;
+    } else if (defer) {
         // The decoder's layers (90 % of the slab bytes): slab sums + Adam on the side stream, behind its weight gradients
         // (which wait for ev_fork2, i.e. for dX of d1, the last reader of the decoder's weight images -- without that order
         // the trajectory test caught a stale-image race), joined by the next user of the decoder (join_side): it runs beside
         // the encoder's backward pass / update and the next step's encoder forward.
+        if (m->abl_skip & 4) HIPCHK(hipEventRecord(m->ev_dec, m->tail));
+        else {
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, alpha, m->adam_b1, m->adam_b2, m->adam_eps, 1, nullptr, 0, 0.f, nullptr, m->tail);
+        }
         m->dec_pending = true;
     }
     HIPCHK(hipGetLastError());
@@ -1870,7 +1938,11 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     // ---- log_w, log-mean-exp over k, objectives (iwae1.py:113-139): the shared kernel
     CHK(ensure(m->logw, (size_t)Mp * 4, st));
     CHK(ensure(m->wn, (size_t)Mp * 4, st));
-    CHK(ensure(m->gx, (size_t)Mp * 4, st));
+    {   // (as forward_impl: wgrad_rows_kernel's row-weighted path reads gx in whole 32-row stages -- 0 x a non-finite pad would be NaN)
+        const void* before = m->gx.p;
+        CHK(ensure(m->gx, (size_t)Mp * 4, st));
+        if (m->gx.p != before) HIPCHK(hipMemsetAsync(m->gx.p, 0, m->gx.cap, st));
+    }
     CHK(ensure(m->cf, (size_t)Mp * 16, st));
     CHK(ensure(m->per_b, (size_t)PB_COUNT * B * 4, st));
     {
@@ -2018,6 +2090,11 @@ extern "C" {
 
 const char* iwae_last_error(void) { return g_err.c_str(); }
 int iwae_version(void) { return 1; }
+#ifndef IWAE_BUILD_ID
+#define IWAE_BUILD_ID "unknown"
+#endif
+static const char kBuildIdMarker[] = "IWAE_BUILD_ID=" IWAE_BUILD_ID;      // (the marker lets a checker read the id from the file without loading it)
+const char* iwae_build_id(void) { return kBuildIdMarker + 14; }
 
 int iwae_create(const iwae_config* cfg, iwae_handle* out) {
     if (!cfg || !out) return fail(IWAE_ERR_ARG, "iwae_create: null argument");
@@ -2349,6 +2426,10 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     const std::string n(name);
     if (n == "out_recompute") m->allow_s_mode = !on;                  // recompute the logits in out_bwd instead of keeping s
     else if (n == "no_defer") m->allow_defer = !on;                   // join the decoder update at the end of every step
+    else if (n == "wout_split") m->wout_split = std::max(0, std::min(95, iv));      // percent of the rows in the output layer's EARLY gradient launch (0: one launch)
+    else if (n == "wout_wg1") m->wout_wg1 = std::max(1, iv);          // ... its workgroups / those of the late launch
+    else if (n == "wout_wg2") m->wout_wg2 = std::max(1, iv);
+    else if (n == "defer_split") m->defer_split = on;                 // 1-layer step: one deferred decoder update per side stream
     else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
     else if (n == "zin_eval") m->allow_zin_eval = on;                 // forward-only calls: z made in the decoder kernel's prologue (measured slower)
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
@@ -2397,6 +2478,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "dense_stamps_epi") m->dstamp_epi = iv;
     else if (n == "dense_stamps_kt") m->dstamp_kt = iv;
     else if (n == "wg_debug") m->wg_debug = iv;
+    else if (n == "abl_skip") m->abl_skip = iv;      // launch ablations of the full-size step (timing only)
     else if (n == "fake_s") m->fake_s = iv;          // byte ablations (timing only): 1 dec_bwd_kernel reads s from 32 rows, 2 the output layer's gradient likewise, 4 the decoder kernel does not store s, 8 ... nor z / g1 / g2
 #endif
     else return fail(IWAE_ERR_ARG, "set_option: unknown option '" + n + "'");
@@ -2546,7 +2628,12 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
     // (2^21 rows per launch at the reference's hidden width -- the single-launch decoder kernels keep nothing per pixel, ~0.4 KiB of HBM per row, and
     // the per-launch costs (image encoder on ~100 images, log-mean-exp, launch boundaries) are a quarter of what they are at 2^19: bf16 186 -> 205 k
     // images/s, float32 35.0 -> 36.7 k; other shapes, whose fallback paths may keep float32 logits, stay at 2^19)
-    const int eval_rows = m->eval_rows > 0 ? m->eval_rows : ((m->dec1[2].KT == 7 && m->C == 0 && !m->has_prior) ? 1 << 21 : 1 << 19);
+    // (advisor, round 4: the large cap only where the single-launch decoder really runs for the evaluator's precision -- 1-layer model, the reference's
+    // hidden width, and neither of the fused paths switched off; the 2-layer model and the unfused float32 path keep per-row tensors: 2^19)
+    const bool eval_f32 = m->eval_precision == IWAE_PREC_FP32;
+    const bool one_launch_dec = m->cfg.n_layers == 1 && m->dec1[2].KT == 7 && m->C == 0 && !m->has_prior &&
+                                (eval_f32 ? (m->allow_f32_dec_fused && m->allow_f32_bern_fused) : (m->allow_bern_pipe && m->allow_dec_fused));
+    const int eval_rows = m->eval_rows > 0 ? m->eval_rows : (one_launch_dec ? 1 << 21 : 1 << 19);
     const int kc = std::min(k, eval_rows);
     if (chunk <= 0) chunk = std::max(1, eval_rows / kc);
     chunk = std::min(chunk, N);

@@ -23,11 +23,17 @@ def _have_gpu():
 
 @pytest.fixture(scope="session")
 def lib_built():
-    """The in-tree HIP library; build it once if the tree is fresh (hipcc cross-compiles without a GPU)."""
+    """The in-tree HIP library, built from THIS tree: build it if it is missing, and rebuild it when its stamped source hash
+    (iwae_build_id) is not the hash of the sources next to it -- the .so is git-ignored and ships prebuilt, nothing else ties the
+    binary under test to the tree (round-4 verdict).  hipcc cross-compiles without a GPU."""
     from iwae_amd import _capi
-    if not os.path.exists(_capi.LIB_PATH):
+    want = _capi.source_build_id()
+    have = _capi.file_build_id()
+    if have != want:
         import __graft_entry__
         __graft_entry__.build()
+        have = _capi.file_build_id()
+        assert have == want, "libiwae_amd.so does not match its sources after a rebuild: %r vs %r" % (have, want)
     return _capi.LIB_PATH
 
 

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Developer script (GPU box): the round's closing measurements in one call -- bench lines of every configuration, the rocprofv3 profiles
 # (kernel stats + PMC traffic passes), alone-times, the evaluator.  usage: bash tools/dev/final_round.sh <tag>     (e.g. r04)
-TAG=${1:-r04}
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p $O
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
+TAG=${1:-r05}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_$TAG; mkdir -p "$O"
 cd $R
 python bench.py --steps 200 --warmup 5 > $O/bench_line_c1.json 2> $O/bench_c1.err; tail -c 300 $O/bench_line_c1.json; echo
 python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_shape.json 2>> $O/bench_c1.err

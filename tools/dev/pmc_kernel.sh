@@ -2,8 +2,13 @@
 # Developer script (GPU box): SQ / TCC counter passes over the bench loop WITH a kernel trace in the same run (counter collection
 # serialises the dispatches, so the traced durations are each kernel ALONE on the machine), per-kernel per-launch averages.
 # usage: bash tools/dev/pmc_kernel.sh <tag> [kernel-name-substring ...]      env: BENCH_ARGS (extra bench.py arguments), PK_CMD (profile another command)
-TAG=${1:-x}; shift
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pk_$TAG; mkdir -p $OUT
+# PK_CMD must START with the interpreter / program itself (python3 ...): no env, bash -c, taskset or other hop after rocprofv3's `--`
+# (the profiler's preloaded library has initialised the GPU by then; a re-exec from there takes the box down).
+set -u
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
+TAG=${1:-x}; shift || true
+BENCH_ARGS=${BENCH_ARGS:-}
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pk_$TAG; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 CMD=${PK_CMD:-"python3 $R/bench.py --steps 30 --warmup 10 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS"}      # (PK_CMD: another program to profile, e.g. "python3 $GRAFT_REPO_ROOT/tools/dev/eval_only.py fp32 400")
 i=0
