@@ -162,11 +162,14 @@ def cpu_baseline(cfg, budget_s=12.0):
                       "TF2 (the reference runtime) is not installed, this is the oracle port" % (n, cfg["B"], cfg["k"], cfg["layers"], dt)}
 
 
-def load_profile_traffic(kernel_match, config):
+def load_profile_traffic(kernel_match, config, build_id):
     """HBM bytes per launch of the kernel whose device-side name contains `kernel_match`, from the PMC passes of
     tools/profile_bench.sh kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE: MI355X_MICROARCH.md, HBM).  Returned WITH its
-    source, or None when no kept profile holds that instantiation (the number is a profile artefact, not a live measurement)."""
-    for tag in ("r04", "r04_c2", "r03", "r03_c2"):      # (newest kept profile of this configuration first)
+    source, or None when no kept profile holds that instantiation.  The number is a profile artefact, not a live measurement, so it is
+    only quoted when the profile was taken ON THIS BUILD: the table carries the iwae_build_id() of the library it measured (round 5), and
+    a table of another build -- a kernel edited since, or a round-4 table, which carries no id -- gives None with the reason as source."""
+    stale = None
+    for tag in ("r05", "r05_c2", "r04", "r04_c2"):      # (newest kept profile of this configuration first)
         path = os.path.join(ROOT, "profiles", "%s_kernel_traffic.json" % tag)
         if not os.path.exists(path):
             continue
@@ -176,10 +179,13 @@ def load_profile_traffic(kernel_match, config):
             continue
         if tab.get("config", "c1") != config:
             continue
+        if tab.get("build_id") != build_id:
+            stale = stale or "profiles/%s_kernel_traffic.json was taken on build %s, this library is %s: not quoted" % (tag, tab.get("build_id"), build_id)
+            continue
         for ent in tab.get("kernels", []):
             if kernel_match in ent.get("kernel", ""):
                 return ent.get("hbm_bytes_per_launch"), "profiles/%s_kernel_traffic.json: %s" % (tag, ent["kernel"]), tab.get("step_hbm_bytes")
-    return None, None, None
+    return None, stale, None
 
 
 class _StdoutToStderr:
@@ -264,10 +270,9 @@ def run():
     net = NativeModel(cfg["layers"], cfg["nh"], cfg["nl"], x_dim=X_DIM, device=local_rank, seed=123, world_size=world, rank=rank,
                       precision=args.precision, options=options)
     net.set_output_bias(utils.bias_from_mean(p))                       # identical init on every rank (same seed)
-    # world > 1: the in-library RCCL exchange.  If it cannot be brought up on EVERY rank, all ranks together take the torch.distributed
-    # path (a collective decision, printed, and recorded in config.dp_path -- never a silent or rank-asymmetric fallback); the library's
-    # own default (DataParallelStep without allow_fallback) raises instead
-    dp = DataParallelStep(net, rank, world, in_library=not args.dp_torch, force_dist=force_dist, allow_fallback=True)
+    # world > 1: the in-library RCCL exchange.  If it cannot be brought up on EVERY rank the run RAISES on every rank
+    # (round 5: a line measured on the torch.distributed fallback is not the path the design describes; --dp-torch selects that path on purpose)
+    dp = DataParallelStep(net, rank, world, in_library=not args.dp_torch, force_dist=force_dist, allow_fallback=False)
     rccl_ranks = net.comm_info()[0] if dp.in_library else (dist.get_world_size() if dist and dp.path == "torch_fallback" else 0)
     lr = 1e-3
     obj_id = OBJ_ID[cfg["obj"]]
@@ -336,6 +341,11 @@ def run():
     if rank == 0:
         ms = dt * 1e3 / args.steps
         value = B * world * args.steps / dt
+        from iwae_amd import _capi
+        try:
+            build_id = _capi.library_build_id()
+        except Exception:      # (--lib with a build older than iwae_build_id)
+            build_id = "unknown"
         launched = {k: v for k, v in ktimes.items() if v[1] > 0}
         dom = max(launched, key=lambda k: launched[k][0]) if launched else None    # the kernel with the longest average launch, over ALL timed kernels
         flop_step = step_flops(cfg)
@@ -346,11 +356,13 @@ def run():
             "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            # the timed region by the wall clock (barrier + synchronise on both sides) and the build the line was measured on
+            "timed_region_s": round(dt, 6), "build_id": build_id,
             "config": {"workload": cfg["label"] + ", objective %s, train step = forward + backward + Adam(eps=1e-4)" % cfg["obj"]
                                    + (" + RCCL all-reduce of the flat fp32 gradient" if world > 1 else ""),
                        "config_id": args.config, "global_batch": B * world, "n_samples": K, "parallelism": "dp%d" % world,
                        # which exchange path ran, and over how many ranks RCCL itself says (ncclCommCount on the library's communicator)
-                       "dp_path": dp.path, "rccl_ranks": rccl_ranks, "allreduce_us": allreduce_us, "settle_steps": settle, "options": options,
+                       "dp_path": dp.path, "rccl_ranks": rccl_ranks, "allreduce_us": allreduce_us, "settle_steps": settle, "options": options, "lib": args.lib,
                        "step_gemm_tflops": round(flop_step * world / (dt / args.steps) / 1e12, 1),
                        "iwae_elbo_after": round(float(elbo), 3), "llh_eval_k5000": llh_eval},
         }
@@ -358,7 +370,7 @@ def run():
             dom_us, dom_n = launched[dom]
             km = models[dom]
             hbm_bound = km["flop"] / max(km["bytes"], 1) < RIDGE
-            traffic, tsrc, step_hbm = load_profile_traffic(km["match"], args.config)
+            traffic, tsrc, step_hbm = load_profile_traffic(km["match"], args.config, build_id)
             ach = km["bytes"] / (dom_us * 1e-6) / 1e9 if hbm_bound else km["flop"] / (dom_us * 1e-6) / 1e12
             peak = PEAK_HBM_GBS if hbm_bound else peak_tf
             out["roofline"] = {

@@ -216,6 +216,13 @@ int iwae_decode(iwae_handle h, const float* z, int32_t n, float* probs);
 int iwae_dataset_upload(iwae_handle h, const uint8_t* gray, int32_t n);
 int iwae_dataset_begin_epoch(iwae_handle h, uint32_t epoch, const int32_t* order /* NULL keeps the order */, int32_t n);
 int iwae_dataset_get_batch(iwae_handle h, int32_t start, int32_t B, float* x_out);
+/* Conditional models (cond_dim > 0; tasks/task05.py:296-322 trains on (x, y) batches of a labelled set): one class id per image of the
+ * uploaded set, each < cond_dim; kept resident next to the images.  iwae_train_step_dataset then feeds onehot(y) of the batch's images
+ * wherever a host-fed step takes iwae_set_condition's rows (the encoder's input concat(x, onehot(y)), the decoder's concat(z, onehot(y)),
+ * the prior network of tasks/task04.py) -- gathered by the same input kernel, no host traffic.  A new iwae_dataset_upload drops the labels.
+ * iwae_dataset_get_labels returns the batch's one-hot rows [B, cond_dim] for inspection. */
+int iwae_dataset_set_labels(iwae_handle h, const uint8_t* labels, int32_t n);
+int iwae_dataset_get_labels(iwae_handle h, int32_t start, int32_t B, float* y_out);
 int iwae_train_step_dataset(iwae_handle h, int32_t start, int32_t B, int32_t k, float beta, float lr, int32_t objective,
                             iwae_scalars* scalars);
 

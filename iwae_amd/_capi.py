@@ -74,6 +74,8 @@ SYMBOLS = {
     "iwae_dataset_upload": (C.c_int, [_P, _P, C.c_int32]),
     "iwae_dataset_begin_epoch": (C.c_int, [_P, C.c_uint32, _P, C.c_int32]),
     "iwae_dataset_get_batch": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "iwae_dataset_set_labels": (C.c_int, [_P, _P, C.c_int32]),
+    "iwae_dataset_get_labels": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "iwae_train_step_dataset": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.POINTER(Scalars)]),
     "iwae_set_condition": (C.c_int, [_P, _P, C.c_int32]),
     "iwae_enable_timing": (C.c_int, [_P, C.c_int32]),

@@ -302,7 +302,8 @@ void launch_wgradp_group(const WgradPGroup& g, hipStream_t st);
 void launch_wgradws_group(const WgradPGroup& g, hipStream_t st);     // shape-7 (specialised waves) gradients, non-row-weighted, in one launch
 void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, int Xp, int Bp, uint16_t* XP, hipStream_t st);
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st);
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st,
+                            const uint8_t* labels = nullptr, int C = 0, float* cond_out = nullptr);      // labels: class ids of the resident set (conditional models)
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks = 0);   // max_blocks > 0: grid-stride over at most that many blocks
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);

@@ -3744,13 +3744,20 @@ __global__ __launch_bounds__(256) void prep_rows_kernel(const float* x, const fl
 // Bernoulli(gray/255) with an integer threshold (bit-exactly reproducible on the host).  Keyed by
 // (epoch, image): one binarisation per image per epoch, as in the reference.  Same block shape and
 // output as prep_rows_kernel (P-layout) + optional float32 copy.
+// labels != null (conditional models, tasks/task05.py:296-322: the training set is (x, y) pairs): the image's class y rides along -- features
+// X .. X + C - 1 of the row are onehot(y) (the encoder's input concat(x, onehot(y)), task05.py:113), and cond_out [B][C] gets the same
+// one-hot row as float32 (what iwae_set_condition would have been handed for a host-fed batch).
 __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp,
-                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, float* xf) {
+                                                              int Bp, uint64_t seed, uint32_t epoch, uint16_t* XP, float* xf,
+                                                              const uint8_t* labels, int C, float* cond_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 64 + lane;
     const int nchunk = Xp / 8;
     if (b >= Bp) return;
     const int img = (b < B) ? order[start + b] : 0;
+    const int lab = (labels && b < B) ? (int)labels[img] : -1;
+    if (cond_out && blockIdx.y == 0 && threadIdx.x < 64 && b < B)
+        for (int j = 0; j < C; ++j) cond_out[(size_t)b * C + j] = (j == lab) ? 1.0f : 0.0f;
     for (int c = blockIdx.y * 4 + (threadIdx.x >> 6); c < nchunk; c += gridDim.y * 4) {
         const int t = c >> 2, qq = c & 3;
         float v[8];
@@ -3767,7 +3774,7 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
                     const uint32_t thr = (uint32_t)(((uint64_t)g * 16777216ull * 2ull + 255ull) / 510ull);   // floor(g*2^24/255 + 0.5)
                     bit = ((r[i] >> 8) < thr) ? 1.0f : 0.0f;
                     if (xf) xf[(size_t)b * X + f0 + i] = bit;
-                }
+                } else if (lab >= 0 && f0 + i == X + lab) bit = 1.0f;
                 v[4 * h + i] = bit;
             }
         }
@@ -4787,10 +4794,10 @@ void launch_prep_rows(const float* x, const float* cond, int B, int X, int C, in
     hipLaunchKernelGGL(prep_rows_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, x, cond, B, X, cond ? C : 0, Xp, Bp, XP);
 }
 void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start, int N, int B, int X, int Xp, int Bp, uint64_t seed,
-                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st) {
+                            uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st, const uint8_t* labels, int C, float* cond_out) {
     const int nchunk = Xp / 8;
     hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
-                       Bp, seed, epoch, XP, xf);
+                       Bp, seed, epoch, XP, xf, labels, labels ? C : 0, cond_out);
 }
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks) {
     const int nd4 = (D + 3) / 4;

@@ -191,6 +191,7 @@ struct iwae_model {
     DevBuf scratch;            // exports
     // resident dataset (iwae_dataset_*): uint8 grey levels [N][X] + the epoch's visiting order
     DevBuf ds_data, ds_order;
+    DevBuf ds_labels; bool ds_has_labels = false;   // class id per image of the resident set (iwae_dataset_set_labels; conditional models)
     int ds_N = 0;
     int wg_target16_1 = 64;    // same, for layers that are a single block wide (IWAE_WG16_1): the hidden layers' gradients -- with the specialised-wave kernel 64 row splits (12.8 MB of slabs each) beat 128 (0.259 -> 0.249-0.254 ms/step); 48 and 32 are slower again
     int eps_blocks = 512;      // blocks of the ahead-of-time noise draw (IWAE_EPS_BLOCKS; 0 = one block per 256 threads of work)
@@ -228,6 +229,7 @@ struct iwae_model {
     hipStream_t side2 = nullptr;       // the hidden layers' weight gradients beside the output layer's (IWAE_NO_SIDE2=1: behind it on `side`)
     hipEvent_t ev_s2 = nullptr;
     hipEvent_t ev_ar = nullptr;        // data-parallel step: recorded behind the encoder segment's all-reduce (dp_finish)
+    bool early_held = false;           // in-library data-parallel step: backward_impl left the decoder's slab reduction to dp_finish
     bool dp_concurrent = false;        // option dp_concurrent: the two all-reduces of a step may run at the same time (see dp_finish)
     bool use_side2 = true;
     int dec_bwd_nw = 8;         // option dec_bwd_nw: dec_bwd_kernel's shape (8 waves x 16 rows, round 4 | 4 waves x 32 rows)
@@ -833,7 +835,11 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     hipStream_t st = m->stream;
     const float* cond = nullptr;
     if (m->C > 0) {
-        if (from_ds) return fail(IWAE_ERR_ARG, "the conditional model takes (x, y) batches, not the resident dataset");
+        if (from_ds) {      // (x, y) from the resident set: the input kernel writes onehot(y) of the batch's images into m->cond (tasks/task05.py:296-322)
+            if (!m->ds_has_labels) return fail(IWAE_ERR_STATE, "conditional model on the resident dataset: call iwae_dataset_set_labels first");
+            CHK(ensure(m->cond, (size_t)B * m->C * 4, m->stream));
+            m->cond_n = B; m->cond_row0 = 0;
+        }
         if (m->cond_row0 + B > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these images first");
         cond = ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C;
     }
@@ -865,7 +871,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if (from_ds) {
         // main.py:117-120 on the device: gather the batch by the epoch's order and binarise it on the fly
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, Xinp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), nullptr, st, m->C > 0 ? ptr<uint8_t>(m->ds_labels) : nullptr, m->C, m->C > 0 ? ptr<float>(m->cond) : nullptr);
         m->ds_start = -1;
     } else {
         const float* xd = x;
@@ -1217,7 +1223,9 @@ float adam_alpha(iwae_model* m, float lr) {      // keras Adam: lr_t = lr * sqrt
 }
 
 // fused_lr >= 0: the optimizer update runs inside the slab reduction (single-GPU train step); < 0: gradient only
-int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool split = false) {
+// hold_early (the in-library data-parallel step): the decoder's slab reduction is NOT launched here but by dp_finish, behind the wait that
+// orders the step's two all-reduces (m->early_held)
+int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool split = false, bool hold_early = false) {
     if (!m->have_forward) return fail(IWAE_ERR_STATE, "backward without forward");
     if (m->fwd_was_f32) return fail(IWAE_ERR_STATE, "the last forward ran in float32 mode");
     const bool two = m->cfg.n_layers == 2;
@@ -1517,10 +1525,14 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
     // (ev_fork2, ev_blk), the last readers of those images.
     const bool defer2 = fuse && two && m->allow_defer && m->allow_defer2 && m->early_first2 > 0 && m->chain2_bwd && m->early_wout && m->use_side2 && !split;
     m->split_offset = m->nparam;
+    m->early_held = false;
     if (early) {
+        if (hold_early && split) m->early_held = true;
+        else {
         set_launch_stop_event(m->ev_dec);
         launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
                             m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
+        }
         m->dec_pending = true;
         if (split) m->split_offset = m->descs[m->dec1[0].sub[0]].offW;
     } else if (defer2) {       // (the side streams' layers are summed and updated there, further down: nothing to join)
@@ -1773,7 +1785,11 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const float* cond = nullptr;      // conditional models (tasks/task05.py, tasks/task04.py): y of these images
     if (m->C > 0) {
-        if (from_ds) return fail(IWAE_ERR_ARG, "the conditional model takes (x, y) batches, not the resident dataset");
+        if (from_ds) {      // (x, y) from the resident set: the input kernel writes onehot(y) of the batch's images into m->cond (tasks/task05.py:296-322)
+            if (!m->ds_has_labels) return fail(IWAE_ERR_STATE, "conditional model on the resident dataset: call iwae_dataset_set_labels first");
+            CHK(ensure(m->cond, (size_t)B * m->C * 4, m->stream));
+            m->cond_n = B; m->cond_row0 = 0;
+        }
         if (m->cond_row0 + B > m->cond_n) return fail(IWAE_ERR_STATE, "conditional model: call iwae_set_condition with y for these images first");
         cond = ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C;
     }
@@ -1802,7 +1818,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         CHK(ensure(m->xP, (size_t)Bp * m->Xinp * 2, st));
         CHK(ensure(m->xin, (size_t)B * X * 4, st));
         launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), m->ds_start, m->ds_N, B, X, m->Xinp, Bp, m->cfg.seed,
-                               m->ds_epoch, ptr<uint16_t>(m->xP), ptr<float>(m->xin), st);
+                               m->ds_epoch, ptr<uint16_t>(m->xP), ptr<float>(m->xin), st, m->C > 0 ? ptr<uint8_t>(m->ds_labels) : nullptr, m->C, m->C > 0 ? ptr<float>(m->cond) : nullptr);
         m->ds_start = -1;
         xd = ptr<float>(m->xin);
     } else if (!is_device_ptr(x, m->cfg.device)) { CHK(copy_in(m, m->xin, x, (size_t)B * X * 4)); xd = ptr<float>(m->xin); }
@@ -2058,6 +2074,13 @@ int dp_finish(iwae_model* m, float lr) {
     const float gs = 1.0f / (float)m->comm_world;
     if (m->descs_dirty) CHK(build_descs(m));
     const size_t n = m->nparam, off = m->split_offset;
+    if (m->early_held && !(off < n && m->dec_pending)) {      // (cannot happen on today's call paths -- nothing joins between backward_impl and here --; kept correct anyway: the held reduction runs now, joined)
+        launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+                            m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
+        HIPCHK(hipEventRecord(m->ev_join, m->tail));
+        HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+        m->early_held = false;
+    }
     if (off < n && m->dec_pending) {
         const int b0 = m->descs[m->dec1[0].sub[0]].block_begin;
         // Two communicators, one per stream.  Until an N > 1 run has shown that the two collectives may be co-resident, they are ORDERED
@@ -2067,9 +2090,19 @@ int dp_finish(iwae_model* m, float lr) {
         // stream's update and the next encoder forward then waited for the decoder's reduction, +22 us per step in the one-rank
         // rehearsal.)  Every rank enqueues them in this order.  Option dp_concurrent = 1 drops the wait.
         { ScopedTimer tm(m, T_AR_ENC); NCCLCHK(g_rccl.AllReduce(m->grad, m->grad, off, ncclFloat32, ncclSum, m->comm_main, m->stream)); }
-        if (!m->dp_concurrent) HIPCHK(hipEventRecord(m->ev_ar, m->stream));
+        // Round 5: the order costs (almost) nothing.  The event rides on the dispatch packet of the encoder's update (the kernel right behind
+        // the all-reduce: no record bubble on the main stream), and the tail stream waits for it IN FRONT of the decoder's slab reduction --
+        // which backward_impl left to this function (early_held) -- i.e. right behind the wait for the output layer's gradient it performs
+        // there anyway, ~15 us before the decoder's exchange instead of directly in front of it (a barrier packet costs its 6-10 us wherever
+        // its event stands; here it falls into the shadow of the hidden layers' gradients).  Measured in the one-rank rehearsal: see DESIGN.md 8.
+        if (!m->dp_concurrent) set_launch_stop_event(m->ev_ar);
         launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->stream, 0);
         if (!m->dp_concurrent) HIPCHK(hipStreamWaitEvent(m->tail, m->ev_ar, 0));
+        if (m->early_held) {
+            launch_reduce_grads(m->d_descs, (int)m->descs.size(), m->early_first, m->reduce_blocks - m->early_first, m->grad, m->param, m->mom,
+                                m->vel, 0.0f, m->adam_b1, m->adam_b2, m->adam_eps, 0, nullptr, 0, 0.f, nullptr, m->tail);
+            m->early_held = false;
+        }
         { ScopedTimer tm(m, T_AR_DEC, m->tail); NCCLCHK(g_rccl.AllReduce(m->grad + off, m->grad + off, n - off, ncclFloat32, ncclSum, m->comm_side, m->tail)); }
         set_launch_stop_event(m->ev_dec);           // join_side() now waits for the decoder's UPDATE, not just its gradient
         launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, gs, m->adam_b1, m->adam_b2, m->adam_eps, 1,
@@ -2516,7 +2549,7 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     }
     CHK(forward_impl(m, x, B, k, beta, eps, objective, true, want));
     if (m->comm_main) {                         // data-parallel step: exchange between gradient and update (iwae_comm_init)
-        CHK(backward_impl(m, objective, -1.0f, true));
+        CHK(backward_impl(m, objective, -1.0f, true, true));
         if (want) CHK(fetch_outputs(m, nullptr, want));
         CHK(dp_finish(m, lr));
     } else if (want) {
@@ -2762,6 +2795,23 @@ int iwae_dataset_upload(iwae_handle m, const uint8_t* gray, int32_t n) {
     HIPCHK(hipStreamSynchronize(m->stream));
     m->ds_N = n;
     m->ds_epoch = 0;
+    m->ds_has_labels = false;      // (a new set: its labels, if any, follow)
+    return IWAE_OK;
+}
+
+int iwae_dataset_set_labels(iwae_handle m, const uint8_t* labels, int32_t n) {
+    if (!m || !labels) return fail(IWAE_ERR_ARG, "dataset_set_labels: null argument");
+    if (m->C <= 0) return fail(IWAE_ERR_STATE, "dataset_set_labels: the model was created with cond_dim = 0");
+    if (m->ds_N <= 0) return fail(IWAE_ERR_STATE, "dataset_set_labels: no dataset uploaded");
+    if (n != m->ds_N) return fail(IWAE_ERR_ARG, "dataset_set_labels: one label per image of the uploaded set");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    if (!is_device_ptr(labels, m->cfg.device))
+        for (int i = 0; i < n; ++i)
+            if ((int)labels[i] >= m->C) return fail(IWAE_ERR_ARG, "dataset_set_labels: label " + std::to_string((int)labels[i]) + " at " + std::to_string(i) + " is not below cond_dim");
+    CHK(ensure(m->ds_labels, (size_t)n, m->stream));
+    HIPCHK(hipMemcpyAsync(m->ds_labels.p, labels, (size_t)n, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->ds_has_labels = true;
     return IWAE_OK;
 }
 
@@ -2782,12 +2832,29 @@ int iwae_dataset_get_batch(iwae_handle m, int32_t start, int32_t B, float* x_out
     if (!m || !x_out || m->ds_N <= 0 || start < 0 || B <= 0 || start + B > m->ds_N) return fail(IWAE_ERR_ARG, "dataset_get_batch: bad range");
     HIPCHK(hipSetDevice(m->cfg.device));
     const int Bp = round_up(B, 128);
-    CHK(ensure(m->xP, (size_t)Bp * m->Xp32 * 2, m->stream));
+    CHK(ensure(m->xP, (size_t)Bp * m->Xinp * 2, m->stream));
     CHK(ensure(m->scratch, (size_t)B * m->X * 4, m->stream));
-    launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), start, m->ds_N, B, m->X, m->Xp32, Bp, m->cfg.seed, m->ds_epoch,
+    launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), start, m->ds_N, B, m->X, m->Xinp, Bp, m->cfg.seed, m->ds_epoch,
                            ptr<uint16_t>(m->xP), ptr<float>(m->scratch), m->stream);
     HIPCHK(hipMemcpyAsync(x_out, m->scratch.p, (size_t)B * m->X * 4, hipMemcpyDefault, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
+    m->have_forward = false;
+    return IWAE_OK;
+}
+
+int iwae_dataset_get_labels(iwae_handle m, int32_t start, int32_t B, float* y_out) {
+    if (!m || !y_out || m->ds_N <= 0 || start < 0 || B <= 0 || start + B > m->ds_N) return fail(IWAE_ERR_ARG, "dataset_get_labels: bad range");
+    if (m->C <= 0 || !m->ds_has_labels) return fail(IWAE_ERR_STATE, "dataset_get_labels: no labels (iwae_dataset_set_labels on a conditional model)");
+    HIPCHK(hipSetDevice(m->cfg.device));
+    CHK(join_side(m));
+    const int Bp = round_up(B, 128);
+    CHK(ensure(m->xP, (size_t)Bp * m->Xinp * 2, m->stream));
+    CHK(ensure(m->cond, (size_t)B * m->C * 4, m->stream));
+    launch_gather_binarize(ptr<uint8_t>(m->ds_data), ptr<int32_t>(m->ds_order), start, m->ds_N, B, m->X, m->Xinp, Bp, m->cfg.seed, m->ds_epoch,
+                           ptr<uint16_t>(m->xP), nullptr, m->stream, ptr<uint8_t>(m->ds_labels), m->C, ptr<float>(m->cond));
+    HIPCHK(hipMemcpyAsync(y_out, m->cond.p, (size_t)B * m->C * 4, hipMemcpyDefault, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->cond_n = 0;                 // (the buffer no longer holds what iwae_set_condition put there)
     m->have_forward = false;
     return IWAE_OK;
 }

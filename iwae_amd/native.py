@@ -282,6 +282,16 @@ class NativeModel:
         check(self.lib.iwae_dataset_get_batch(self.h, int(start), int(B), out.ctypes.data))
         return out
 
+    def dataset_set_labels(self, labels):
+        """One class id (< cond_dim) per image of the uploaded set: conditional models on the resident dataset (tasks/task05.py:296-322)."""
+        y = np.ascontiguousarray(labels, dtype=np.uint8).ravel()
+        check(self.lib.iwae_dataset_set_labels(self.h, y.ctypes.data, y.size))
+
+    def dataset_get_labels(self, start, B):
+        out = np.empty((B, self.cond_dim), dtype=np.float32)
+        check(self.lib.iwae_dataset_get_labels(self.h, int(start), int(B), out.ctypes.data))
+        return out
+
     def train_step_dataset(self, start, B, k, beta=1.0, lr=1e-3, objective="iwae_elbo", scalars=True):
         s = Scalars()
         check(self.lib.iwae_train_step_dataset(self.h, int(start), int(B), int(k), float(beta), float(lr), OBJECTIVES[objective],

@@ -61,5 +61,17 @@ class CIWAE(IWAE):
         x_sample = (np.random.random_sample(probs.shape) < probs).astype(np.float32)
         return as_tensor(x_sample), as_tensor(probs)
 
-    def set_dataset(self, *a, **k):
-        raise NotImplementedError("the conditional model takes (x, y) batches; the resident-dataset path carries no labels")
+    def set_dataset(self, X_gray, y):
+        """The labelled training set resident in HBM (tasks/task05.py:296-322 feeds (x, y) batches from tf.data): grey levels as uint8 and one
+        class id per image; train_step_dataset then gathers, binarises and one-hot-encodes on the device (iwae_dataset_set_labels)."""
+        y = np.asarray(y).astype(np.int64).ravel()
+        if y.size != np.asarray(X_gray).shape[0]:
+            raise ValueError("set_dataset: one label per image")
+        if y.min() < 0 or y.max() >= N_CLASSES:
+            raise ValueError("set_dataset: labels must be in [0, %d)" % N_CLASSES)
+        super().set_dataset(X_gray)
+        self._net.dataset_set_labels(y.astype(np.uint8))
+
+    def train_step_dataset(self, start, batch_size, n_samples, beta, optimizer, objective="vae_elbo"):
+        res = super().train_step_dataset(start, batch_size, n_samples, beta, optimizer, objective=objective)
+        return {self._rename.get(k, k): v for k, v in res.items()}

@@ -35,6 +35,17 @@ def test_binding_table_covers_header(lib_built):
     _capi.load()
 
 
+def test_library_is_built_from_this_tree(lib_built):
+    """iwae_build_id() = the sha256 csrc/build.sh stamps over the library's sources (16 hex digits): the binary under test is the one these
+    sources build -- conftest.lib_built rebuilds on a mismatch -- and the id is readable from the file without loading it (bench.py quotes
+    profile artefacts only when they carry the same id)."""
+    from iwae_amd import _capi
+    want = _capi.source_build_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    assert _capi.file_build_id(lib_built) == want
+    assert _capi.library_build_id() == want
+
+
 def test_struct_layouts_match_header():
     from iwae_amd import _capi
     assert C.sizeof(_capi.Config) == 64          # uint32 + 7 int32 + uint64 + 6 int32; static_assert'ed in model.hip

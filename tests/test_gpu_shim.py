@@ -93,8 +93,16 @@ def test_task05_ciwae_api(gpu):
     xs, probs = model.sample(np.random.randn(6, 100).astype(np.float32), 7)
     assert xs.shape == (6, 784) and probs.shape == (6, 784) and 0.0 <= probs.min() and probs.max() <= 1.0
     assert set(np.unique(xs)) <= {0.0, 1.0}
-    with pytest.raises(NotImplementedError):
-        model.set_dataset(x)
+    # the labelled resident dataset (round 5; tasks/task05.py:296-322 feeds (x, y) batches): grey levels + class ids in HBM, a step per batch range
+    gray = (np.clip(x + 0.1 * np.random.rand(*x.shape), 0, 1) * 255).astype(np.uint8)
+    with pytest.raises(ValueError):
+        model.set_dataset(gray, y[:-1])
+    with pytest.raises(ValueError):
+        model.set_dataset(gray, y + 5)                                             # labels beyond the 10 classes
+    model.set_dataset(gray, y)
+    model.begin_epoch(1)
+    rd = model.train_step_dataset(0, 20, 5, 1.0, opt, objective="iwae_elbo")
+    assert np.isfinite(float(rd["iwae_elbo"])) and "lpxzy" in rd and "lqzxy" in rd
 
 
 def test_task04_ciwae_api(gpu):

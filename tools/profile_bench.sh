@@ -50,7 +50,12 @@ for k, v in sorted(summ.items(), key=lambda kv: -float(stat.get(kv[0], {"TotalDu
                  "hbm_bytes_per_launch": rd + wr, "correction": "read side x2 (gfx950 FETCH_SIZE), write side exact"})
     if per_step >= 0.5: step_bytes += round(per_step) * (rd + wr)
     lines.append("%-60s %6.2f %8.1f %8.1f %8.1f %6.2f" % (k[:60], per_step, us, rd / 1e6, wr / 1e6, (rd + wr) / 1e6 / max(us, 1e-9)))
-json.dump({"config": "$CONFIG", "command": "$CMD".replace("$R/", ""), "kernels": kern, "step_hbm_bytes": step_bytes}, open(out + "/kernel_traffic.json", "w"), indent=1)
+# the build the counters were taken on (bench.py quotes a table only on the build it was measured with): the id is read from the library file
+import re
+blob = open("$R/iwae_amd/libiwae_amd.so", "rb").read()
+m = re.search(rb"IWAE_BUILD_ID=([0-9a-f]+(?:-diag)?)", blob)
+build_id = m.group(1).decode() if m else "unknown"
+json.dump({"config": "$CONFIG", "build_id": build_id, "command": "$CMD".replace("$R/", ""), "kernels": kern, "step_hbm_bytes": step_bytes}, open(out + "/kernel_traffic.json", "w"), indent=1)
 with open(out + "/kernel_traffic_table.txt", "w") as f:
     f.write("%-60s %6s %8s %8s %8s %6s\n" % ("kernel", "n/step", "avg_us", "rdMB", "wrMB", "TB/s"))
     f.write("\n".join(lines) + "\n")
