@@ -171,7 +171,7 @@ class BaseIWAE:
         for k in ("vae_elbo", "iwae_elbo"):
             if k in res:
                 out[k] = float(res[k])
-        for k in ("lpxz", "lqzx", "lpz", "lpxz1", "lpz1z2", "lqz1x", "lqz2z1", "lpz2"):
+        for k in ("lpxz", "lqzx", "lpz", "lpxz1", "lpz1z2", "lqz1x", "lqz2z1", "lpz2", "lpxzy", "lqzxy", "lpzy"):      # (the last three: tasks/task05.py:248-253, task04.py)
             if k in res:
                 out[k] = float(np.mean(res[k]))
         return out

@@ -53,11 +53,28 @@ def _init_data_parallel():
 
 def main(argv=None):
     args = parser.parse_args(argv)
+    string = "main_{0}_{1}_{2}".format(args.objective, args.stochastic_layers, args.n_samples)
+
+    def make_model(**kw):
+        if args.stochastic_layers == 1:
+            return iwae1.IWAE(200, 100, **kw)
+        if args.objective == "vae_elbo_kl":
+            raise KeyError(args.objective)      # src/iwae2.py:154-173 has no such key
+        return iwae2.IWAE([200, 100], [100, 50], **kw)
+
+    return run_training(args, string, make_model, args.objective)
+
+
+def run_training(args, string, make_model, objective, labelled=False, report=None):
+    """The training protocol of the reference's drivers (main.py:38-184; tasks/task02.py:110-259, task04.py / task05.py:200-345 are the same loop
+    around another model class): seeds, the 8-stage learning-rate schedule, per-epoch dynamic binarisation + shuffle, a test evaluation every 200
+    steps, final weights, the k = 5000 test-set estimate.  make_model(**kw) builds the model (kw: device, output_bias, world_size, rank);
+    labelled: the model's steps take (x, y) (the conditional models); report: the scalar printed as "ELBO" (default: the objective)."""
     rank, world, dist = _init_data_parallel()
     if rank == 0:
         print(args)
-    string = "main_{0}_{1}_{2}".format(args.objective, args.stochastic_layers, args.n_samples)
     device = int(os.environ["LOCAL_RANK"]) if world > 1 else int(str(args.gpu).split(",")[0])
+    report = report or objective
 
     # ---- set random seeds (main.py:40-41)
     np.random.seed(123)
@@ -84,8 +101,9 @@ def main(argv=None):
         print("NOTE: no local mnist.npz found (set IWAE_MNIST_PATH); using synthetic MNIST-like data")
         Xtrain, Xtest = utils.synthetic_mnist()
         Ntrain, Ntest = Xtrain.shape[0], Xtest.shape[0]
+        lab = np.random.default_rng(123)
+        ytrain, ytest = lab.integers(0, 10, Ntrain), lab.integers(0, 10, Ntest)      # (stand-in classes for the conditional models)
 
-    objective = args.objective
     n_samples = args.n_samples
     batch_size = args.batch_size
     if batch_size % world:
@@ -100,13 +118,7 @@ def main(argv=None):
     log_w = None
 
     # ---- instantiate the model, optimizer and metrics (main.py:84-94)
-    bias = utils.get_bias(Xtrain)
-    if args.stochastic_layers == 1:
-        model = iwae1.IWAE(200, 100, device=device, output_bias=bias, world_size=world, rank=rank)
-    else:
-        if objective == "vae_elbo_kl":
-            raise KeyError(objective)      # src/iwae2.py:154-173 has no such key
-        model = iwae2.IWAE([200, 100], [100, 50], device=device, output_bias=bias, world_size=world, rank=rank)
+    model = make_model(device=device, output_bias=utils.get_bias(Xtrain), world_size=world, rank=rank)
 
     if world > 1:      # the gradient exchange happens inside the library from here on (RCCL over xGMI)
         from iwae_amd.parallel import init_in_library_exchange
@@ -123,7 +135,10 @@ def main(argv=None):
 
     # ---- the training set stays in HBM; shuffling order comes from the host RNG, binarisation and the
     #      batch gather run on the device (the reference re-binarises 47M pixels on the host every epoch)
-    model.set_dataset(Xtrain)
+    if labelled:
+        model.set_dataset(Xtrain, ytrain)      # (x, y) pairs: tasks/task05.py:296-322
+    else:
+        model.set_dataset(Xtrain)
 
     start = time.time()
     for epoch in range(epochs):
@@ -151,7 +166,7 @@ def main(argv=None):
                 res = model.train_step_dataset(lo, nb, n_samples, beta, optimizer, objective=objective)
 
             if step % 200 == 0 and rank == 0:
-                test_res = model.val_step(Xtest, n_samples, beta)
+                test_res = model.val_step(Xtest, ytest, n_samples, beta) if labelled else model.val_step(Xtest, n_samples, beta)
                 row = {"split": "train", **model.write_to_tensorboard(res, step)}
                 row_t = {"split": "test", **model.write_to_tensorboard(test_res, step)}
                 if log_w is None:
@@ -163,7 +178,7 @@ def main(argv=None):
                 took = time.time() - start
                 start = time.time()
                 print("epoch {0}/{1}, step {2}/{3}, train ELBO: {4:.2f}, val ELBO: {5:.2f}, time: {6:.2f}"
-                      .format(epoch, epochs, step, total_steps, res[objective].numpy(), test_res[objective], took))
+                      .format(epoch, epochs, step, total_steps, res[report].numpy(), test_res[report], took))
 
     # ---- save final weights (main.py:165)
     if rank == 0:
@@ -171,16 +186,17 @@ def main(argv=None):
 
     # ---- test-set llh estimate using 5000 samples (main.py:170-184); data-parallel: every rank takes a slice of the test set
     L = 5000
+    llh_of = (lambda X, y: model.eval_llh(X, y, L)) if labelled else (lambda X, y: model.eval_llh(X, L))
     if world > 1:
         import torch
-        mine = Xtest[rank::world]
+        mine, ymine = Xtest[rank::world], ytest[rank::world] if labelled else None
         model._net.set_step(1 << 20, 0)
-        part = torch.tensor([model.eval_llh(mine, L) * mine.shape[0], float(mine.shape[0])], dtype=torch.float64)
+        part = torch.tensor([llh_of(mine, ymine) * mine.shape[0], float(mine.shape[0])], dtype=torch.float64)
         dist.all_reduce(part)
         test_set_llh = float(part[0] / part[1])
         dist.destroy_process_group()
     else:
-        test_set_llh = model.eval_llh(Xtest, L)
+        test_set_llh = llh_of(Xtest, ytest if labelled else None)
     if rank == 0:
         print("Test-set {0} sample log likelihood estimate: {1:.4f}".format(L, test_set_llh))
     return test_set_llh

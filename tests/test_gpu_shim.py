@@ -144,3 +144,33 @@ def test_main_runs_one_epoch(gpu, monkeypatch, capsys):
     llh = main.main(["--epochs", "1", "--batch_size", "100", "--n_samples", "5", "--objective", "iwae_elbo"])
     out = capsys.readouterr().out
     assert "train ELBO" in out and "Test-set 5000 sample log likelihood estimate" in out and np.isfinite(llh)
+
+
+@pytest.mark.parametrize("task,argv", [("task02", ["--epochs", "1", "--batch_size", "100", "--n_samples", "5"]),
+                                       ("task05", ["--epochs", "1", "--batch_size", "100", "--n_samples", "5", "--objective", "iwae_elbo"]),
+                                       ("task04", ["--epochs", "1", "--batch_size", "100", "--n_samples", "5", "--objective", "vae_elbo"])])
+def test_task_drivers_run_one_epoch(gpu, monkeypatch, capsys, task, argv):
+    """tasks/task02.py (:110-259: DReG), tasks/task05.py (:200-345: labelled (x, y) batches) and tasks/task04.py (learned conditional prior) of the
+    reference as drivers here: their own flags, main.py's loop, the labelled set resident in HBM -- end to end on a tiny synthetic set."""
+    import importlib
+    import os
+    import sys
+    from iwae_amd import utils, iwae1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.syspath_prepend(os.path.join(root, "tasks"))
+    for name in ("_common", "task05", task):
+        sys.modules.pop(name, None)
+    mod = importlib.import_module(task)
+    monkeypatch.setattr(utils, "load_mnist", lambda path=None: None)
+    monkeypatch.setattr(utils, "synthetic_mnist", lambda: (np.clip(np.tile(utils.synthetic_pixel_means(), (400, 1)), 0, 1),
+                                                            np.clip(np.tile(utils.synthetic_pixel_means(), (60, 1)), 0, 1)))
+    if task == "task02":
+        monkeypatch.setattr(iwae1.IWAE, "eval_llh", lambda self, x, L, chunk=0: self._net.eval_llh(x[:8], 100))
+    else:
+        from iwae_amd import task05 as t5
+        monkeypatch.setattr(t5.CIWAE, "eval_llh", lambda self, x, y, L, chunk=0: (self._net.set_condition(t5.one_hot(y[:8])), self._net.eval_llh(x[:8], 100))[1])
+    llh = mod.main(argv)
+    out = capsys.readouterr().out
+    assert "train ELBO" in out and "Test-set 5000 sample log likelihood estimate" in out and np.isfinite(llh)
+    for name in ("_common", "task05", task):
+        sys.modules.pop(name, None)

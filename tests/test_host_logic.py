@@ -88,6 +88,23 @@ def test_utils_and_optimizer_shim():
         Adam(1e-3, beta_1=1.0)
 
 
+def test_task_driver_flags_identical_to_reference():
+    """tasks/task02.py:15-22 and tasks/task04.py / task05.py:34-43 of the reference: the drivers under tasks/ parse the same flags with the same defaults."""
+    sys.path.insert(0, os.path.join(ROOT, "tasks"))
+    try:
+        import importlib
+        common = importlib.import_module("_common")
+        a = common.parser_task02().parse_args([])
+        assert (a.n_samples, a.batch_size, a.epochs, a.gpu) == (5, 20, -1, "0")
+        with pytest.raises(SystemExit):
+            common.parser_task02().parse_args(["--objective", "iwae_elbo"])      # task02's script has no such flag
+        c = common.parser_conditional().parse_args(["--objective", "vae_elbo_kl", "--stochastic_layers", "2"])
+        assert (c.stochastic_layers, c.n_samples, c.batch_size, c.epochs, c.objective, c.gpu) == (2, 5, 20, -1, "vae_elbo_kl", "0")
+    finally:
+        sys.path.remove(os.path.join(ROOT, "tasks"))
+        sys.modules.pop("_common", None)
+
+
 def test_main_cli_flags_identical_to_reference():
     sys.argv = ["main.py"]
     import importlib
