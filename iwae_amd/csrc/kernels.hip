@@ -159,6 +159,10 @@ __device__ __forceinline__ void eps4(const EpsSrc& e, int b, int s, int row, int
 // One 32-feature step t of z = mu + sigma*eps for the lane's (row, quad): the lane's 8 features of P-layout chunk 4t+q (features
 // 32t+4q..+3 and 32t+16+4q..+3) and their contributions to the row's log-densities (sample_kernel; block_fwd_kernel's sampling mode)
 __device__ __forceinline__ void sample_step(const SampleArgs& a, int t, int q, int rowc, int b, int s, const float* hd, float z8[8], float& lp, float& lq, float& lq2) {
+    // Round 5: the density arithmetic in the decoder kernel's new form -- a density scored at its own sample has (z - mu)/sigma = eps, the
+    // chunks that straddle or lie beyond the latent width take a wave-uniform masked path instead of a branch per element, and the
+    // log-scales are summed as log2 of pair products (one v_log per 2 elements; __logf was ~12 instructions per element).  The k = 5000
+    // evaluator's sampling pass is this function behind Philox + Box-Muller: 107 us per 520 k rows before.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int f0 = 32 * t + 16 * h + 4 * q;
@@ -174,29 +178,47 @@ __device__ __forceinline__ void sample_step(const SampleArgs& a, int t, int q, i
                 ps4 = *(const float4*)(a.prior_head + (size_t)b * a.ldH + a.Dp + f0);
             }
         }
-        const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
-        const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
+        float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
+        float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, psv[4] = {ps4.x, ps4.y, ps4.z, ps4.w};
+        float cnt = 4.0f;                                     // valid features of this chunk
+        const bool ragged = 32 * t + 16 * h + 16 > a.D;      // wave-uniform where t is (sample_kernel, block_fwd_kernel's sampling mode)
+        if (ragged) {
+            cnt = (float)max(0, min(4, a.D - f0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = f0 + i < a.D;
+                e[i] = in ? e[i] : 0.0f; muv[i] = in ? muv[i] : 0.0f; sgv[i] = in ? sgv[i] : 1.0f;
+                pmv[i] = in ? pmv[i] : 0.0f; psv[i] = in ? psv[i] : 1.0f;
+            }
+        }
+        float sz = 0.0f, se = 0.0f, su = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float z = 0.0f;
-            if (a.cond && f0 + i >= a.D && f0 + i < a.D + a.C) z = a.cond[(size_t)b * a.C + (f0 + i - a.D)];   // decoder input = concat(z, y)
-            if (f0 + i < a.D) {
-                const float mu = muv[i], sg = sgv[i];
-                z = mu + sg * e[i];                                  // iwae1.py:59
-                if (a.prior_head) {
-                    const float up = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
-                    lp += -0.5f * up * up - 0.5f * LOG2PI_F - __logf(psv[i]);   // task04.py:130
-                } else {
-                    lp += -0.5f * z * z - 0.5f * LOG2PI_F;           // iwae1.py:107
-                }
-                const float u = (z - mu) * __builtin_amdgcn_rcpf(sg);
-                lq += -0.5f * u * u - 0.5f * LOG2PI_F - __logf(sg);  // iwae1.py:109
-                if (a.lq_dreg) {                                     // tasks/task02.py:63-65
-                    const float s2 = sg + 1e-6f, u2 = (z - mu) * __builtin_amdgcn_rcpf(s2);
-                    lq2 += -0.5f * u2 * u2 - 0.5f * LOG2PI_F - __logf(s2);
-                }
+            const float z = muv[i] + sgv[i] * e[i];                  // iwae1.py:59 (pad features: exactly 0)
+            se = fmaf(e[i], e[i], se);                               // iwae1.py:109: (z - mu)/sigma = eps
+            if (a.prior_head) {
+                const float up = (z - pmv[i]) * __builtin_amdgcn_rcpf(psv[i]);
+                sz = fmaf(up, up, sz);                               // task04.py:130
+            } else sz = fmaf(z, z, sz);                              // iwae1.py:107
+            if (a.lq_dreg) {                                         // tasks/task02.py:63-65: scale sigma + 1e-6
+                const float u2 = (sgv[i] * __builtin_amdgcn_rcpf(sgv[i] + 1e-6f)) * e[i];
+                su = fmaf(u2, u2, su);
             }
             z8[4 * h + i] = z;
+        }
+        if (a.cond && ragged) {      // decoder input = concat(z, y): the condition sits in the pad features behind D
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (f0 + i >= a.D && f0 + i < a.D + a.C) z8[4 * h + i] = a.cond[(size_t)b * a.C + (f0 + i - a.D)];
+        }
+        const float c0 = -0.5f * LOG2PI_F * cnt;
+        lp += fmaf(-0.5f, sz, c0) - (a.prior_head ? LN2_F * (log2_raw(psv[0] * psv[1]) + log2_raw(psv[2] * psv[3])) : 0.0f);
+        lq += fmaf(-0.5f, se, c0) - LN2_F * (log2_raw(sgv[0] * sgv[1]) + log2_raw(sgv[2] * sgv[3]));
+        if (a.lq_dreg) {
+            const float s20 = sgv[0] + 1e-6f, s21 = sgv[1] + 1e-6f, s22 = sgv[2] + 1e-6f, s23 = sgv[3] + 1e-6f;
+            const float m0 = ragged && !(f0 + 0 < a.D) ? 1.0f : s20, m1 = ragged && !(f0 + 1 < a.D) ? 1.0f : s21;
+            const float m2 = ragged && !(f0 + 2 < a.D) ? 1.0f : s22, m3 = ragged && !(f0 + 3 < a.D) ? 1.0f : s23;
+            lq2 += fmaf(-0.5f, su, c0) - LN2_F * (log2_raw(m0 * m1) + log2_raw(m2 * m3));
         }
     }
 }
@@ -1907,40 +1929,55 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
     auto quad_sum = [&](float v) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
     // ---- z1 = mu1 + sigma1 * eps1 of this row (iwae2.py:61) and log q(z1|x) (:123): sample_kernel's arithmetic, without its launch and
     // without reading z1 back -- the fragments are this kernel's first operand; the rows are kept for the decoder and the weight gradient
+    // (round 5: the three sampling / density sections of this kernel in the decoder kernel's new form -- every load of a section requested before
+    // the first use instead of a load-and-wait per 4 elements, no per-element branches (the chunks that straddle or lie beyond the latent width
+    // take a wave-uniform masked path), (z - mu)/sigma = eps for a density scored at its own sample, and sum log sigma as log2 of pair
+    // products: one v_log per 2 elements instead of a 12-instruction __logf per element.  Counters before: 3 578 vector instructions per wave
+    // for 208 MFMAs, profiles/r05_c2_*.)
+    auto log2_pairs = [&](const float (&sv)[4]) { return log2_raw(sv[0] * sv[1]) + log2_raw(sv[2] * sv[3]); };
     uint4 zf[KT0];
     {
         const float* hz = a.head1 + (size_t)b * a.ldH1;
-        float lq = 0.0f;
+        float e[2 * KT0][4];
+        float4 mu4[2 * KT0], sg4[2 * KT0];
+        auto request = [&](int c) {
+            const int f0 = 32 * (c >> 1) + 16 * (c & 1) + 4 * q;
+            e[c][0] = e[c][1] = e[c][2] = e[c][3] = 0.0f;
+            if (f0 < a.D0) eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e[c]);
+            mu4[c] = *(const float4*)(hz + f0); sg4[c] = *(const float4*)(hz + 32 * KT0 + f0);      // (f0 < 32 KT0: inside the padded head row)
+        };
+        // (two k-steps = four chunks = twelve 16-byte loads at a time: all eight chunks at once are 96 registers of loads in flight and spilled)
+#pragma unroll
+        for (int c = 0; c < 4 && c < 2 * KT0; ++c) request(c);
+        float se = 0.0f, sl = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KT0; ++ks) {
+            if (ks == 2) {
+#pragma unroll
+                for (int c = 4; c < 2 * KT0; ++c) request(c);
+            }
             float z8[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int f0 = 32 * ks + 16 * h + 4 * q;
-                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                float4 mu4 = make_float4(0.f, 0.f, 0.f, 0.f), sg4 = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (f0 < a.D0) {
-                    eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e);
-                    mu4 = *(const float4*)(hz + f0); sg4 = *(const float4*)(hz + 32 * KT0 + f0);
+                const int c = 2 * ks + h, f0 = 32 * ks + 16 * h + 4 * q;
+                float muv[4] = {mu4[c].x, mu4[c].y, mu4[c].z, mu4[c].w}, sgv[4] = {sg4[c].x, sg4[c].y, sg4[c].z, sg4[c].w};
+                if (32 * ks + 16 * h + 16 > a.D0) {      // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const bool in = f0 + i < a.D0; e[c][i] = in ? e[c][i] : 0.0f; muv[i] = in ? muv[i] : 0.0f; sgv[i] = in ? sgv[i] : 1.0f; }
                 }
-                const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, sgv[4] = {sg4.x, sg4.y, sg4.z, sg4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float z = 0.0f;
-                    if (f0 + i < a.D0) {
-                        z = muv[i] + sgv[i] * e[i];
-                        const float uu = (z - muv[i]) * __builtin_amdgcn_rcpf(sgv[i]);
-                        lq += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sgv[i]);
-                    }
-                    z8[4 * h + i] = z;
+                    z8[4 * h + i] = fmaf(sgv[i], e[c][i], muv[i]);              // iwae2.py:61
+                    se = fmaf(e[c][i], e[c][i], se);
                 }
+                sl += log2_pairs(sgv);
             }
             const uint4 frag = make_uint4(pack2(z8[0], z8[1]), pack2(z8[2], z8[3]), pack2(z8[4], z8[5]), pack2(z8[6], z8[7]));
-            zf[ks] = valid ? frag : make_uint4(0, 0, 0, 0);
+            zf[ks] = frag;      // (a data row is a COLUMN of every product here: rows beyond M carry a clamped row's finite values, nothing of them is stored)
             if (valid) *(uint4*)(a.Z1P + (size_t)row * (32 * KT0) + ks * 32 + q * 8) = frag;
         }
-        lq = quad_sum(lq);
-        if (q == 0 && valid) a.lqz1x[row] = lq;
+        se = quad_sum(se); sl = quad_sum(sl);
+        if (q == 0 && valid) a.lqz1x[row] = -0.5f * se - 0.5f * LOG2PI_F * (float)a.D0 - LN2_F * sl;      // iwae2.py:123
     }
     int u = 0;
     // one unit: the 4 accumulator tiles (64 out-features x 16 rows) of a weight group, started from the group's bias block
@@ -1975,7 +2012,7 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = tanh_fast(acc[2 * p2 + (j >> 2)][j & 3]);
                     const uint4 frag = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-                    bout[kso] = valid ? frag : make_uint4(0, 0, 0, 0);
+                    bout[kso] = frag;
                     if (valid && Hout) *(uint4*)(Hout + (size_t)row * (32 * KTH) + kso * 32 + q * 8) = frag;
                 }
             }
@@ -1993,47 +2030,53 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
         f32x4 mu2[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) unit_mfma(std::integral_constant<int, KTH>{}, h2f, mu2[g]);
-        float lp = 0.0f, lq = 0.0f;
+        float sz = 0.0f, se = 0.0f, sl = 0.0f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
+            float e[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {      // the group's draws, requested in front of its sigma unit
+                const int f0 = 64 * g + 16 * t + 4 * q;
+                e[t][0] = e[t][1] = e[t][2] = e[t][3] = 0.0f;
+                if (f0 < a.D1) eps4(a.eps2, b, sidx, rowc, f0 >> 2, a.D1, e[t]);
+            }
             f32x4 sa[4];
             unit_mfma(std::integral_constant<int, KTH>{}, h2f, sa);
             float zt[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int f0 = 64 * g + 16 * t + 4 * q;
-                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (f0 < a.D1) eps4(a.eps2, b, sidx, rowc, f0 >> 2, a.D1, e);
-                float sg4[4];
+                float sgv[4], muv[4] = {mu2[g][t][0], mu2[g][t][1], mu2[g][t][2], mu2[g][t][3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sgv[i] = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;          // iwae2.py:43 (exp activation), :45 (+ 1e-6)
+                if (valid && a.EHEAD) {
+                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + f0) = make_float4(muv[0], muv[1], muv[2], muv[3]);
+                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + 32 * KT1 + f0) = make_float4(sgv[0], sgv[1], sgv[2], sgv[3]);
+                }
+                if (64 * g + 16 * t + 16 > a.D1) {      // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const bool in = f0 + i < a.D1; e[t][i] = in ? e[t][i] : 0.0f; muv[i] = in ? muv[i] : 0.0f; sgv[i] = in ? sgv[i] : 1.0f; }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float sg = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;          // iwae2.py:43 (exp activation), :45 (+ 1e-6)
-                    sg4[i] = sg;
-                    float z = 0.0f;
-                    if (f0 + i < a.D1) {
-                        const float mu = mu2[g][t][i];
-                        z = fmaf(sg, e[i], mu);
-                        lp += -0.5f * z * z - 0.5f * LOG2PI_F;                      // log p(z2), iwae2.py:119
-                        const float uu = (z - mu) * __builtin_amdgcn_rcpf(sg);
-                        lq += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sg);       // log q(z2|z1), iwae2.py:124
-                    }
+                    const float z = fmaf(sgv[i], e[t][i], muv[i]);      // iwae2.py:65
+                    sz = fmaf(z, z, sz);                                // log p(z2), iwae2.py:119
+                    se = fmaf(e[t][i], e[t][i], se);                    // log q(z2|z1), iwae2.py:124: (z2 - mu2)/sigma2 = eps2
                     zt[t][i] = z;
                 }
-                if (valid && a.EHEAD) {
-                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + f0) = make_float4(mu2[g][t][0], mu2[g][t][1], mu2[g][t][2], mu2[g][t][3]);
-                    *(float4*)(a.EHEAD + (size_t)row * (64 * KT1) + 32 * KT1 + f0) = make_float4(sg4[0], sg4[1], sg4[2], sg4[3]);
-                }
+                sl += log2_pairs(sgv);
             }
 #pragma unroll
             for (int p2 = 0; p2 < 2; ++p2) {
                 const uint4 frag = make_uint4(pack2(zt[2 * p2][0], zt[2 * p2][1]), pack2(zt[2 * p2][2], zt[2 * p2][3]),
                                               pack2(zt[2 * p2 + 1][0], zt[2 * p2 + 1][1]), pack2(zt[2 * p2 + 1][2], zt[2 * p2 + 1][3]));
-                z2f[2 * g + p2] = valid ? frag : make_uint4(0, 0, 0, 0);
+                z2f[2 * g + p2] = frag;
                 if (valid && a.Z2P) *(uint4*)(a.Z2P + (size_t)row * (32 * KT1) + (2 * g + p2) * 32 + q * 8) = frag;
             }
         }
-        lp = quad_sum(lp); lq = quad_sum(lq);
-        if (q == 0 && valid) { a.lpz2[row] = lp; a.lqz2z1[row] = lq; }
+        sz = quad_sum(sz); se = quad_sum(se); sl = quad_sum(sl);
+        const float cD = 0.5f * LOG2PI_F * (float)a.D1;
+        if (q == 0 && valid) { a.lpz2[row] = -0.5f * sz - cD; a.lqz2z1[row] = -0.5f * se - cD - LN2_F * sl; }
     }
     // ---- p(z1|z2): decode_z2_to_z1 (iwae2.py:90) and log p(z1|z2) (iwae2.py:122), z1 = mu1 + sigma1 * eps1 in float32
     uint4 g1f[KTH], g2f[KTH];
@@ -2044,41 +2087,56 @@ __global__ __launch_bounds__(512, 4) void chain2_fwd_kernel(Chain2FwdArgs a) {
         f32x4 mup[NG][4];
 #pragma unroll
         for (int g = 0; g < NG; ++g) unit_mfma(std::integral_constant<int, KTH>{}, g2f, mup[g]);
-        float lp = 0.0f;
+        float su = 0.0f, sl = 0.0f;
         const float* hz = a.head1 + (size_t)b * a.ldH1;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            f32x4 sa[4];
-            unit_mfma(std::integral_constant<int, KTH>{}, g2f, sa);
+            // z1 = mu1 + sigma1 * eps1 once more, in float32 (its bf16 fragments went into the first layer): the group's draws and the image's head,
+            // requested in front of the sigma unit
+            float e[4][4];
+            float4 zm[4], zs[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int f0 = 64 * g + 16 * t + 4 * q;
-                float e[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                float4 zm = make_float4(0.f, 0.f, 0.f, 0.f), zs = zm;
-                if (f0 < a.D0) {
-                    eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e);
-                    zm = *(const float4*)(hz + f0); zs = *(const float4*)(hz + 32 * KT0 + f0);
+                e[t][0] = e[t][1] = e[t][2] = e[t][3] = 0.0f;
+                if (f0 < a.D0) eps4(a.eps1, b, sidx, rowc, f0 >> 2, a.D0, e[t]);
+            }
+            f32x4 sa[4];
+            unit_mfma(std::integral_constant<int, KTH>{}, g2f, sa);
+            // (the head behind the unit, two tiles at a time: with the draws it would be 48 registers held across the MFMAs, beside the mu accumulators)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f0 = 64 * g + 16 * t + 4 * q;
+                if ((t & 1) == 0) {
+#pragma unroll
+                    for (int tt = t; tt < t + 2; ++tt) {
+                        const int ff = 64 * g + 16 * tt + 4 * q;
+                        zm[tt] = *(const float4*)(hz + ff); zs[tt] = *(const float4*)(hz + 32 * KT0 + ff);
+                    }
                 }
-                const float zmv[4] = {zm.x, zm.y, zm.z, zm.w}, zsv[4] = {zs.x, zs.y, zs.z, zs.w};
-                float sg4[4];
+                const float zmv[4] = {zm[t].x, zm[t].y, zm[t].z, zm[t].w}, zsv[4] = {zs[t].x, zs[t].y, zs[t].z, zs[t].w};
+                float sgv[4], uv[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float sg = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;
-                    sg4[i] = sg;
-                    if (f0 + i < a.D0) {
-                        const float z = zmv[i] + zsv[i] * e[i];
-                        const float uu = (z - mup[g][t][i]) * __builtin_amdgcn_rcpf(sg);
-                        lp += -0.5f * uu * uu - 0.5f * LOG2PI_F - __logf(sg);
-                    }
+                    sgv[i] = exp2_raw(sa[t][i] * LOG2E_F) + 1e-6f;
+                    const float z = fmaf(zsv[i], e[t][i], zmv[i]);
+                    uv[i] = (z - mup[g][t][i]) * __builtin_amdgcn_rcpf(sgv[i]);      // iwae2.py:122
                 }
                 if (valid && a.DHEAD) {
                     *(float4*)(a.DHEAD + (size_t)row * (64 * KT0) + f0) = make_float4(mup[g][t][0], mup[g][t][1], mup[g][t][2], mup[g][t][3]);
-                    *(float4*)(a.DHEAD + (size_t)row * (64 * KT0) + 32 * KT0 + f0) = make_float4(sg4[0], sg4[1], sg4[2], sg4[3]);
+                    *(float4*)(a.DHEAD + (size_t)row * (64 * KT0) + 32 * KT0 + f0) = make_float4(sgv[0], sgv[1], sgv[2], sgv[3]);
                 }
+                if (64 * g + 16 * t + 16 > a.D0) {      // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const bool in = f0 + i < a.D0; uv[i] = in ? uv[i] : 0.0f; sgv[i] = in ? sgv[i] : 1.0f; }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) su = fmaf(uv[i], uv[i], su);
+                sl += log2_pairs(sgv);
             }
         }
-        lp = quad_sum(lp);
-        if (q == 0 && valid) a.lpz1z2[row] = lp;
+        su = quad_sum(su); sl = quad_sum(sl);
+        if (q == 0 && valid) a.lpz1z2[row] = -0.5f * su - 0.5f * LOG2PI_F * (float)a.D0 - LN2_F * sl;
     }
 }
 
