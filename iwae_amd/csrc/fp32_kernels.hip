@@ -625,6 +625,35 @@ __global__ __launch_bounds__(256) void reduce_slabs_f32_kernel(const float* slab
     if (g == 0 && i < n) out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// Round 5: every slab sum of a float32 step in ONE launch.  A step has 14 row-split weight / bias gradients; as 14 launches of
+// reduce_slabs_f32_kernel (5.7 us each, latency) they were 76 us of the 1.52 ms step.  The gradients now keep their slabs (each in its own
+// region of the slab buffer) and the host queues a job per tensor; this kernel walks the concatenated block ranges.  Same block shape, same
+// order of additions per element as reduce_slabs_f32_kernel: bitwise the same sums.
+__global__ __launch_bounds__(256) void reduce_slabs_multi_f32_kernel(ReduceSlabsJobs jobs) {
+    __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].block_begin) ++j;
+    const ReduceSlabsJob J = jobs.job[j];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)((int)blockIdx.x - J.block_begin) * 64 + c;
+    float s = 0.0f;
+    if (i < J.n) {
+        const float* p = J.slabs + i;
+        int z = g;
+        for (; z + 28 < J.nsplit; z += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + 4 * u) * J.stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < J.nsplit; z += 4) s += p[(size_t)z * J.stride];
+    }
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && i < J.n) J.out[i] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // log p(x|z) per data row from float32 logits: sum_j x_j l_j - softplus(l_j) (iwae1.py:111); one wave per row (image-major rows: b = row / k)
 __global__ __launch_bounds__(256) void bern_f32_kernel(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -737,6 +766,11 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, stride, nsplit, n, out);
+}
+void launch_reduce_slabs_multi_f32(ReduceSlabsJobs& jobs, hipStream_t st) {
+    int blocks = 0;
+    for (int j = 0; j < jobs.n; ++j) { jobs.job[j].block_begin = blocks; blocks += (int)((jobs.job[j].n + 63) / 64); }
+    if (blocks > 0) hipLaunchKernelGGL(reduce_slabs_multi_f32_kernel, dim3(blocks), dim3(256), 0, st, jobs);
 }
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st) {
     hipLaunchKernelGGL(bern_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, ld, x, X, M, k, lpxz);

@@ -153,6 +153,7 @@ struct BlockBwdArgs {                 // block_bwd_kernel: the dX chain of a Bas
     // for the head's weight gradient.  One dependent launch less per step.
     int lat_on;
     LatentBwdArgs lat;
+    int rows_per_wg;                  // 16, or 4 with lat_on (many samples per image: four waves per image, four times the workgroups)
 };
 bool block_bwd_ok(const BlockBwdArgs& a);
 void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st);
@@ -371,6 +372,11 @@ long gemm_f32_tiles(int M, int N);                       // output tiles of the 
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
+// every slab sum of a float32 step in one launch (round 5): out[i] = sum over the job's slabs, i < n; block_begin is filled by the launcher
+#define REDUCE_SLABS_MAX_JOBS 40
+struct ReduceSlabsJob { const float* slabs; size_t stride; size_t n; float* out; int nsplit; int block_begin; };
+struct ReduceSlabsJobs { ReduceSlabsJob job[REDUCE_SLABS_MAX_JOBS]; int n; };
+void launch_reduce_slabs_multi_f32(ReduceSlabsJobs& jobs, hipStream_t st);
 void launch_bern_f32(const float* logits, size_t ld, const float* x, int X, int M, int k, float* lpxz, hipStream_t st);
 void launch_dl_f32(float* logits, size_t ld, const float* x, int X, int M, int k, const float* gx, hipStream_t st);
 void launch_sigmoid_f32(float* v, size_t n, hipStream_t st);

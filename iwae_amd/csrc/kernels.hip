@@ -853,15 +853,29 @@ __global__ __launch_bounds__(1024, ((AD > 6 || OUT) ? 2 : 5)) void block_fwd_ker
 // second layer's are requested before the first product starts), the data operands sit in LDS as 1 KiB k-step blocks.
 // As two dense_kernel<EPI_DX> launches this was 6.5 + 6.4 us alone and 20 - 35 us beside the weight gradients.
 // ---------------------------------------------------------------------------------
+// the per-image transforms behind the sums over the samples (latent_bwd_kernel's last step): the KL terms of vae_elbo_kl, d sigma -> d pre-activation of the exp
+__device__ __forceinline__ void latent_finish(const LatentBwdArgs& a, const int f0, const float (&mu)[4], const float (&sgm)[4], float (&dmu)[4], float (&dsg)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (f0 + i < a.D) {
+            dmu[i] += a.kmu * mu[i];
+            dsg[i] += a.ksig * (sgm[i] - 1.0f / sgm[i]);
+            dsg[i] *= (sgm[i] - 1e-6f);
+        } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+    }
+}
 // latent_bwd_kernel's sums for ONE image by ONE wave (block_bwd_kernel with lat_on: the image encoder's backward on few rows): lanes = 32 feature
 // quads x 2 sample groups, four samples' loads in flight per lane; on return lanes < 32 hold d mu and d sigma -> pre-activation of the exp
 // for features 4 lane .. 4 lane + 3 (zeros beyond D).  The same arithmetic as latent_bwd_kernel, another summation order; no
 // conditional prior (the caller keeps the separate kernel for that).
-__device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const int b, const int lane, float (&dmu)[4], float (&dsg)[4]) {
+// part / nparts: this wave's share of the image's samples (s = sg + 2 part + 2 nparts j); FINISH: the whole image in this wave (nparts = 1):
+// the cross-half add and the final transforms follow here, else the caller combines the parts' raw sums (lanes < 32 after the shuffle) first
+template <bool FINISH>
+__device__ __forceinline__ void latent_image_part(const LatentBwdArgs& a, const int b, const int lane, const int part, const int nparts, float (&dmu)[4], float (&dsg)[4],
+                                                  float (&mu)[4], float (&sgm)[4]) {
     const int f4 = lane & 31, sg = lane >> 5, f0 = 4 * f4;
-    float mu[4] = {0, 0, 0, 0}, sgm[4] = {1, 1, 1, 1};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dmu[i] = 0.0f; dsg[i] = 0.0f; }
+    for (int i = 0; i < 4; ++i) { dmu[i] = 0.0f; dsg[i] = 0.0f; mu[i] = 0.0f; sgm[i] = 1.0f; }
     if (f0 < a.D) {
         float rs2[4], rsg[4];
 #pragma unroll
@@ -874,12 +888,13 @@ __device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const 
             rsg[i] = 1.0f / sgm[i];
         }
         constexpr int UN = 4;
-        for (int s0 = sg; s0 < a.k; s0 += 2 * UN) {
+        const int sstep = 2 * nparts;
+        for (int s0 = sg + 2 * part; s0 < a.k; s0 += sstep * UN) {
             float4 dz[UN], cf[UN];
             float e[UN][4];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int s = s0 + 2 * u, sc = s < a.k ? s : a.k - 1, row = b * a.k + sc;      // clamped, weighted by 0 below
+                const int s = s0 + sstep * u, sc = s < a.k ? s : a.k - 1, row = b * a.k + sc;      // clamped, weighted by 0 below
                 if (a.dzh) { const uint2 h2 = *(const uint2*)(a.dzh + (size_t)row * a.ldDZ + f0); dz[u] = make_float4(bflo(h2.x), bfhi(h2.x), bflo(h2.y), bfhi(h2.y)); }
                 else dz[u] = *(const float4*)(a.dz + (size_t)row * a.ldDZ + f0);
                 if (a.dz2) {
@@ -891,7 +906,7 @@ __device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const 
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                if (s0 + 2 * u >= a.k) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (s0 + sstep * u >= a.k) cf[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 const float dzv[4] = {dz[u].x, dz[u].y, dz[u].z, dz[u].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -907,25 +922,68 @@ __device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const 
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dmu[i] += __shfl_xor(dmu[i], 32); dsg[i] += __shfl_xor(dsg[i], 32); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (f0 + i < a.D) {
-            dmu[i] += a.kmu * mu[i];
-            dsg[i] += a.ksig * (sgm[i] - 1.0f / sgm[i]);
-            dsg[i] *= (sgm[i] - 1e-6f);
-        } else { dmu[i] = 0.0f; dsg[i] = 0.0f; }
-    }
+    if constexpr (FINISH) latent_finish(a, f0, mu, sgm, dmu, dsg);
 }
+__device__ __forceinline__ void latent_image_wave(const LatentBwdArgs& a, const int b, const int lane, float (&dmu)[4], float (&dsg)[4]) {
+    float mu[4], sgm[4];
+    latent_image_part<true>(a, b, lane, 0, 1, dmu, dsg, mu, sgm);
+}
+// RW = data rows per workgroup.  16: the tile is full.  4 (round 5, lat_on with many samples per image): a QUARTER-filled tile per workgroup and four
+// times the workgroups -- the latent sums in front of the dX chain read k x (dz + draws) per image, which 64 workgroups (a wave per image) pull at a
+// quarter of the chip's bandwidth (k = 50: +10 us over the separate latent_bwd_kernel, round 4); with 4 images per workgroup the 16 waves take
+// an image's samples four ways (partial sums meet in LDS in part order) on 256 workgroups, and latent_bwd_kernel's launch is gone from the step's
+// main chain at k = 50 too (13.8 + 8.6 us alone + a boundary -> one launch).  The 12 idle rows of the MFMA tile cost nothing that matters (0.16 GFLOP).
+template <int RW>
 __global__ __launch_bounds__(1024, 4) void block_bwd_kernel(BlockBwdArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rho = lane & 15, q = lane >> 4;
-    const int r0 = blockIdx.x * 16;
+    const int r0 = blockIdx.x * RW;
     const int row = r0 + rho;
-    const bool valid = row < a.R;
+    const bool valid = rho < RW && row < a.R;
     const int a_off = rho * 64 + ((q ^ hperm(rho >> 2)) * 16);
     char* act0 = smem;                                   // dhead tile: KTH blocks
     char* act1 = smem + (size_t)a.KTH * 1024;            // d2 tile: KT1 blocks
+    if (RW == 4 && a.lat_on) {
+        // wave w: image r0 + (w >> 2), part w & 3 of its samples; raw sums -> LDS; waves 0, 4, 8, 12 add the four parts in part order, finish, and
+        // write their image's row of the dhead tile (rows 4..15 of the tile: zeros)
+        float* part_lds = (float*)(smem + (size_t)(a.KTH + a.KT1) * 1024);      // [4 images][4 parts][32 lanes][8]
+        for (int c = threadIdx.x; c < a.KTH * 64; c += 1024) *(uint4*)(act0 + c * 16) = make_uint4(0, 0, 0, 0);
+        float dmu[4], dsg[4], mu[4], sgm[4];
+        const int img = wave >> 2, part = wave & 3, b = r0 + img, Dp = a.lat.Dp;
+        if (b < a.R) latent_image_part<false>(a.lat, b, lane, part, 4, dmu, dsg, mu, sgm);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dmu[i] = 0.0f; dsg[i] = 0.0f; mu[i] = 0.0f; sgm[i] = 1.0f; }
+        }
+        if (lane < 32) {
+            float* pl = part_lds + ((size_t)(img * 4 + part) * 32 + lane) * 8;
+            *(float4*)pl = make_float4(dmu[0], dmu[1], dmu[2], dmu[3]);
+            *(float4*)(pl + 4) = make_float4(dsg[0], dsg[1], dsg[2], dsg[3]);
+        }
+        __syncthreads();      // (also: the zero fill of the tile is complete)
+        if (part == 0 && lane < 32) {
+#pragma unroll
+            for (int pp = 1; pp < 4; ++pp) {
+                const float* pl = part_lds + ((size_t)(img * 4 + pp) * 32 + lane) * 8;
+                const float4 m4 = *(const float4*)pl, s4 = *(const float4*)(pl + 4);
+                dmu[0] += m4.x; dmu[1] += m4.y; dmu[2] += m4.z; dmu[3] += m4.w;
+                dsg[0] += s4.x; dsg[1] += s4.y; dsg[2] += s4.z; dsg[3] += s4.w;
+            }
+            latent_finish(a.lat, 4 * lane, mu, sgm, dmu, dsg);
+            if (lane < Dp / 4) {
+                const int f0 = 4 * lane;
+                const uint2 vm = make_uint2(pack2(dmu[0], dmu[1]), pack2(dmu[2], dmu[3])), vs = make_uint2(pack2(dsg[0], dsg[1]), pack2(dsg[2], dsg[3]));
+                const int pm = p_pos(f0), ps = p_pos(Dp + f0);
+                *(uint2*)(act0 + (pm >> 5) * 1024 + img * 64 + ((((pm & 31) >> 3) ^ hperm(img >> 2)) * 16) + ((pm >> 2) & 1) * 8) = vm;
+                *(uint2*)(act0 + (ps >> 5) * 1024 + img * 64 + ((((ps & 31) >> 3) ^ hperm(img >> 2)) * 16) + ((ps >> 2) & 1) * 8) = vs;
+                if (b < a.R && a.lat.DHP) {
+                    *(uint2*)(a.lat.DHP + (size_t)b * (2 * Dp) + pm) = vm;
+                    *(uint2*)(a.lat.DHP + (size_t)b * (2 * Dp) + ps) = vs;
+                }
+            }
+        }
+    } else
     if (a.lat_on) {      // the dhead tile is MADE here: wave w = image r0 + w (latent_bwd_kernel's job, without its launch)
         float dmu[4], dsg[4];
         const int b = r0 + wave, Dp = a.lat.Dp;
@@ -949,7 +1007,7 @@ __global__ __launch_bounds__(1024, 4) void block_bwd_kernel(BlockBwdArgs a) {
     for (int c = threadIdx.x; c < a.KTH * 64; c += 1024) {      // 16-byte chunks: (ks, row, quad)
         const int ks = c >> 6, rr = (c >> 2) & 15, qq = c & 3;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + rr < a.R) v = *(const uint4*)(a.DH + (size_t)(r0 + rr) * a.ldDH + ks * 32 + qq * 8);
+        if (rr < RW && r0 + rr < a.R) v = *(const uint4*)(a.DH + (size_t)(r0 + rr) * a.ldDH + ks * 32 + qq * 8);
         *(uint4*)(act0 + ks * 1024 + rr * 64 + ((qq ^ hperm(rr >> 2)) * 16)) = v;
     }
     const int mg = wave >> 2, tg = wave & 3;
@@ -4698,7 +4756,8 @@ bool block_bwd_ok(const BlockBwdArgs& a) {
     return a.R <= 4096 && a.KTH <= BLOCKFWD_MAX_KT && a.KT1 <= BLOCKFWD_MAX_KT && a.NT1 <= 16 && a.NT1 == 2 * a.KT1;
 }
 void launch_block_bwd(const BlockBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(block_bwd_kernel, dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KTH + a.KT1) * 1024, st, a);
+    if (a.rows_per_wg == 4) hipLaunchKernelGGL(block_bwd_kernel<4>, dim3((a.R + 3) / 4), dim3(1024), (size_t)(a.KTH + a.KT1) * 1024 + 16384, st, a);
+    else hipLaunchKernelGGL(block_bwd_kernel<16>, dim3((a.R + 15) / 16), dim3(1024), (size_t)(a.KTH + a.KT1) * 1024, st, a);
 }
 void launch_block_fwd(const BlockFwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(a.KT0 + 2 * a.KT1) * 1024 + (a.sample ? (size_t)a.KT0 * 768 : 0);

@@ -137,6 +137,11 @@ struct iwae_model {
     // float32 mode (iwae_config.precision / iwae_set_eval_precision): row-major float32 activations, GEMMs on v_mfma_f32_16x16x4_f32
     struct F32Block { DevBuf h1, h2, dhead, d2, d1, dx; };
     struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat; } f32;
+    // float32 weight gradients of a step keep their row-split slabs (each in its own region of f32.slab) and are summed by ONE launch at the end of
+    // backward_f32 (reduce_slabs_multi_f32_kernel): jobs queued by f32_dw, slab offsets in floats (the buffer may still grow while they queue)
+    struct F32Pending { size_t off; size_t stride; size_t n; float* out; int nsplit; };
+    std::vector<F32Pending> f32_pending; size_t f32_slab_used = 0; bool allow_f32_multi_reduce = true;
+    size_t f32_slab_want = 0, f32_slab_want_step = 0;      // floats of slabs the last whole step asked for (the buffer's target size) / this step so far
     int eval_tag_kill = -1;
     int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
     DevBuf eval_x, eval_lme;                  // iwae_eval_llh: the images (uploaded once) and the per-image log-mean-exps of every launch
@@ -182,6 +187,10 @@ struct iwae_model {
     // (0.2044 -> 0.2154 ms, interleaved A/B): the decoder kernel pays 4 us for 23 MB more writes and the backward phase is bound by its bytes, not
     // by that kernel's instruction stream.
     bool allow_g2w = false, g2w = false, g2w_descs = false;
+    bool allow_lat_rows4 = false;                    // option lat_rows4 (round 5, measured and NOT the default): beyond 16 samples per image the sums inside block_bwd_kernel<4> (4 images per
+                                                     // workgroup, an image's samples over four waves, 256 workgroups).  In the step it takes 32.6 us where latent_bwd_kernel + block_bwd_kernel
+                                                     // take 18.7 + 10.1: its 1024-thread / 101-register workgroups need a whole CU each and only ~96 CUs are free beside the weight
+                                                     // gradients (three rounds), where latent_bwd_kernel's small workgroups fit anywhere: c1 0.1965 vs 0.1962 ms, c2 0.3856 vs 0.3802
     bool allow_lat_in_block = true;                  // few images: latent_bwd_kernel's sums inside the encoder's block_bwd_kernel (option no_lat_in_block)
     bool lse_pending = false, allow_lse_in_bwd = true;      // few rows: this step's lse_kernel work was left to dec_bwd_rows_kernel (lse_saved; option no_lse_in_bwd)
     LseArgs lse_saved;
@@ -690,7 +699,10 @@ int block_bwd(iwae_model* m, Linear* blk, BlockWs& w, const uint16_t* inP, int R
         b.H2 = ptr<uint16_t>(w.h2P); b.H1 = ptr<uint16_t>(w.h1P); b.ldH = blk[0].Np32;
         b.D2 = ptr<uint16_t>(w.d2P); b.D1 = ptr<uint16_t>(w.d1P);
         if (block_bwd_ok(b)) {
-            if (lat && lat->Dp <= 128 && lat->Dp == blk[2].Np32 / 2 && !lat->prior_head && !lat->DHF) { b.lat_on = 1; b.lat = *lat; if (lat_taken) *lat_taken = true; }
+            if (lat && lat->Dp <= 128 && lat->Dp == blk[2].Np32 / 2 && !lat->prior_head && !lat->DHF) {
+                b.lat_on = 1; b.lat = *lat; if (lat_taken) *lat_taken = true;
+                b.rows_per_wg = lat->k > 16 ? 4 : 16;      // (many samples per image: four waves per image, 4 images per workgroup -- block_bwd_kernel<4>)
+            }
             else if (lat) return IWAE_OK;      // (not taken: nothing launched)
             launch_block_bwd(b, m->stream); chain_fused = true;
         } else if (lat) return IWAE_OK;
@@ -1493,7 +1505,9 @@ int backward_impl(iwae_model* m, int objective, float fused_lr = -1.0f, bool spl
         lat_args = a;
         // (measured, end-to-end us per step with / without: B = 20, k = 1: 67.7 / 70.0; B = 20, k = 5: 67.5 / 69.3; B = 100, k = 5: 72.1 / 73.4; B = 20, k = 50: 88.2 / 78.5 --
         // one wave walking 50 samples is slower than latent_bwd_kernel's 256 threads: up to 16 samples per image)
-        lat_fuse = m->allow_lat_in_block && !m->has_prior && B <= 1024 && k <= 16 && m->allow_block_fused;
+        // (round 5, option lat_rows4: beyond 16 samples per image block_bwd_kernel<4> -- 4 images per workgroup, an image's samples over four waves --
+        // can take the sums on 4 x the workgroups; measured no faster than the two launches in the step, see allow_lat_rows4)
+        lat_fuse = m->allow_lat_in_block && !m->has_prior && B <= 1024 && (k <= 16 || (m->allow_lat_rows4 && B >= 64)) && m->allow_block_fused;
         if (!lat_fuse && !(m->abl_skip & 8)) { ScopedTimer tm(m, T_LATENT_BWD); launch_latent_bwd(a, st); }
     }
     if (m->has_prior) CHK(block_bwd(m, m->prior, m->wprior, ptr<uint16_t>(m->condP), B, false, false));
@@ -1720,6 +1734,22 @@ int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int ro
     return f32_gemm(m, G, ldg, 1, m->param + kl.offW, 1, kl.Nout, DX, lddx, rows, kl.Kin, kl.Nout, nullptr, ACT ? GEMM_EPI_DTANH : GEMM_EPI_NONE, ACT, ldact, accumulate,
                     nullptr, rowscale);
 }
+// the queued slab sums of this step's float32 weight gradients, one launch (f32_dw)
+int f32_flush_reductions(iwae_model* m) {
+    if (!m->f32_pending.empty()) {
+        ReduceSlabsJobs jobs;
+        memset(&jobs, 0, sizeof(jobs));
+        for (const auto& p : m->f32_pending) {
+            ReduceSlabsJob& j = jobs.job[jobs.n++];
+            j.slabs = ptr<float>(m->f32.slab) + p.off; j.stride = p.stride; j.n = p.n; j.out = p.out; j.nsplit = p.nsplit;
+        }
+        launch_reduce_slabs_multi_f32(jobs, m->stream);
+        HIPCHK(hipGetLastError());
+        m->f32_pending.clear();
+    }
+    m->f32_slab_used = 0;
+    return IWAE_OK;
+}
 // grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
 // (rowscale: G's row r is multiplied by rowscale[r] as it is fetched -- the values the separate g_r s pass used to store)
 int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr) {
@@ -1727,8 +1757,17 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout);      // (+ 1: the row of ones whose product row is the bias gradient)
     const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (m->f32_dw_tiles + tiles - 1) / tiles));
     const size_t nW = (size_t)kl.Kin * kl.Nout;
-    CHK(ensure(m->f32.slab, nsplit * nW * 4, m->stream));
-    CHK(ensure(m->f32.bpart, (size_t)nsplit * kl.Nout * 4, m->stream));
+    // (round 5: the slabs of every gradient of the step stay until ONE reduction launch at the end of the backward pass; the buffer is sized for a
+    // whole step -- a step that outgrows it falls back to the reduction per tensor, and the buffer grows for the next step)
+    const size_t need = (size_t)nsplit * (nW + kl.Nout);
+    const bool queue = m->allow_f32_multi_reduce && nsplit > 1 && (m->f32_slab_used + need) * 4 <= m->f32.slab.cap && m->f32_pending.size() + 2 <= REDUCE_SLABS_MAX_JOBS;
+    if (!queue) {
+        if (!m->f32_pending.empty()) CHK(f32_flush_reductions(m));      // (queued jobs still read the buffer ensure() may replace)
+        CHK(ensure(m->f32.slab, std::max(need, m->f32_slab_want) * 4, m->stream));
+    }
+    m->f32_slab_want_step += need;
+    float* slabW = ptr<float>(m->f32.slab) + (queue ? m->f32_slab_used : 0);
+    float* slabB = slabW + (size_t)nsplit * nW;
     GemmF32Args a;
     memset(&a, 0, sizeof(a));
     a.A = X; a.sam = 1; a.sak = ldx; a.B = G; a.sbk = ldg; a.sbn = 1; a.M = kl.Kin; a.N = kl.Nout; a.K = rows;
@@ -1740,10 +1779,16 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
         a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; a.Cones = m->grad + kl.offb; a.cones_stride = 0;
         launch_gemm_f32(a, 1, m->stream);
     } else {
-        a.C = ptr<float>(m->f32.slab); a.ldc = kl.Nout; a.slab_stride = nW; a.Cones = ptr<float>(m->f32.bpart); a.cones_stride = (size_t)kl.Nout;
+        a.C = slabW; a.ldc = kl.Nout; a.slab_stride = nW; a.Cones = slabB; a.cones_stride = (size_t)kl.Nout;
         launch_gemm_f32(a, ns, m->stream);
-        launch_reduce_slabs_f32(ptr<float>(m->f32.slab), nW, ns, nW, m->grad + kl.offW, m->stream);
-        launch_reduce_slabs_f32(ptr<float>(m->f32.bpart), kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
+        if (queue) {
+            m->f32_pending.push_back({(size_t)(slabW - ptr<float>(m->f32.slab)), nW, nW, m->grad + kl.offW, ns});
+            m->f32_pending.push_back({(size_t)(slabB - ptr<float>(m->f32.slab)), (size_t)kl.Nout, (size_t)kl.Nout, m->grad + kl.offb, ns});
+            m->f32_slab_used += need;
+        } else {
+            launch_reduce_slabs_f32(slabW, nW, ns, nW, m->grad + kl.offW, m->stream);
+            launch_reduce_slabs_f32(slabB, kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
+        }
     }
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -1988,6 +2033,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
 
 // closed-form backward in float32: leaves the flat gradient in m->grad
 int backward_f32(iwae_model* m, int objective) {
+    m->f32_slab_want_step = 0;
     if (!m->have_forward || !m->fwd_was_f32) return fail(IWAE_ERR_STATE, "backward without a float32 forward");
     const bool two = m->cfg.n_layers == 2;
     const int B = m->B, k = m->k, M = m->M, Mp = m->Mp, X = m->X;
@@ -2060,6 +2106,8 @@ int backward_f32(iwae_model* m, int objective) {
     if (m->has_prior)
         CHK(f32_block_bwd(m, m->prior[0].sub[0], m->f32.prior, ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C, m->C, B, Dp0, nullptr, 0));
     CHK(f32_block_bwd(m, m->enc1[0].sub[0], m->f32.enc1, m->C > 0 ? ptr<float>(m->f32.xcat) : m->f32_x, X + m->C, B, Dp0, nullptr, 0));
+    CHK(f32_flush_reductions(m));      // every row-split gradient's slabs -> the flat gradient, one launch
+    m->f32_slab_want = std::max(m->f32_slab_want, m->f32_slab_want_step);
     HIPCHK(hipGetLastError());
     m->split_offset = m->nparam;       // (data-parallel step: one all-reduce of the whole gradient)
     return IWAE_OK;
@@ -2471,12 +2519,14 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
+    else if (n == "no_f32_multi_reduce") m->allow_f32_multi_reduce = !on;      // float32 mode: a slab reduction launch per gradient tensor instead of one per step
     else if (n == "no_f32_dec_fused") m->allow_f32_dec_fused = !on;   // float32 mode: the decoder forward as three GEMM launches
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
     else if (n == "no_dec_rows") m->allow_dec_rows = !on;             // few data rows: the decoder's weight gradients as the grouped launch on the side stream + deferred reduction
     else if (n == "no_wgrad_rows") m->allow_wgrad_rows = !on;         // few rows: the encoder's weight gradients as the grouped launch + slabs + reduce_grads_kernel
     else if (n == "no_wg3") m->allow_wg3 = !on;                       // few rows: the decoder's weight gradients as three launches on two streams
     else if (n == "g2w") m->allow_g2w = on;                           // the decoder kernel leaves bf16(g_r g2); the output layer's weight gradient runs unweighted on it (measured slower)
+    else if (n == "lat_rows4") m->allow_lat_rows4 = on;               // many samples per image: latent_bwd_kernel's sums inside block_bwd_kernel<4> (measured no faster)
     else if (n == "no_lat_in_block") m->allow_lat_in_block = !on;     // few images: latent_bwd_kernel as its own launch in front of the encoder's backward pass
     else if (n == "no_lse_in_bwd") m->allow_lse_in_bwd = !on;         // few rows: lse_kernel as its own launch between decoder forward and backward
     else if (n == "no_lse_fused") m->allow_lse_fused = !on;           // lse_kernel as its own launch behind the decoder kernel

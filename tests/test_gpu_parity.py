@@ -449,7 +449,7 @@ def test_kernel_variants_agree(gpu, B, k):
     for env in ({"out_recompute": 1}, {"dense_g1": 0}, {"no_zin": 1}, {"no_bern_pipe": 1},
                 {"no_dec_fused": 1}, {"no_block_fused": 1}, {"no_early_wout": 1}, {"bern_qw_force": 1},
                 {"no_dec_bwd": 1}, {"no_wg7": 1}, {"wg9": 3}, {"no_side2": 1}, {"wg_group": 1}, {"no_lse_dup": 1}, {"no_lse_fused": 1}, {"no_wg3": 1}, {"dz_f32": 1}, {"no_small_dec_bwd": 1},
-                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}, {"no_dec_rows": 1}, {"no_lse_in_bwd": 1}, {"no_lat_in_block": 1}, {"g2w": 1}, {"dec_bwd_nw": 4}):
+                {"dec_rows": 0}, {"dec_rows": 16384}, {"no_out_in_block": 1}, {"no_wgrad_rows": 1}, {"no_dec_rows": 1}, {"no_lse_in_bwd": 1}, {"no_lat_in_block": 1}, {"lat_rows4": 1}, {"g2w": 1}, {"dec_bwd_nw": 4}, {"defer_split": 1}, {"wout_split": 35}):
         e1, g1 = run(env)
         assert abs(e1 - e0) < 2e-3, env
         assert np.linalg.norm(g1 - g0) / np.linalg.norm(g0) < 5e-3, env

@@ -5,7 +5,8 @@ fn = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:58], r["Queue_Id"]) for r in csv.DictReader(open(fn)))
 # one step = from one reduce on the main queue to the next (exactly one per training step; the window is a whole step, phase-shifted:
 # it opens with the encoder forward of the next step)
-starts = [i + 1 for i, e in enumerate(ev) if "latent_bwd_kernel" in e[2]]
+anchor = "latent_bwd_kernel" if any("latent_bwd_kernel" in e[2] for e in ev) else "block_bwd_kernel"      # (round 5: the latent sums may ride in block_bwd_kernel<4>)
+starts = [i + 1 for i, e in enumerate(ev) if anchor in e[2]]
 starts = [i for i in starts if i < len(ev)]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 i0, i1 = starts[n], starts[n + 1]
