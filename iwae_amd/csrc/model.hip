@@ -207,7 +207,7 @@ struct iwae_model {
     int wg_target8 = 128;      // same for the 8-wave launches on many rows (narrow layers of the 2-layer model; option wg8): 128 row splits halve the 109 MB of fp32 slabs 256 wrote per step (c2: 0.4193 -> 0.4176 ms; 64: 0.462)
     int wg_target8_few = 32;   // 8-wave launches on < 8 192 rows (the encoder's layers on the batch's images; IWAE_WG8_FEW): the 784-wide first layer in 4 row
                                // splits instead of 16 (10.6 -> 2.7 MB of slabs each way): 0.2439 -> 0.2351 ms/step at B = 1 024; 8 / 16 / 48: 0.2374 / 0.2374 / 0.2360
-    int wg_target16 = 0;       // workgroups aimed at per 16-wave weight-gradient launch (option wg16; 0 = the model's default: 96 for the 1-layer model, 128 for
+    int wg_target16 = 0;       // workgroups aimed at per 16-wave weight-gradient launch (option wg16; 0 = the model's default: 96 for the 1-layer model, 64 (round 5; 128 before) for
                                // the 2-layer one -- round 3, with the output layer's gradient starting right behind the decoder kernel: 80 / 88 / 96 / 104 / 112 / 128
                                // -> 0.2192 / 0.2168 / 0.2132 / 0.2164 / 0.2206 / 0.2175 ms, 24 row splits write 17 MB of slabs instead of 22.5; the 2-layer
                                // step: 0.3932 vs 0.3916): these are one-per-CU
@@ -603,7 +603,9 @@ int wgradp_plan(iwae_model* m, Linear& L, const uint16_t* XP, const uint16_t* GP
     // 128 -> 0.425, 256 -> 0.406, 384 -> 0.443 ms/step (fewer leaves CUs idle, more pays a full fp32 slab per extra split).
     // Since they run beside the dX chain and with the register-blocked kernel: 160 (see wg_target16); the
     // single-block-wide hidden layers prefer 128.
-    const int target16 = m->wg_target16 > 0 ? m->wg_target16 : (m->cfg.n_layers == 2 ? 128 : 96);
+    // (round 5: the 2-layer step's MAIN stream is its long chain and its side streams have slack: 64 workgroups for the output layer's gradient leave the
+    // main chain's kernels more CUs -- 128 / 96 / 72 / 64 / 56 / 48 -> 0.3915 / 0.3834 / 0.3896 / 0.3769 / 0.3805 / 0.3852 ms, interleaved)
+    const int target16 = m->wg_target16 > 0 ? m->wg_target16 : (m->cfg.n_layers == 2 ? 64 : 96);
     const int target = (nw != 8) ? (blocks == 1 ? m->wg_target16_1 : target16) : (chunks < 128 ? m->wg_target8_few : m->wg_target8);
     nsplit = std::max(1, std::min(chunks, target / std::max(1, blocks)));
     const int cps = (chunks + nsplit - 1) / nsplit;

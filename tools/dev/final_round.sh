@@ -11,6 +11,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_line_driver_shape.json 2>> $O/b
 for c in c0 c2 c3; do python bench.py --config $c --steps 200 --warmup 5 --no-llh-eval > $O/bench_line_$c.json 2> $O/bench_$c.err; done
 python bench.py --precision fp32 --steps 60 --warmup 5 --no-llh-eval > $O/bench_line_c1_fp32.json 2> $O/bench_fp32.err
 python bench.py --config c0 --precision fp32 --steps 100 --warmup 5 --no-llh-eval --no-cpu-baseline > $O/bench_line_c0_fp32.json 2>> $O/bench_fp32.err
+for c in c2 c3; do python bench.py --config $c --precision fp32 --steps 60 --warmup 5 --no-llh-eval --no-cpu-baseline > $O/bench_line_${c}_fp32.json 2>> $O/bench_fp32.err; done
 python bench.py --force-dist --steps 200 --warmup 5 --no-llh-eval --no-cpu-baseline > $O/bench_line_c1_forcedist.json 2> $O/bench_forcedist.err
 for f in $O/bench_line_*.json; do python3 - "$f" <<'PY'
 import sys, json
@@ -25,4 +26,4 @@ bash tools/profile_bench.sh $TAG c1 > $O/profile_c1.txt 2>&1; tail -25 $O/profil
 bash tools/profile_bench.sh ${TAG}_c2 c2 quick > $O/profile_c2.txt 2>&1; tail -25 $O/profile_c2.txt
 bash tools/dev/alone.sh "bern_pipe|dec_bwd|wgradws|wgrad_rows|reduce_grads|block_fwd|block_bwd|latent|eps_gen" wg16=128 > $O/alone_times.txt 2>&1; cat $O/alone_times.txt
 BENCH_ARGS="--config c2" bash tools/dev/alone.sh "chain2|gblock|bern_pipe|dec_bwd|wgradws|wgradp|wgrad_rows|reduce_grads|block_fwd|block_bwd|latent" > $O/alone_times_c2.txt 2>&1; cat $O/alone_times_c2.txt
-for p in fp32 bf16; do python tools/dev/eval_only.py $p 2000 >> $O/eval.txt 2>&1; done; cat $O/eval.txt
+for p in fp32 bf16; do python tools/dev/eval_only.py $p 4190 >> $O/eval.txt 2>&1; python tools/dev/eval_only.py $p 10000 >> $O/eval.txt 2>&1; done; cat $O/eval.txt
