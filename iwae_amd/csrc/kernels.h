@@ -306,6 +306,7 @@ void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start
                             uint32_t epoch, uint16_t* XP, float* xf, hipStream_t st,
                             const uint8_t* labels = nullptr, int C = 0, float* cond_out = nullptr);      // labels: class ids of the resident set (conditional models)
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks = 0);   // max_blocks > 0: grid-stride over at most that many blocks
+void launch_eps_gen_multi(const EpsSrc& e, int M, int D, int ld, float* out, int nsteps, size_t step_stride, hipStream_t st);   // steps e.step .. e.step + nsteps - 1, step s at out + s * step_stride
 void launch_sample(const SampleArgs& a, hipStream_t st);
 void launch_gauss_lp(const GaussLpArgs& a, hipStream_t st);
 void launch_lse(const LseArgs& a, hipStream_t st);

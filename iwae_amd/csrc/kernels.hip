@@ -3904,6 +3904,19 @@ __global__ __launch_bounds__(256) void gather_binarize_kernel(const uint8_t* dat
 // Grid-stride: drawn ahead (a whole step early, beside the forward pass) the launch is a few hundred small blocks that
 // take their time in a corner of every CU; as 5 000 blocks it filled the machine for 11 us and the forward's large
 // workgroups queued behind it.
+// The draws of `nsteps` consecutive steps in one launch (few rows: a step's 2 000 draws are a 4.5 us launch on a chain of 9-17 us kernels; eight steps'
+// worth cost the same): step e.step + s goes to out + s * step_stride, each value exactly what eps_gen_kernel would draw for that step.
+__global__ __launch_bounds__(256) void eps_gen_multi_kernel(EpsSrc e, int M, int nd4, int ld, float* out, int nsteps, size_t step_stride) {
+    const size_t per = (size_t)M * nd4, total = per * nsteps;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int s = (int)(idx / per);
+        const size_t r = idx - (size_t)s * per;
+        const int row = (int)(r / nd4), d4 = (int)(r - (size_t)row * nd4);
+        float n[4];
+        normal4(e.row_offset + (uint64_t)row, (uint32_t)d4, e.stream, e.step + (uint32_t)s, e.seed, n);
+        *(float4*)(out + (size_t)s * step_stride + (size_t)row * ld + 4 * d4) = make_float4(n[0], n[1], n[2], n[3]);
+    }
+}
 __global__ __launch_bounds__(256) void eps_gen_kernel(EpsSrc e, int M, int nd4, int ld, float* out) {
     const size_t total = (size_t)M * nd4;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -4915,6 +4928,10 @@ void launch_gather_binarize(const uint8_t* data, const int32_t* order, int start
     const int nchunk = Xp / 8;
     hipLaunchKernelGGL(gather_binarize_kernel, dim3(Bp / 64, std::min(32, (nchunk + 3) / 4)), dim3(256), 0, st, data, order, start, N, B, X, Xp,
                        Bp, seed, epoch, XP, xf, labels, labels ? C : 0, cond_out);
+}
+void launch_eps_gen_multi(const EpsSrc& e, int M, int D, int ld, float* out, int nsteps, size_t step_stride, hipStream_t st) {
+    const int nd4 = (D + 3) / 4;
+    hipLaunchKernelGGL(eps_gen_multi_kernel, grid1((size_t)nsteps * M * nd4, 256), dim3(256), 0, st, e, M, nd4, ld, out, nsteps, step_stride);
 }
 void launch_eps_gen(const EpsSrc& e, int M, int D, int ld, float* out, hipStream_t st, int max_blocks) {
     const int nd4 = (D + 3) / 4;

@@ -223,6 +223,11 @@ struct iwae_model {
                                 // when the next step's are requested) and the next step's (drawn during this step's forward)
     struct EpsTag { bool valid = false; uint32_t step = 0; uint64_t row_offset = 0; int M = 0; } eps_tag[3];
     int epsc_par = 0;
+    // Few data rows (the single-stream regime of dec_rows_step, round 5): the draws of EPSM_STEPS consecutive steps in ONE launch, two buffers taking turns
+    // (the next group is drawn during the forward pass of the current group's last step: the buffer it overwrites was last read a whole group ago, in stream order)
+    DevBuf epsm[2][2];          // [buffer][layer]: [EPSM_STEPS][Mp][eps_ld]
+    struct EpsMTag { bool valid = false; uint32_t step0 = 0; uint64_t row_offset = 0; int M = 0; } epsm_tag[2];
+    bool allow_eps_multi = true;   // option no_eps_multi: one draw launch per step there too
     const float* epsc_ptr[2] = {nullptr, nullptr};
     char* d_zero = nullptr;    // 1 KiB of zeros (wgradp_kernel's source for rows >= M)
     uint32_t ds_epoch = 0;
@@ -818,6 +823,33 @@ int draw_eps(iwae_model* m, int par, uint32_t step, int M, hipStream_t gs, int m
     return IWAE_OK;
 }
 
+#define EPSM_STEPS 8
+// few rows: draws of steps [step0, step0 + EPSM_STEPS) into multi-step buffer `buf` (stream order on gs protects the buffer: see iwae_model::epsm)
+int draw_eps_multi(iwae_model* m, int buf, uint32_t step0, int M, hipStream_t gs) {
+    const int Mp = round_up(M, 128);
+    iwae_model::EpsMTag& tg = m->epsm_tag[buf];
+    tg.valid = false;
+    for (int l = 0; l < m->cfg.n_layers; ++l) {
+        const size_t stride = (size_t)Mp * eps_ld(m, l);
+        CHK(ensure(m->epsm[buf][l], (size_t)EPSM_STEPS * stride * 4, m->stream));
+        EpsSrc e = eps_src(m, l);
+        e.user = nullptr; e.cache = nullptr; e.step = step0;
+        launch_eps_gen_multi(e, M, m->D[l], eps_ld(m, l), ptr<float>(m->epsm[buf][l]), EPSM_STEPS, stride, gs);
+    }
+    HIPCHK(hipGetLastError());
+    tg.valid = true; tg.step0 = step0; tg.row_offset = (uint64_t)m->batch_offset * (uint64_t)m->k; tg.M = M;
+    return IWAE_OK;
+}
+// the multi-step buffer that holds the draws of `step` for this batch shape, or -1
+int epsm_find(const iwae_model* m, uint32_t step, int M) {
+    const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)m->k;
+    for (int i = 0; i < 2; ++i) {
+        const iwae_model::EpsMTag& t = m->epsm_tag[i];
+        if (t.valid && t.M == M && t.row_offset == ro && step - t.step0 < (uint32_t)EPSM_STEPS) return i;      // (unsigned: step >= step0)
+    }
+    return -1;
+}
+
 // the stream that carries the speculative draw of the NEXT step's noise: one that this step's backward pass orders behind the main stream
 // and whose last event the next forward joins (see the call in forward_impl; m->early_wout must be decided)
 hipStream_t eps_draw_stream(const iwae_model* m, int M) {
@@ -864,6 +896,17 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     const bool zin_eval = !bwd && !two && m->C == 0 && m->allow_zin && m->allow_zin_eval && (int64_t)B * k >= 8192 && m->allow_dec_fused && m->allow_bern_pipe;
     const bool keep_eps = !eps && (bwd || two || zin_eval);
     m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
+    // few data rows, training step, single-stream backward (dec_rows_step): the draws come from the multi-step buffers (one launch per EPSM_STEPS steps)
+    const bool eps_multi = keep_eps && bwd && !two && m->allow_eps_multi && m->eval_k_total == 0 && dec_rows_step(m, M, B);
+    if (eps_multi) {
+        int bi = epsm_find(m, m->noise_step, M);
+        if (bi < 0) {      // (first step, another batch shape, a jump of iwae_set_step: drawn now, in stream order)
+            bi = (m->epsm_tag[0].valid && !m->epsm_tag[1].valid) ? 1 : 0;
+            CHK(draw_eps_multi(m, bi, m->noise_step, M, st));
+        }
+        const size_t soff = (size_t)(m->noise_step - m->epsm_tag[bi].step0) * (size_t)round_up(M, 128);
+        for (int l = 0; l < m->cfg.n_layers; ++l) m->epsc_ptr[l] = ptr<float>(m->epsm[bi][l]) + soff * eps_ld(m, l);
+    } else
     if (keep_eps) {
         const int np = (m->epsc_par + 1) % 3;
         const uint64_t ro = (uint64_t)m->batch_offset * (uint64_t)k;
@@ -1181,6 +1224,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         // gradient forks early (early_wout, known here); without that -- hidden widths without a stored-s instantiation, options out_recompute /
         // no_early_wout -- everything runs on `side`, the stream whose event the next step joins and which is re-ordered behind the main stream every
         // step (the ring slot written here was last read by step t - 2's backward pass on the main stream).)
+        if (eps_multi) {      // the next GROUP of steps, once per group: into the buffer the current step does not read (main stream: this regime touches no other)
+            if (epsm_find(m, m->noise_step + 1, M) < 0) CHK(draw_eps_multi(m, 1 - epsm_find(m, m->noise_step, M), m->noise_step + 1, M, st));
+        } else
         if (bwd && keep_eps && m->side)
             CHK(draw_eps(m, (m->epsc_par + 1) % 3, m->noise_step + 1, M, eps_draw_stream(m, M), m->eps_blocks));
         if (want && want->logits) CHK(copy_out(m, want->logits, m->scratch.p, (size_t)M * X * 4));
@@ -2295,7 +2341,8 @@ void iwae_destroy(iwae_handle m) {
     for (Linear* L : all_linears(m)) free_linear(*L);
     DevBuf* bufs[] = {&m->xin, &m->xP, &m->epsbuf, &m->zP[0], &m->zP[1], &m->rows[0], &m->rows[1],
                       &m->rows[2], &m->rows[3], &m->rows[4], &m->rows[5], &m->logw, &m->wn, &m->gx, &m->cf, &m->per_b, &m->logw2, &m->wn2, &m->gx2, &m->cf2, &m->per_b2,
-                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1], &m->eval_x, &m->eval_lme};
+                      &m->dzdir, &m->scratch, &m->ds_data, &m->ds_order, &m->dstamps, &m->px_part, &m->dg2_part, &m->cond, &m->condP, &m->epsc[0][0], &m->epsc[0][1], &m->epsc[1][0], &m->epsc[1][1], &m->epsc[2][0], &m->epsc[2][1], &m->eval_x, &m->eval_lme,
+                      &m->ds_labels, &m->epsm[0][0], &m->epsm[0][1], &m->epsm[1][0], &m->epsm[1][1]};
     for (DevBuf* b : bufs) free_buf(*b);
     BlockWs* bw[] = {&m->wenc1, &m->wenc2, &m->wdec2, &m->wprior};
     for (BlockWs* w : bw) {
@@ -2513,6 +2560,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "wout_wg1") m->wout_wg1 = std::max(1, iv);          // ... its workgroups / those of the late launch
     else if (n == "wout_wg2") m->wout_wg2 = std::max(1, iv);
     else if (n == "defer_split") m->defer_split = on;                 // 1-layer step: one deferred decoder update per side stream
+    else if (n == "no_eps_multi") m->allow_eps_multi = !on;           // few rows: one noise-draw launch per step instead of one per 8 steps
     else if (n == "no_zin") m->allow_zin = !on;                       // always the separate sampling kernel
     else if (n == "zin_eval") m->allow_zin_eval = on;                 // forward-only calls: z made in the decoder kernel's prologue (measured slower)
     else if (n == "no_chain2_bwd") m->allow_chain2_bwd = !on;         // ... only their backward unfused
