@@ -397,7 +397,11 @@ def test_kernel_family_boundaries_match_oracle(gpu, layers, B, k, obj):
 
 
 @pytest.mark.parametrize("B,k,nh,nl,obj", [(170, 50, 200, 100, "iwae_elbo"), (20, 3, 200, 100, "iwae_elbo"), (9, 4, 64, 10, "iwae_elbo"), (6, 5, 64, 2, "iwae_elbo"),
-                                           (170, 50, 200, 100, "dreg"), (20, 3, 200, 100, "dreg")])
+                                           (170, 50, 200, 100, "dreg"), (20, 3, 200, 100, "dreg"),
+                                           # round 5 (the decoder kernel's rewritten sampling prologue at 8 500 rows): a latent of 2 k-steps whose width is not
+                                           # a multiple of 4 (50: the masked chunk straddles D), one that fills its k-steps exactly (64), a ragged 4-step one (98),
+                                           # and rows that leave the last workgroup's shared tile half empty (163 x 52 = 8 476)
+                                           (170, 50, 200, 50, "iwae_elbo"), (170, 50, 200, 64, "dreg"), (170, 50, 200, 98, "iwae_elbo"), (163, 52, 200, 100, "iwae_elbo")])
 def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl, obj):
     """The training step on the DEVICE's own noise (the path bench.py times: noise drawn ahead by eps_gen_kernel, the first
     decoder layer making z = mu + sigma*eps itself; on few rows block_fwd_kernel's sampling mode) against the oracle fed the same
@@ -413,8 +417,13 @@ def test_device_noise_step_matches_oracle_on_the_same_draws(gpu, B, k, nh, nl, o
     m.set_step(step, 0)
     r = m.forward_backward(x, k, 1.0, obj, want=("lpxz", "lpz", "lqzx", "z"))
     np.testing.assert_allclose(r["z"], res_e["z"], rtol=0, atol=1e-2)
+    # every row against the oracle evaluated at the device's own encoder head (a bf16 ulp flip of one encoder activation moves an image's mu, hence
+    # log p(z) of all its samples: nl = 50 has such a row at 0.039 nat against the pure oracle), and the typical row against the pure oracle
+    at = _densities_at_device_head(m, P, x, eps, nl)
     for key in ("lpxz", "lpz", "lqzx"):
-        assert np.max(np.abs(r[key] - res_e[key])) < EMU_ROW_ATOL, key
+        assert np.max(np.abs(r[key] - at[key])) < EMU_ROW_ATOL, key
+        assert np.quantile(np.abs(r[key] - res_e[key]), 0.98) < EMU_ROW_ATOL, key
+        assert np.max(np.abs(r[key] - res_e[key])) < 10 * EMU_ROW_ATOL, key
     for key in (("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "iwae_elbo", "iwae_eq14")):
         assert abs(r[key] - res_e[key]) < EMU_SCALAR_ATOL, (key, r[key], res_e[key])
     if obj == "dreg":      # (tasks/task02.py:61-76; at >= 8 192 rows the second log q is summed in the decoder kernel's prologue)
