@@ -36,6 +36,7 @@ struct LseArgs {
     float* logw; float* wn; float* gx; float4* cf; float* per_b;
     int n_px_part; size_t px_stride;     // term[0] arrives as n partial sums [n][stride] (n <= 1: a plain array)
     float* term0_out;                    // [M] total of term[0] (== term[0] when n_px_part <= 1)
+    int lme_only;                        // iwae_eval_llh's launches: only the per-image log-mean-exp and the means are wanted -- no softmax weights / gradient coefficients pass (28 B of stores per row)
     float* gx_local; int gx_r0, gx_n;    // optional: the row weights of rows [gx_r0, gx_r0 + gx_n) also go to gx_local[row - gx_r0] (kernels that do lse_image's work for their own rows: dec_bwd_rows_kernel, bern_pipe_kernel)
 };
 

@@ -1167,6 +1167,7 @@ __device__ __forceinline__ void lse_image(const LseArgs& a, const int b, const i
     const float inv_se = 1.0f / se;
     const float invB = 1.0f / (float)a.B, invkB = invB / (float)k;
     float eq14 = 0.0f, dreg = 0.0f;
+    if (!a.lme_only)
     for (int s = lane; s < k; s += NT) {
         const int r = b * k + s;
         const float lw = single ? lw_reg : a.logw[r];

@@ -144,6 +144,7 @@ struct iwae_model {
     size_t f32_slab_want = 0, f32_slab_want_step = 0;      // floats of slabs the last whole step asked for (the buffer's target size) / this step so far
     int eval_tag_kill = -1;
     int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
+    bool in_eval_llh = false;                 // iwae_eval_llh's launches need log_w only: no second (DReG) density per sample (round 5: ~14 % of the sampling pass)
     DevBuf eval_x, eval_lme;                  // iwae_eval_llh: the images (uploaded once) and the per-image log-mean-exps of every launch
     int eval_rows = 0;                        // data rows per evaluator launch (option eval_rows): images x samples, k chunked beyond it; 0 = eval_rows_auto()
     int eval_precision = IWAE_PREC_FP32;      // arithmetic of iwae_eval_llh (iwae_set_eval_precision)
@@ -988,7 +989,7 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
         s.prior_head = m->has_prior ? ptr<float>(m->wprior.head) : nullptr;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
-        const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);    // tasks/task02.py:63-65
+        const bool want_dreg = !two && (objective == OBJ_DREG || (!bwd && !m->in_eval_llh));    // tasks/task02.py:63-65
         s.lq_dreg = want_dreg ? lqd : nullptr;
         // 1-layer training step on the device's own noise: the first decoder layer makes z itself (dense_kernel ZIN mode)
         // (the DReG step too: the decoder kernel's prologue also sums the second log q; if that kernel turns out not to apply, sample_kernel runs after all)
@@ -1081,8 +1082,9 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
             a.head = nullptr;
             a.cz_on = 0.f;
         }
-        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
+        a.lq_dreg = (!two && (objective == OBJ_DREG || (!bwd && !m->in_eval_llh))) ? lqd : nullptr;
         a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
+        a.lme_only = (!bwd && m->in_eval_llh && !want) ? 1 : 0;
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
         a.n_px_part = 1; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
@@ -1950,7 +1952,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
         s.prior_head = m->has_prior ? ptr<float>(m->wprior.head) : nullptr;
         s.lp_prior = two ? nullptr : t1;
         s.lq = two ? t3 : t2;
-        const bool want_dreg = !two && (objective == OBJ_DREG || !bwd);
+        const bool want_dreg = !two && (objective == OBJ_DREG || (!bwd && !m->in_eval_llh));
         s.lq_dreg = want_dreg ? lqd : nullptr;
         launch_sample(s, st);
     }
@@ -2064,8 +2066,9 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
             a.term[0] = lpxz; a.coef[0] = 1.f; a.term[1] = t1; a.coef[1] = 1.f; a.term[2] = t2; a.coef[2] = 1.f;
             a.term[3] = t3; a.coef[3] = -1.f; a.term[4] = t4; a.coef[4] = -1.f; a.head = nullptr; a.cz_on = 0.f;
         }
-        a.lq_dreg = (!two && (objective == OBJ_DREG || !bwd)) ? lqd : nullptr;
+        a.lq_dreg = (!two && (objective == OBJ_DREG || (!bwd && !m->in_eval_llh))) ? lqd : nullptr;
         a.B = B; a.k = k; a.beta = two ? 1.f : beta; a.objective = objective;
+        a.lme_only = (!bwd && m->in_eval_llh && !want) ? 1 : 0;
         a.logw = ptr<float>(m->logw); a.wn = ptr<float>(m->wn); a.gx = ptr<float>(m->gx);
         a.cf = ptr<float4>(m->cf); a.per_b = ptr<float>(m->per_b);
         a.n_px_part = m->px_parts; a.px_stride = (size_t)Mp; a.term0_out = lpxz;
@@ -2789,9 +2792,10 @@ int iwae_eval_llh(iwae_handle m, const float* x, int32_t N, int32_t k, int32_t c
             m->eval_k_total = (kc < k) ? k : 0;
             m->eval_s_off = s0;
             const bool f32 = m->eval_precision == IWAE_PREC_FP32;
+            m->in_eval_llh = true;
             rc = f32 ? forward_f32(m, xd + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr)
                      : forward_impl(m, xd + (size_t)i0 * m->X, nb, kn, 1.0f, nullptr, OBJ_IWAE_ELBO, false, nullptr);
-            m->eval_k_total = 0; m->eval_s_off = 0;
+            m->eval_k_total = 0; m->eval_s_off = 0; m->in_eval_llh = false;
             if (rc != IWAE_OK) break;
             if (hipMemcpyAsync(ptr<float>(m->eval_lme) + (size_t)si * N + i0, ptr<float>(m->per_b) + (size_t)PB_LME * nb, (size_t)nb * 4, hipMemcpyDeviceToDevice,
                                m->stream) != hipSuccess) { rc = fail(IWAE_ERR_HIP, "eval_llh: keeping the per-image estimates failed"); break; }
