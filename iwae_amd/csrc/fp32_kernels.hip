@@ -335,6 +335,323 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
 }
 
 // ---------------------------------------------------------------------------------
+// gemm_f32_v2_kernel (round 5): the same products, tiles, K split and epilogues as gemm_f32_big_kernel with a k loop that leaves the vector
+// issue to the MFMAs.  Counters of the old loop (profiles/r05_f32_gemm_counters.txt): 4.45 vector instructions per MFMA -- 249 per wave and
+// k-step of 16 against 56 MFMAs: the operands' addresses, bounds and alignment re-derived per fetched quad and k-step (64-bit multiplies), a scalar
+// stash (four ds_write_b32 per quad, 53 % of the LDS cycles bank conflicts) -- and the matrix pipe 50 % busy.  Here:
+//   * a quad's global pointer is made once and advanced by a constant per k-step; whether it is inside the matrix, aligned (one 16-byte load), outside
+//     (zeros) or on an edge (element by element, with every bound -- also the whole last k-step of a ragged K) is a per-thread state made once;
+//   * one ds_write_b128 per quad, conflict-free: an operand whose k index is the unit-stride one sits in LDS as [row][16 k] with the four 16-byte
+//     slots of a row XOR-ed by swz(row) -- so that a lane reads its four k values of the k-step as ONE ds_read_b128 without bank conflicts in that
+//     instruction's 16-lane groups (MI355X_MICROARCH.md, LDS table) -- the other kind as [16 k][extent + 4] (pitch = 4 mod 8: the two quads of a
+//     ds_read_b32 half fall into different halves of the banks);
+//   * lane quad q contracts k = 4 q + j in MFMA step j of a k-step (any assignment of the 16 k's to (q, j) is a valid product; this one is what the
+//     16-byte reads deliver) -- float32 results differ from gemm_f32_big_kernel's in the order of the sum only;
+//   * the operand with fewer MFMA tiles per wave is held in registers for the k-step, the other streams through two-tile groups read one group ahead.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int gemm_swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }      // (0, 2, 3, 1) for rows 0-3, 4-7, 8-11, 12-15 of a 16-row tile
+// a quad off the fast path: kfast: elements (e, k .. k + 3), else (e .. e + 3, k); zero outside the matrix / beyond k_end; `ones`: row e == Ext is all ones
+__device__ __forceinline__ float4 gemm_f32_slow_quad(const float* base, long s_e, long s_k, int e, int k, int Ext, int k_end, bool kfast, bool ones) {
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ee = kfast ? e : e + t, kk = kfast ? k + t : k;
+        float x = 0.0f;
+        if (kk < k_end) {
+            if (ee < Ext) x = base[(size_t)ee * s_e + (size_t)kk * s_k];
+            else if (ones && ee == Ext) x = 1.0f;
+        }
+        v[t] = x;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+// An accumulator tile holds, per lane (n16, q), rows 4q .. 4q + 3 of column n16.  Transposed inside every group of four lanes (two exchanges with
+// lane ^ 1 and lane ^ 2), lane (n16 = 4c + p, q) holds row 4q + p, columns 4c .. 4c + 3: ONE 16-byte store (and one 16-byte load per epilogue
+// operand) per tile instead of four dword ones -- what a vector-memory instruction costs a CU is the instruction.
+__device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
+    const int p = lane & 3;
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[r ^ 1]), 0xB1, 0xF, 0xF, true));      // lane ^ 1
+        t[r] = ((r ^ p) & 1) ? o : x[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t[r ^ 2]), 0x4E, 0xF, 0xF, true));      // lane ^ 2
+        x[r] = ((r ^ p) & 2) ? o : t[r];
+    }
+}
+template <int TM, int TN, bool AK, bool BNF>      // AK: op(A)'s k index is the unit-stride one; BNF: op(B)'s n index is
+__global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    constexpr int PA = AK ? 16 : BM + 4, PB = BNF ? BN + 4 : 16;                    // row pitch in LDS (floats)
+    constexpr int SA = AK ? BM * 16 : 16 * PA, SB = BNF ? 16 * PB : BN * 16;        // floats per buffer
+    constexpr int QM = BM / 4, QN = BN / 4;
+    constexpr bool HOLD_A = TM <= TN;
+    __shared__ __attribute__((aligned(16))) float sA[2][SA];
+    __shared__ __attribute__((aligned(16))) float sB[2][SB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    // ---- the thread's quads.  Quad u of an operand tile [E = BM | BN][16 k]:
+    //   k index unit-stride: row e = (tid >> 2) + 64 u, k = 4 (tid & 3) .. + 3            (E / 64 quads per thread, rounded up)
+    //   otherwise:          k row = (256 / TPR) u + tid / TPR, e = 4 (tid % TPR) .. + 3    (TPR = threads per k row: the power of two >= E / 4)
+    // -- either way quad u + 1 is a CONSTANT away from quad u, in memory and in LDS: one pointer, one LDS offset and two state bits per quad
+    // (0 outside: zeros, 1 one 16-byte load, 2 element by element, 3 no such quad) are all a thread keeps per operand.
+    constexpr int TPRA = QM > 32 ? 64 : QM > 16 ? 32 : 16, TPRB = QN > 32 ? 64 : QN > 16 ? 32 : 16;
+    constexpr int NA = AK ? (BM + 63) / 64 : TPRA / 16, NB = BNF ? TPRB / 16 : (BN + 63) / 64;
+    const bool ones = a.Cones != nullptr;
+    const int eA0 = AK ? tid >> 2 : 4 * (tid % TPRA), kA0 = AK ? 4 * (tid & 3) : tid / TPRA;
+    const int eB0 = BNF ? 4 * (tid % TPRB) : tid >> 2, kB0 = BNF ? tid / TPRB : 4 * (tid & 3);
+    constexpr int dEA = AK ? 64 : 0, dKA = AK ? 0 : 256 / TPRA, dEB = BNF ? 0 : 64, dKB = BNF ? 256 / TPRB : 0;      // quad u -> u + 1
+    const int oA0 = AK ? eA0 * 16 + (((tid & 3) ^ gemm_swz16(eA0)) << 2) : kA0 * PA + eA0;
+    const int oB0 = BNF ? kB0 * PB + eB0 : eB0 * 16 + (((tid & 3) ^ gemm_swz16(eB0)) << 2);
+    constexpr int dOA = AK ? 64 * 16 : dKA * PA, dOB = BNF ? dKB * PB : 64 * 16;
+    const float* pA = a.A + (size_t)(m0 + eA0) * a.sam + (size_t)(k_beg + kA0) * a.sak;
+    const float* pB = a.B + (size_t)(n0 + eB0) * a.sbn + (size_t)(k_beg + kB0) * a.sbk;
+    const long dPA = AK ? 64 * a.sam : (long)dKA * a.sak, dPB = BNF ? (long)dKB * a.sbk : 64 * a.sbn;
+    unsigned stA = 0, stB = 0;
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int le = eA0 + dEA * u, ge = m0 + le;
+        const bool exists = AK ? le < BM : le < BM && kA0 + dKA * u < 16;
+        const bool inside = AK ? ge < a.M : ge + 3 < a.M, outside = ge >= a.M + (ones ? 1 : 0);
+        stA |= (unsigned)(!exists ? 3 : (inside && a.avec) ? 1 : outside ? 0 : 2) << (2 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int le = eB0 + dEB * u, ge = n0 + le;
+        const bool exists = BNF ? le < BN && kB0 + dKB * u < 16 : le < BN;
+        const bool inside = BNF ? ge + 3 < a.N : ge < a.N, outside = ge >= a.N;
+        stB |= (unsigned)(!exists ? 3 : (inside && a.bvec) ? 1 : outside ? 0 : 2) << (2 * u);
+    }
+    const long stepA = 16 * a.sak, stepB = 16 * a.sbk;
+    float4 ra[NA], rb[NB];
+    // the quads of the k-step at k0 (full: all 16 k's exist); the pointers move on to the next k-step
+    auto fetch = [&](int k0, bool full) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const unsigned st = (stA >> (2 * u)) & 3u;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st == 1 && full) t = *(const float4*)(pA + u * dPA);
+            else if (st == 2 || (st == 1 && !full)) t = gemm_f32_slow_quad(a.A, a.sam, a.sak, m0 + eA0 + dEA * u, k0 + kA0 + dKA * u, a.M, k_end, AK, ones);
+            ra[u] = t;
+        }
+        pA += stepA;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const unsigned st = (stB >> (2 * u)) & 3u;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st == 1 && full) t = *(const float4*)(pB + u * dPB);
+            else if (st == 2 || (st == 1 && !full)) t = gemm_f32_slow_quad(a.B, a.sbn, a.sbk, n0 + eB0 + dEB * u, k0 + kB0 + dKB * u, a.N, k_end, !BNF, false);
+            if (a.brow_scale && st != 3) {      // row k of op(B) counts with weight brow_scale[k] (wave-uniform branch)
+                const int gk = k0 + kB0 + dKB * u;
+                if (BNF) { const float w = gk < k_end ? a.brow_scale[gk] : 0.0f; t.x *= w; t.y *= w; t.z *= w; t.w *= w; }
+                else {
+                    t.x *= gk < k_end ? a.brow_scale[gk] : 0.0f; t.y *= gk + 1 < k_end ? a.brow_scale[gk + 1] : 0.0f;
+                    t.z *= gk + 2 < k_end ? a.brow_scale[gk + 2] : 0.0f; t.w *= gk + 3 < k_end ? a.brow_scale[gk + 3] : 0.0f;
+                }
+            }
+            rb[u] = t;
+        }
+        pB += stepB;
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) if (((stA >> (2 * u)) & 3u) != 3u) *(float4*)&sA[buf][oA0 + dOA * u] = ra[u];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) if (((stB >> (2 * u)) & 3u) != 3u) *(float4*)&sB[buf][oB0 + dOB * u] = rb[u];
+    };
+    // ---- fragment addresses of the lane: tile t of the wave's TM (TN) tiles, step j
+    const int arow = 16 * TM * wm + r16, brow = 16 * TN * wn + r16;
+    const int afr = AK ? arow * 16 + ((q ^ gemm_swz16(r16)) << 2) : 4 * q * PA + arow;      // (+ 16 * 16 t | + 16 t, + j * PA)
+    const int bfr = BNF ? 4 * q * PB + brow : brow * 16 + ((q ^ gemm_swz16(r16)) << 2);
+    auto frag_a = [&](const float* As, int t, float (&v)[4]) {
+        if (AK) { const float4 x = *(const float4*)(As + afr + 256 * t); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = As[afr + 16 * t + j * PA];
+        }
+    };
+    auto frag_b = [&](const float* Bs, int t, float (&v)[4]) {
+        if (BNF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = Bs[bfr + 16 * t + j * PB];
+        } else { const float4 x = *(const float4*)(Bs + bfr + 256 * t); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+    };
+    auto compute = [&](int buf) {
+        const float *As = sA[buf], *Bs = sB[buf];
+        if constexpr (HOLD_A) {
+            float ah[TM][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) frag_a(As, i, ah[i]);
+            constexpr int NG = (TN + 1) / 2;
+            float cur[2][4], nxt[2][4];
+            frag_b(Bs, 0, cur[0]);
+            if (TN > 1) frag_b(Bs, 1, cur[1]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) { frag_b(Bs, 2 * g + 2, nxt[0]); if (2 * g + 3 < TN) frag_b(Bs, 2 * g + 3, nxt[1]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (2 * g + h < TN) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) acc[i][2 * g + h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[i][j], cur[h][j], acc[i][2 * g + h], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cur[h][j] = nxt[h][j];
+            }
+        } else {
+            float bh[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) frag_b(Bs, j, bh[j]);
+            constexpr int NG = (TM + 1) / 2;
+            float cur[2][4], nxt[2][4];
+            frag_a(As, 0, cur[0]);
+            if (TM > 1) frag_a(As, 1, cur[1]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) { frag_a(As, 2 * g + 2, nxt[0]); if (2 * g + 3 < TM) frag_a(As, 2 * g + 3, nxt[1]); }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (2 * g + h < TM) {
+#pragma unroll
+                            for (int n = 0; n < TN; ++n) acc[2 * g + h][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[h][j], bh[n][j], acc[2 * g + h][n], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cur[h][j] = nxt[h][j];
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NA; ++u) ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k_beg < k_end) fetch(k_beg, k_beg + 16 <= k_end);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+#ifdef IWAE_DIAG
+#define GEMM_DBG(bit) (a.dbg & (bit))
+#else
+#define GEMM_DBG(bit) false
+#endif
+    for (int k0 = k_beg; k0 < k_end; k0 += 16) {
+        const bool more = k0 + 16 < k_end;
+        if (more && !GEMM_DBG(1)) fetch(k0 + 16, k0 + 32 <= k_end);
+        if (!GEMM_DBG(4)) compute(buf);
+        if (more && !GEMM_DBG(2)) stash(buf ^ 1);
+        if (!GEMM_DBG(16)) __syncthreads();
+        if (!GEMM_DBG(8)) buf ^= 1;
+    }
+    if constexpr (TM == 4 && TN == 4) {
+    if (a.epi == GEMM_EPI_BERN) {       // the output layer: log p(x|z) of this half tile's 64 columns per row, no logits in HBM (see gemm_f32_big_kernel)
+        float bias4[4];
+        bool nok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 64 * wn + 16 * j + r16;
+            nok[j] = n < a.N;
+            bias4[j] = (nok[j] && a.bias) ? a.bias[n] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * q + r;
+                const int mc = min(m, a.M - 1);
+                const float* xr = a.XB + (size_t)(mc / a.bern_k) * a.bern_X;
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (nok[j]) {
+                        const float l = acc[i][j][r] + bias4[j];
+                        const float xv = xr[n0 + 64 * wn + 16 * j + r16];
+                        const float e = __expf(-fabsf(l)), ope = 1.0f + e;
+                        sum += xv * l - (fmaxf(l, 0.0f) + __logf(ope));      // iwae1.py:111
+                        if (a.C && m < a.M) a.C[(size_t)m * a.ldc + n0 + 64 * wn + 16 * j + r16] = xv - (l >= 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(ope);
+                    }
+                }
+                sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+                if (r16 == 0 && m < a.M) a.part[(size_t)(2 * blockIdx.x + wn) * a.part_stride + m] = sum;
+            }
+        return;
+    }
+    }
+    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+    if (a.cvec) {      // every row of C (and of ACT, the bias) is 16-byte aligned, N is a multiple of 4: transposed tiles, 16-byte accesses
+        const int p = lane & 3, cq = 4 * (r16 >> 2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + 16 * TM * wm + 16 * i + 4 * q + p;           // the lane's row behind the transposition
+            const float rs = (a.orow_scale && m < a.M) ? a.orow_scale[m] : 1.0f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + 16 * TN * wn + 16 * j + cq;              // its four columns n .. n + 3
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                quad_transpose(v, lane);
+                if (n >= a.N) continue;
+                if (m >= a.M) {
+                    if (a.Cones && m == a.M) *(float4*)(a.Cones + (size_t)blockIdx.z * a.cones_stride + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    continue;
+                }
+                if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (a.orow_scale) { v[0] *= rs; v[1] *= rs; v[2] *= rs; v[3] *= rs; }
+                if (a.epi == GEMM_EPI_TANH) { v[0] = tanh_f32(v[0]); v[1] = tanh_f32(v[1]); v[2] = tanh_f32(v[2]); v[3] = tanh_f32(v[3]); }
+                else if (a.epi == GEMM_EPI_EXP) { v[0] = expf(v[0]) + 1e-6f; v[1] = expf(v[1]) + 1e-6f; v[2] = expf(v[2]) + 1e-6f; v[3] = expf(v[3]) + 1e-6f; }
+                else if (a.epi == GEMM_EPI_DTANH) {
+                    const float4 y = *(const float4*)(a.ACT + (size_t)m * a.ldact + n);
+                    v[0] *= 1.0f - y.x * y.x; v[1] *= 1.0f - y.y * y.y; v[2] *= 1.0f - y.z * y.z; v[3] *= 1.0f - y.w * y.w;
+                }
+                float4* dst = (float4*)(C + (size_t)m * a.ldc + n);
+                if (a.accumulate) { const float4 o = *dst; v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *dst = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + 16 * TN * wn + 16 * j + r16;
+            if (n >= a.N) continue;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * TM * wm + 16 * i + 4 * q + r;
+                if (m >= a.M) {
+                    if (a.Cones && m == a.M) a.Cones[(size_t)blockIdx.z * a.cones_stride + n] = acc[i][j][r];
+                    continue;
+                }
+                float v = acc[i][j][r] + bias;
+                if (a.orow_scale) v *= a.orow_scale[m];
+                if (a.epi == GEMM_EPI_TANH) v = tanh_f32(v);
+                else if (a.epi == GEMM_EPI_EXP) v = expf(v) + 1e-6f;
+                else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n]; v *= 1.0f - y * y; }
+                float* dst = C + (size_t)m * a.ldc + n;
+                *dst = a.accumulate ? *dst + v : v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------
 // dec_fwd_f32_kernel (round 4): the WHOLE decoder forward in float32 -- z -> tanh -> tanh -> logits -> log p(x|z) (src/iwae1.py:79-85,111) --
 // in one launch, row-block stationary like the bf16 path's decoder kernel.  Before: three launches of the generic GEMM (88 TFLOP/s on the
 // 784-wide product, 53 on the 200-wide ones: tiles of 7-13 k-steps pay their prologue, epilogue and a float32 round trip of every activation
@@ -710,6 +1027,8 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
     hipLaunchKernelGGL(concat_f32_kernel, dim3((unsigned)(((size_t)rows * (na + nb) + 255) / 256)), dim3(256), 0, st, a, na, b, nb, rows, out);
 }
 
+int g_gemm_f32_dbg = 0;
+bool g_gemm_f32_v2 = true;      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
 // Tile choice of the big kernel: the candidate with the least padded area (ties: the 128 x 128 tile); returns its workgroup count per K split
 static long gemm_f32_pick(int M, int N, int& bm, int& bn) {
     const int cand[3][2] = {{128, 128}, {64, 224}, {224, 64}};
@@ -732,10 +1051,14 @@ bool gemm_f32_takes_big(int M, int N, int nsplit) {
 }
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;
+    a.dbg = g_gemm_f32_dbg;
     // float4 fetches where every quad is 16-byte aligned: base pointer, the non-unit stride and the k-chunk offsets
     const long a_str = a.sak == 1 ? a.sam : a.sak, b_str = a.sbn == 1 ? a.sbk : a.sbn;
     a.avec = (((uintptr_t)a.A & 15) == 0 && a_str % 4 == 0 && (a.sak == 1 || a.sam == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
     a.bvec = (((uintptr_t)a.B & 15) == 0 && b_str % 4 == 0 && (a.sbn == 1 || a.sbk == 1) && (nsplit == 1 || a.kchunk % 4 == 0)) ? 1 : 0;
+    a.cvec = (a.N % 4 == 0 && ((uintptr_t)a.C & 15) == 0 && a.ldc % 4 == 0 && a.slab_stride % 4 == 0 && (!a.bias || ((uintptr_t)a.bias & 15) == 0) &&
+              (a.epi != GEMM_EPI_DTANH || (((uintptr_t)a.ACT & 15) == 0 && a.ldact % 4 == 0)) &&
+              (!a.Cones || (((uintptr_t)a.Cones & 15) == 0 && a.cones_stride % 4 == 0))) ? 1 : 0;
     // 128 x 128 tiles wherever both extents exceed one 64-tile (the per-sample layers, the weight gradients); the small kernel for the
     // rest (few images, narrow heads: a 128-tile would be mostly padding)
     // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
@@ -745,9 +1068,17 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
         if (a.epi != GEMM_EPI_BERN) gemm_f32_pick(a.M, a.N, bm, bn);      // (the Bernoulli epilogue's partial sums are per 64-column half of a 128-tile)
         const dim3 grid((a.N + bn - 1) / bn, (Mg + bm - 1) / bm, nsplit);
         const bool ak = a.sak == 1, bnf = a.sbn == 1;
+        // (the v2 loop wants unit strides on the fast index of each operand -- every caller's are -- and falls back to the old kernel otherwise)
+        const bool v2 = g_gemm_f32_v2 && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1);
 #define IWAE_F32_BIG(TM, TN)                                                                                             \
         do {                                                                                                             \
-            if (ak && bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);     \
+            if (v2) {                                                                                                    \
+                if (ak && bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);  \
+                else if (ak) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, a);   \
+                else if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, a);  \
+                else hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, a);          \
+            }                                                                                                            \
+            else if (ak && bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);     \
             else if (ak) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, a);      \
             else if (bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, a);     \
             else hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, a);             \

@@ -344,6 +344,7 @@ struct GemmF32Args {
     int accumulate;                       // C += instead of C =
     int kchunk; size_t slab_stride;       // K split over blockIdx.z: split z covers kchunk k's and writes C + z*slab_stride
     int avec, bvec;                       // set by launch_gemm_f32: the operand's quads may be fetched as float4
+    int cvec;                             // ... and C (bias, ACT, Cones) may be accessed as float4 (gemm_f32_v2_kernel's transposed epilogue)
     // GEMM_EPI_BERN (128-tile kernel only, forward-only calls): the logits are not stored; every 64-column half tile leaves its partial
     // log p(x|z) = sum_n x_n l_n - softplus(l_n) per row in part[(2 * column tile + half) * part_stride + m]; lse_kernel adds them in fixed order
     const float* XB; int bern_k, bern_X;  // x [B][bern_X] float32 in {0,1}; row m belongs to image m / bern_k
@@ -355,6 +356,7 @@ struct GemmF32Args {
     // weight gradients: op(A) = X^T gets one more row m == M of ONES, whose product row -- the column sums of op(B), i.e. the bias gradient --
     // goes to Cones[z * cones_stride + n] instead of C (round 3: no separate pass over G for the bias gradients)
     float* Cones; size_t cones_stride;
+    int dbg;                              // diagnostic builds (DIAG=1) only: timing ablations of gemm_f32_v2_kernel (option f32_gemm_dbg; results wrong)
 };
 // dec_fwd_f32_kernel: the decoder forward in float32 in ONE launch (z -> tanh -> tanh -> logits -> log p(x|z)), rows stationary
 struct DecFwdF32Args {
@@ -373,6 +375,8 @@ void launch_dec_fwd_f32(const DecFwdF32Args& a, hipStream_t st);
 long gemm_f32_tiles(int M, int N);                       // output tiles of the kernel launch_gemm_f32 takes for an M x N product
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
+extern int g_gemm_f32_dbg;
+extern bool g_gemm_f32_v2;                               // false: gemm_f32_big_kernel (the round-3 k loop) instead of gemm_f32_v2_kernel
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
 // every slab sum of a float32 step in one launch (round 5): out[i] = sum over the job's slabs, i < n; block_begin is filled by the launcher
 #define REDUCE_SLABS_MAX_JOBS 40

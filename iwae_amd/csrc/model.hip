@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <random>
 #include <memory>
 #include <dlfcn.h>
@@ -139,8 +140,11 @@ struct iwae_model {
     struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat; } f32;
     // float32 weight gradients of a step keep their row-split slabs (each in its own region of f32.slab) and are summed by ONE launch at the end of
     // backward_f32 (reduce_slabs_multi_f32_kernel): jobs queued by f32_dw, slab offsets in floats (the buffer may still grow while they queue)
-    struct F32Pending { size_t off; size_t stride; size_t n; float* out; int nsplit; };
+    struct F32Pending { size_t off; size_t stride; size_t n; float* out; int nsplit; int seg; };
     std::vector<F32Pending> f32_pending; size_t f32_slab_used = 0; bool allow_f32_multi_reduce = true;
+    bool allow_f32_side = true, f32_side_active = false, f32_wout_first = false;      // float32 step: the decoder's weight gradients + update on the side stream (options no_f32_side, f32_wout_first)
+    bool f32_z_pending = false;
+    bool bf16_side_used = false;      // a bf16 call may have left a speculative draw on a side stream (forward_f32 waits for it on the host)
     size_t f32_slab_want = 0, f32_slab_want_step = 0;      // floats of slabs the last whole step asked for (the buffer's target size) / this step so far
     int eval_tag_kill = -1;
     int eval_k_total = 0, eval_s_off = 0;     // > 0 while iwae_eval_llh walks an image's samples in chunks (eps_src)
@@ -875,6 +879,8 @@ int forward_impl(iwae_model* m, const float* x, int B, int k, float beta, const 
     if ((int64_t)B * k > (int64_t)1 << 30) return fail(IWAE_ERR_ARG, "forward: B*k too large");
     const bool two = m->cfg.n_layers == 2;
     m->B = B; m->k = k; m->M = B * k; m->beta = beta;
+    m->bf16_side_used = true;
+    if (m->f32_z_pending) { HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0)); m->f32_z_pending = false; }      // (ev_join is this path's too)
     m->lse_pending = false;      // (set again below if this step leaves its log-mean-exp to the backward pass)
     m->time_this = m->timing > 0 && (m->timing_calls++ % m->timing) == 0;
     m->Mp = round_up(m->M, 128); m->Bp = round_up(B, 128);
@@ -1763,13 +1769,14 @@ int adam_impl(iwae_model* m, float lr, float gscale) {
 // path with plain row-major float32 tensors and one generic MFMA GEMM (fp32_kernels.hip); the per-sample kernels that already
 // work in float32 (sampling + densities, lse_kernel, latent_bwd_kernel, gauss_*_kernel, Adam) are shared.
 int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc, int M, int N, int K,
-             const float* bias, int epi, const float* ACT, long ldact, bool accumulate, const float* brow_scale = nullptr, const float* orow_scale = nullptr) {
+             const float* bias, int epi, const float* ACT, long ldact, bool accumulate, const float* brow_scale = nullptr, const float* orow_scale = nullptr,
+             hipStream_t st = nullptr) {
     GemmF32Args a;
     memset(&a, 0, sizeof(a));
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.epi = epi; a.ACT = ACT; a.ldact = ldact; a.accumulate = accumulate ? 1 : 0; a.kchunk = K; a.slab_stride = 0;
     a.brow_scale = brow_scale; a.orow_scale = orow_scale;
-    launch_gemm_f32(a, 1, m->stream);
+    launch_gemm_f32(a, 1, st ? st : m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
@@ -1784,36 +1791,44 @@ int f32_dx(iwae_model* m, const KerasLayer& kl, const float* G, long ldg, int ro
     return f32_gemm(m, G, ldg, 1, m->param + kl.offW, 1, kl.Nout, DX, lddx, rows, kl.Kin, kl.Nout, nullptr, ACT ? GEMM_EPI_DTANH : GEMM_EPI_NONE, ACT, ldact, accumulate,
                     nullptr, rowscale);
 }
-// the queued slab sums of this step's float32 weight gradients, one launch (f32_dw)
-int f32_flush_reductions(iwae_model* m) {
-    if (!m->f32_pending.empty()) {
+// the queued slab sums of this step's float32 weight gradients, one launch per segment (f32_dw): seg 0 = the gradients made on the main stream,
+// seg 1 = the decoder's, made on the side stream (backward_f32); seg < 0: whatever is queued, each segment on its own stream
+int f32_flush_reductions(iwae_model* m, int seg = -1) {
+    for (int sg = 0; sg < 2; ++sg) {
+        if (seg >= 0 && sg != seg) continue;
         ReduceSlabsJobs jobs;
         memset(&jobs, 0, sizeof(jobs));
         for (const auto& p : m->f32_pending) {
+            if (p.seg != sg) continue;
             ReduceSlabsJob& j = jobs.job[jobs.n++];
             j.slabs = ptr<float>(m->f32.slab) + p.off; j.stride = p.stride; j.n = p.n; j.out = p.out; j.nsplit = p.nsplit;
         }
-        launch_reduce_slabs_multi_f32(jobs, m->stream);
-        HIPCHK(hipGetLastError());
-        m->f32_pending.clear();
+        if (jobs.n > 0) {
+            launch_reduce_slabs_multi_f32(jobs, sg == 1 ? m->side : m->stream);
+            HIPCHK(hipGetLastError());
+        }
     }
-    m->f32_slab_used = 0;
+    if (seg < 0) m->f32_pending.clear();
+    else m->f32_pending.erase(std::remove_if(m->f32_pending.begin(), m->f32_pending.end(), [seg](const iwae_model::F32Pending& p) { return p.seg == seg; }), m->f32_pending.end());
+    if (m->f32_pending.empty()) m->f32_slab_used = 0;
     return IWAE_OK;
 }
 // grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
 // (rowscale: G's row r is multiplied by rowscale[r] as it is fetched -- the values the separate g_r s pass used to store)
-int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr) {
+int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr, int seg = 0) {
+    hipStream_t st = seg == 1 ? m->side : m->stream;
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
     const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout);      // (+ 1: the row of ones whose product row is the bias gradient)
-    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), (m->f32_dw_tiles + tiles - 1) / tiles));
+    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), m->f32_dw_tiles / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     // (round 5: the slabs of every gradient of the step stay until ONE reduction launch at the end of the backward pass; the buffer is sized for a
     // whole step -- a step that outgrows it falls back to the reduction per tensor, and the buffer grows for the next step)
-    const size_t need = (size_t)nsplit * (nW + kl.Nout);
+    const size_t need = ((size_t)nsplit * (nW + kl.Nout) + 3) & ~(size_t)3;      // (a multiple of 4 floats: the next gradient's slabs stay 16-byte aligned)
     const bool queue = m->allow_f32_multi_reduce && nsplit > 1 && (m->f32_slab_used + need) * 4 <= m->f32.slab.cap && m->f32_pending.size() + 2 <= REDUCE_SLABS_MAX_JOBS;
     if (!queue) {
         if (!m->f32_pending.empty()) CHK(f32_flush_reductions(m));      // (queued jobs still read the buffer ensure() may replace)
-        CHK(ensure(m->f32.slab, std::max(need, m->f32_slab_want) * 4, m->stream));
+        if (m->f32_side_active) { HIPCHK(hipStreamSynchronize(m->side)); HIPCHK(hipStreamSynchronize(m->stream)); }      // (first steps only: the buffer is still growing)
+        CHK(ensure(m->f32.slab, std::max(need, m->f32_slab_want) * 4, st));
     }
     m->f32_slab_want_step += need;
     float* slabW = ptr<float>(m->f32.slab) + (queue ? m->f32_slab_used : 0);
@@ -1827,17 +1842,18 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     // the bias gradient = the column sums of (weighted) G = the product row of a row of ONES appended to X^T (GemmF32Args.Cones): no pass of its own
     if (ns == 1) {
         a.C = m->grad + kl.offW; a.ldc = kl.Nout; a.slab_stride = 0; a.Cones = m->grad + kl.offb; a.cones_stride = 0;
-        launch_gemm_f32(a, 1, m->stream);
+        launch_gemm_f32(a, 1, st);
     } else {
         a.C = slabW; a.ldc = kl.Nout; a.slab_stride = nW; a.Cones = slabB; a.cones_stride = (size_t)kl.Nout;
-        launch_gemm_f32(a, ns, m->stream);
+        launch_gemm_f32(a, ns, st);
         if (queue) {
-            m->f32_pending.push_back({(size_t)(slabW - ptr<float>(m->f32.slab)), nW, nW, m->grad + kl.offW, ns});
-            m->f32_pending.push_back({(size_t)(slabB - ptr<float>(m->f32.slab)), (size_t)kl.Nout, (size_t)kl.Nout, m->grad + kl.offb, ns});
+            m->f32_pending.push_back({(size_t)(slabW - ptr<float>(m->f32.slab)), nW, nW, m->grad + kl.offW, ns, seg});
+            m->f32_pending.push_back({(size_t)(slabB - ptr<float>(m->f32.slab)), (size_t)kl.Nout, (size_t)kl.Nout, m->grad + kl.offb, ns, seg});
             m->f32_slab_used += need;
         } else {
-            launch_reduce_slabs_f32(slabW, nW, ns, nW, m->grad + kl.offW, m->stream);
-            launch_reduce_slabs_f32(slabB, kl.Nout, ns, kl.Nout, m->grad + kl.offb, m->stream);
+            launch_reduce_slabs_f32(slabW, nW, ns, nW, m->grad + kl.offW, st);
+            launch_reduce_slabs_f32(slabB, kl.Nout, ns, kl.Nout, m->grad + kl.offb, st);
+            if (m->f32_side_active) { HIPCHK(hipStreamSynchronize(st)); }      // (the next unqueued gradient reuses the buffer's front from another stream)
         }
     }
     HIPCHK(hipGetLastError());
@@ -1894,13 +1910,17 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     m->time_this = false;
     const int M = m->M, Mp = m->Mp, Bp = m->Bp, X = m->X;
     hipStream_t st = m->stream;
-    CHK(join_side(m));
+    if (m->bf16_side_used) {      // a bf16 call's deferred update / speculative draw may sit on either side stream
+        CHK(join_side(m));
+        if (m->side) HIPCHK(hipStreamSynchronize(m->side));
+        if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));
+        m->bf16_side_used = false;
+    }
+    // (a float32 step's own deferred decoder update is joined in front of the decoder forward: the encoder and the sampling run beside it)
     m->user_eps = eps != nullptr;
     m->epsc_ptr[0] = m->epsc_ptr[1] = nullptr;
     if (!eps) {       // the step's draws, kept for the backward pass and the 2-layer densities (same generator as the bf16 path)
         const int np = (m->epsc_par + 1) % 3;
-        if (m->side) HIPCHK(hipStreamSynchronize(m->side));
-        if (m->side2) HIPCHK(hipStreamSynchronize(m->side2));      // (a bf16 step's speculative draw may sit on either side stream)
         CHK(draw_eps(m, np, m->noise_step, M, st));
         if (m->eval_k_total > 0) m->eps_tag[np].valid = false;      // a k-chunk's draws: the tag (step, offset, rows) does not describe them
         if (bwd) m->epsc_par = np;      // (forward-only calls reuse one slot, as in forward_impl)
@@ -1941,6 +1961,10 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     float* lqd = ptr<float>(m->rows[5]);
     // ---- z (z1) = mu + sigma*eps and its densities (iwae1.py:59,107,109)
     const int Dz = m->D[0] + m->C;      // row width of the decoder's input: z, or concat(z, y) (tasks/task05.py:185)
+    if (m->f32_z_pending) {      // the previous step's gradient of the decoder's first layer reads z on the side stream
+        HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+        m->f32_z_pending = false;
+    }
     CHK(ensure(m->f32.z[0], (size_t)Mp * Dz * 4, st));
     {
         SampleArgs s;
@@ -1981,6 +2005,7 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     const int b_dec1 = m->dec1[0].sub[0];
     const KerasLayer *d1 = &m->klayers[b_dec1], *d2 = d1 + 1, *d3 = d1 + 2;
     const int H = d1->Nout;
+    CHK(join_side(m));      // the decoder's parameters (and g1, g2, s, which the previous step's weight gradients still read)
     // Round 4: the whole decoder forward in ONE launch where its shapes fit (dec_fwd_f32_kernel: rows stationary, activations in LDS, the
     // weights streamed from the float32 master parameters; log p(x|z) per row comes out whole) -- the k = 5000 evaluator's three GEMM launches
     // ran at 0.35 of the f32 MFMA peak between them.  A training step also keeps g1, g2 and s = x - sigmoid(l) for the backward pass.
@@ -2083,7 +2108,13 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
 }
 
 // closed-form backward in float32: leaves the flat gradient in m->grad
-int backward_f32(iwae_model* m, int objective) {
+// Round 5: two streams.  The decoder's three weight gradients (58 % of the backward pass's FLOPs, needed by nobody until the update) go to the
+// side stream: the hidden layers' behind the dX product that makes their operand, the output layer's LAST -- it needs only s, g2 and the
+// row weights, so it is what runs beside the main stream's few-row tail (dz, the latent sums, the encoder's seven launches on the batch's
+// images: 64 workgroups each on 256 CUs).  fused_lr >= 0 (the single-GPU train step): the update is part of it -- the encoder's
+// layers on the main stream, the decoder's on the side stream behind its own slab reduction, DEFERRED: the next step's encoder forward
+// and sampling run beside the output layer's gradient, and forward_f32 joins (ev_dec) in front of the decoder forward.
+int backward_f32(iwae_model* m, int objective, float fused_lr = -1.0f) {
     m->f32_slab_want_step = 0;
     if (!m->have_forward || !m->fwd_was_f32) return fail(IWAE_ERR_STATE, "backward without a float32 forward");
     const bool two = m->cfg.n_layers == 2;
@@ -2099,11 +2130,26 @@ int backward_f32(iwae_model* m, int objective) {
     CHK(ensure(m->f32.d2, (size_t)M * H * 4, st));
     CHK(ensure(m->f32.d1, (size_t)M * H * 4, st));
     CHK(ensure(m->wdec1.dz, (size_t)Mp * Dp0 * 4, st));
-    CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw));
+    if (m->descs_dirty) CHK(build_descs(m));
+    // (the conditional prior's block sits BEHIND the decoder in the flat parameters: its gradient is made on the main stream -- one stream for that model)
+    const bool use_side = m->allow_f32_side && m->side && !m->has_prior && M >= 4096 && b_dec1 + 3 == (int)m->klayers.size();
+    m->f32_side_active = use_side;
+    const int sg = use_side ? 1 : 0;
+    if (use_side) {
+        HIPCHK(hipEventRecord(m->ev_fork, st));      // s, g1, g2, z, the row weights
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        if (m->f32_wout_first) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
+    } else {
+        CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw));
+    }
     CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false, rw));
-    CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M));
+    if (use_side) { HIPCHK(hipEventRecord(m->ev_fork2, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0)); }
+    CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M, nullptr, sg));
     CHK(f32_dx(m, *d2, ptr<float>(m->f32.d2), H, M, ptr<float>(m->f32.d1), H, ptr<float>(m->f32.g1), H, false));
-    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M));
+    if (use_side) { HIPCHK(hipEventRecord(m->ev_blk, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0)); }
+    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M, nullptr, sg));
+    if (use_side) { HIPCHK(hipEventRecord(m->ev_join, m->side)); m->f32_z_pending = true; }      // (z is free for the next step's sampling)
+    if (use_side && !m->f32_wout_first) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
     CHK(f32_dx(m, *d1, ptr<float>(m->f32.d1), H, M, ptr<float>(m->wdec1.dz), Dp0, nullptr, 0, false));
     const float *dz1_b = nullptr, *dz1_c = nullptr;
     if (two) {
@@ -2157,10 +2203,25 @@ int backward_f32(iwae_model* m, int objective) {
     if (m->has_prior)
         CHK(f32_block_bwd(m, m->prior[0].sub[0], m->f32.prior, ptr<float>(m->cond) + (size_t)m->cond_row0 * m->C, m->C, B, Dp0, nullptr, 0));
     CHK(f32_block_bwd(m, m->enc1[0].sub[0], m->f32.enc1, m->C > 0 ? ptr<float>(m->f32.xcat) : m->f32_x, X + m->C, B, Dp0, nullptr, 0));
-    CHK(f32_flush_reductions(m));      // every row-split gradient's slabs -> the flat gradient, one launch
     m->f32_slab_want = std::max(m->f32_slab_want, m->f32_slab_want_step);
-    HIPCHK(hipGetLastError());
     m->split_offset = m->nparam;       // (data-parallel step: one all-reduce of the whole gradient)
+    if (!use_side) {
+        CHK(f32_flush_reductions(m));      // every row-split gradient's slabs -> the flat gradient, one launch
+        if (fused_lr >= 0.0f) CHK(adam_impl(m, fused_lr, 1.0f));
+        HIPCHK(hipGetLastError());
+        return IWAE_OK;
+    }
+    const int b0 = m->descs[b_dec1].block_begin;
+    const float alpha = fused_lr >= 0.0f ? adam_alpha(m, fused_lr) : 0.0f;
+    CHK(f32_flush_reductions(m, 0));       // the slabs of the main stream's gradients (every block but the decoder)
+    if (fused_lr >= 0.0f)
+        launch_adam(m->d_descs, (int)m->descs.size(), b0, m->param, m->grad, m->mom, m->vel, alpha, 1.0f, m->adam_b1, m->adam_b2, m->adam_eps, 1, st, 0);
+    CHK(f32_flush_reductions(m, 1));       // the decoder's, on the side stream
+    if (fused_lr >= 0.0f)
+        launch_adam(m->d_descs, (int)m->descs.size(), m->elem_blocks - b0, m->param, m->grad, m->mom, m->vel, alpha, 1.0f, m->adam_b1, m->adam_b2, m->adam_eps, 1, m->side, b0);
+    HIPCHK(hipEventRecord(m->ev_dec, m->side));
+    m->dec_pending = true;                 // (join_side: whoever reads the decoder's gradient or parameters next)
+    HIPCHK(hipGetLastError());
     return IWAE_OK;
 }
 
@@ -2518,6 +2579,7 @@ int iwae_forward_backward_split(iwae_handle m, const float* x, int32_t B, int32_
     if (m->cfg.precision == IWAE_PREC_FP32) {       // float32 mode: nothing is left on the side stream (*side_offset = n)
         CHK(forward_f32(m, x, B, k, beta, eps, objective, true, nullptr));
         CHK(backward_f32(m, objective));
+        CHK(join_side(m));
     } else {
         CHK(forward_impl(m, x, B, k, beta, eps, objective, true, nullptr));
         CHK(backward_impl(m, objective, -1.0f, true));
@@ -2572,6 +2634,10 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
+    else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_gemm_v1") g_gemm_f32_v2 = !on;                  // float32 GEMMs with the round-3 k loop (process-wide switch, A/B only)
+    else if (n == "no_f32_side") m->allow_f32_side = !on;             // float32 step on one stream (no side-stream weight gradients, no deferred decoder update)
+    else if (n == "f32_wout_first") m->f32_wout_first = on;           // ... with the output layer's gradient first on the side stream instead of last
     else if (n == "no_f32_multi_reduce") m->allow_f32_multi_reduce = !on;      // float32 mode: a slab reduction launch per gradient tensor instead of one per step
     else if (n == "no_f32_dec_fused") m->allow_f32_dec_fused = !on;   // float32 mode: the decoder forward as three GEMM launches
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
@@ -2642,10 +2708,14 @@ int iwae_train_step(iwae_handle m, const float* x, int32_t B, int32_t k, float b
     CHK(check_objective(m, objective));
     if (m->cfg.precision == IWAE_PREC_FP32) {   // float32 mode: forward, closed-form backward, [exchange,] Adam -- all in float32
         CHK(forward_f32(m, x, B, k, beta, eps, objective, true, want));
-        CHK(backward_f32(m, objective));
-        if (want) CHK(fetch_outputs(m, nullptr, want));
-        if (m->comm_main) CHK(dp_finish(m, lr));
-        else CHK(adam_impl(m, lr, 1.0f));
+        if (m->comm_main || want) {
+            CHK(backward_f32(m, objective));
+            if (want) CHK(fetch_outputs(m, nullptr, want));      // tensors refer to the pre-update forward (src/iwae1.py:162)
+            if (m->comm_main) CHK(dp_finish(m, lr));
+            else { CHK(join_side(m)); CHK(adam_impl(m, lr, 1.0f)); }
+        } else {
+            CHK(backward_f32(m, objective, lr));   // the update rides behind the gradients, the decoder's on the side stream (deferred)
+        }
         CHK(fetch_outputs(m, scalars, nullptr));
         m->noise_step += 1;
         return IWAE_OK;
