@@ -349,6 +349,19 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_big_kernel(GemmF32Args a) {  
 //     16-byte reads deliver) -- float32 results differ from gemm_f32_big_kernel's in the order of the sum only;
 //   * the operand with fewer MFMA tiles per wave is held in registers for the k-step, the other streams through two-tile groups read one group ahead.
 // ---------------------------------------------------------------------------------
+#ifdef IWAE_DENSE_STAMPS      // diagnostic build (STAMPS=1): per-wave cycle sums of the kernel's phases -> a.stamps[wave][8]
+#define GS_STAMP(slot)                                                                 \
+    {                                                                                  \
+        unsigned long long t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        gs_sum[slot] += t_ - gs_prev;                                                  \
+        gs_prev = t_;                                                                  \
+    }
+#else
+#define GS_STAMP(slot)
+#endif
 __device__ __forceinline__ int gemm_swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }      // (0, 2, 3, 1) for rows 0-3, 4-7, 8-11, 12-15 of a 16-row tile
 // a quad off the fast path: kfast: elements (e, k .. k + 3), else (e .. e + 3, k); zero outside the matrix / beyond k_end; `ones`: row e == Ext is all ones
 __device__ __forceinline__ float4 gemm_f32_slow_quad(const float* base, long s_e, long s_k, int e, int k, int Ext, int k_end, bool kfast, bool ones) {
@@ -382,9 +395,14 @@ __device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
         x[r] = ((r ^ p) & 2) ? o : t[r];
     }
 }
-template <int TM, int TN, bool AK, bool BNF>      // AK: op(A)'s k index is the unit-stride one; BNF: op(B)'s n index is
-__global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
-    constexpr int BM = 32 * TM, BN = 32 * TN;
+// WGM x WGN = the workgroup's waves (2 x 2: the tiles of gemm_f32_big_kernel; 4 x 2 / 2 x 4: 8 waves on a 128 x 224 / 224 x 128 tile).  The k loop is
+// bound by what a CU can request per clock (ablations, profiles/r05_f32_gemm_ablations.txt: the requests alone take as long as the MFMAs alone,
+// and the two overlap badly): a tile twice as tall moves 39 % fewer operand bytes per FLOP.
+template <int TM, int TN, int WGM, int WGN, bool AK, bool BNF>      // AK: op(A)'s k index is the unit-stride one; BNF: op(B)'s n index is
+__global__ __launch_bounds__(64 * WGM * WGN, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
+    constexpr int NT = 64 * WGM * WGN;
+    [[maybe_unused]] constexpr int NW = WGM * WGN;
+    constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
     constexpr int PA = AK ? 16 : BM + 4, PB = BNF ? BN + 4 : 16;                    // row pitch in LDS (floats)
     constexpr int SA = AK ? BM * 16 : 16 * PA, SB = BNF ? 16 * PB : BN * 16;        // floats per buffer
     constexpr int QM = BM / 4, QN = BN / 4;
@@ -392,9 +410,24 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
     __shared__ __attribute__((aligned(16))) float sA[2][SA];
     __shared__ __attribute__((aligned(16))) float sB[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int k_beg = blockIdx.z * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
-    const int wm = wave >> 1, wn = wave & 1;
+#ifdef IWAE_DENSE_STAMPS
+    unsigned long long gs_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_prev = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gs_prev)::"memory");
+#endif
+    // K-split launches: the output tiles of ONE split read the same rows of both operands -- workgroups go to the 8 XCDs round-robin by their linear
+    // index, so the index is re-read such that a split's tiles are neighbours on one XCD (its L2 then serves the re-reads: counters of the output
+    // layer's weight gradient had 505 MB fetched for 201 MB of operands, 13 column tiles of a split on 8 different L2s)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int nb = gridDim.x * gridDim.y * gridDim.z;
+        if (gridDim.z > 1 && (nb & 7) == 0) {
+            const int L = bx + gridDim.x * (by + gridDim.y * bz), V = (L & 7) * (nb >> 3) + (L >> 3);
+            bx = V % gridDim.x; by = (V / gridDim.x) % gridDim.y; bz = V / (gridDim.x * gridDim.y);
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int k_beg = bz * a.kchunk, k_end = min(a.K, k_beg + a.kchunk);
+    const int wm = wave / WGN, wn = wave % WGN;
     const int r16 = lane & 15, q = lane >> 4;
     f32x4v acc[TM][TN];
 #pragma unroll
@@ -406,18 +439,19 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
     //   otherwise:          k row = (256 / TPR) u + tid / TPR, e = 4 (tid % TPR) .. + 3    (TPR = threads per k row: the power of two >= E / 4)
     // -- either way quad u + 1 is a CONSTANT away from quad u, in memory and in LDS: one pointer, one LDS offset and two state bits per quad
     // (0 outside: zeros, 1 one 16-byte load, 2 element by element, 3 no such quad) are all a thread keeps per operand.
-    constexpr int TPRA = QM > 32 ? 64 : QM > 16 ? 32 : 16, TPRB = QN > 32 ? 64 : QN > 16 ? 32 : 16;
-    constexpr int NA = AK ? (BM + 63) / 64 : TPRA / 16, NB = BNF ? TPRB / 16 : (BN + 63) / 64;
+    constexpr int TPRA = QM > 32 ? 64 : QM > 16 ? 32 : 16, TPRB = QN > 32 ? 64 : QN > 16 ? 32 : 16;      // (with NT threads: NT / 4 rows, NT / TPR k rows per quad index)
+    constexpr int RQ = NT / 4, KRA = NT / TPRA, KRB = NT / TPRB;
+    constexpr int NA = AK ? (BM + RQ - 1) / RQ : (16 + KRA - 1) / KRA, NB = BNF ? (16 + KRB - 1) / KRB : (BN + RQ - 1) / RQ;
     const bool ones = a.Cones != nullptr;
     const int eA0 = AK ? tid >> 2 : 4 * (tid % TPRA), kA0 = AK ? 4 * (tid & 3) : tid / TPRA;
     const int eB0 = BNF ? 4 * (tid % TPRB) : tid >> 2, kB0 = BNF ? tid / TPRB : 4 * (tid & 3);
-    constexpr int dEA = AK ? 64 : 0, dKA = AK ? 0 : 256 / TPRA, dEB = BNF ? 0 : 64, dKB = BNF ? 256 / TPRB : 0;      // quad u -> u + 1
+    constexpr int dEA = AK ? RQ : 0, dKA = AK ? 0 : KRA, dEB = BNF ? 0 : RQ, dKB = BNF ? KRB : 0;      // quad u -> u + 1
     const int oA0 = AK ? eA0 * 16 + (((tid & 3) ^ gemm_swz16(eA0)) << 2) : kA0 * PA + eA0;
     const int oB0 = BNF ? kB0 * PB + eB0 : eB0 * 16 + (((tid & 3) ^ gemm_swz16(eB0)) << 2);
-    constexpr int dOA = AK ? 64 * 16 : dKA * PA, dOB = BNF ? dKB * PB : 64 * 16;
+    constexpr int dOA = AK ? RQ * 16 : dKA * PA, dOB = BNF ? dKB * PB : RQ * 16;
     const float* pA = a.A + (size_t)(m0 + eA0) * a.sam + (size_t)(k_beg + kA0) * a.sak;
     const float* pB = a.B + (size_t)(n0 + eB0) * a.sbn + (size_t)(k_beg + kB0) * a.sbk;
-    const long dPA = AK ? 64 * a.sam : (long)dKA * a.sak, dPB = BNF ? (long)dKB * a.sbk : 64 * a.sbn;
+    const long dPA = AK ? RQ * a.sam : (long)dKA * a.sak, dPB = BNF ? (long)dKB * a.sbk : RQ * a.sbn;
     unsigned stA = 0, stB = 0;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
@@ -434,7 +468,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
         stB |= (unsigned)(!exists ? 3 : (inside && a.bvec) ? 1 : outside ? 0 : 2) << (2 * u);
     }
     const long stepA = 16 * a.sak, stepB = 16 * a.sbk;
-    float4 ra[NA], rb[NB];
+    float4 ra[NA], rb[NB], rw[NB];
     // the quads of the k-step at k0 (full: all 16 k's exist); the pointers move on to the next k-step
     auto fetch = [&](int k0, bool full) {
 #pragma unroll
@@ -452,15 +486,16 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (st == 1 && full) t = *(const float4*)(pB + u * dPB);
             else if (st == 2 || (st == 1 && !full)) t = gemm_f32_slow_quad(a.B, a.sbn, a.sbk, n0 + eB0 + dEB * u, k0 + kB0 + dKB * u, a.N, k_end, !BNF, false);
-            if (a.brow_scale && st != 3) {      // row k of op(B) counts with weight brow_scale[k] (wave-uniform branch)
-                const int gk = k0 + kB0 + dKB * u;
-                if (BNF) { const float w = gk < k_end ? a.brow_scale[gk] : 0.0f; t.x *= w; t.y *= w; t.z *= w; t.w *= w; }
-                else {
-                    t.x *= gk < k_end ? a.brow_scale[gk] : 0.0f; t.y *= gk + 1 < k_end ? a.brow_scale[gk + 1] : 0.0f;
-                    t.z *= gk + 2 < k_end ? a.brow_scale[gk + 2] : 0.0f; t.w *= gk + 3 < k_end ? a.brow_scale[gk + 3] : 0.0f;
-                }
-            }
             rb[u] = t;
+            // row k of op(B) counts with weight brow_scale[k] (wave-uniform branch): the weights are REQUESTED here and multiplied in when the quads go
+            // to LDS -- multiplied here, the wait for a weight was a wait for every quad requested before it (vector-memory results return in order):
+            // the whole fetch latency sat in front of the k-step's MFMAs (phase stamps: 64 % of the output layer's weight gradient)
+            if (a.brow_scale && st != 3) {
+                const int gk = k0 + kB0 + dKB * u;
+                if (BNF) { const float w = gk < k_end ? a.brow_scale[gk] : 0.0f; rw[u] = make_float4(w, w, w, w); }
+                else rw[u] = make_float4(gk < k_end ? a.brow_scale[gk] : 0.0f, gk + 1 < k_end ? a.brow_scale[gk + 1] : 0.0f,
+                                         gk + 2 < k_end ? a.brow_scale[gk + 2] : 0.0f, gk + 3 < k_end ? a.brow_scale[gk + 3] : 0.0f);
+            }
         }
         pB += stepB;
     };
@@ -468,7 +503,12 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) if (((stA >> (2 * u)) & 3u) != 3u) *(float4*)&sA[buf][oA0 + dOA * u] = ra[u];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) if (((stB >> (2 * u)) & 3u) != 3u) *(float4*)&sB[buf][oB0 + dOB * u] = rb[u];
+        for (int u = 0; u < NB; ++u)
+            if (((stB >> (2 * u)) & 3u) != 3u) {
+                float4 t = rb[u];
+                if (a.brow_scale) { t.x *= rw[u].x; t.y *= rw[u].y; t.z *= rw[u].z; t.w *= rw[u].w; }
+                *(float4*)&sB[buf][oB0 + dOB * u] = t;
+            }
     };
     // ---- fragment addresses of the lane: tile t of the wave's TM (TN) tiles, step j
     const int arow = 16 * TM * wm + r16, brow = 16 * TN * wn + r16;
@@ -552,16 +592,64 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
 #else
 #define GEMM_DBG(bit) false
 #endif
+    GS_STAMP(0)      // set-up, first k-step's quads in LDS
     for (int k0 = k_beg; k0 < k_end; k0 += 16) {
         const bool more = k0 + 16 < k_end;
         if (more && !GEMM_DBG(1)) fetch(k0 + 16, k0 + 32 <= k_end);
+        GS_STAMP(1)      // requests of the next k-step
         if (!GEMM_DBG(4)) compute(buf);
-        if (more && !GEMM_DBG(2)) stash(buf ^ 1);
+        GS_STAMP(2)      // fragment reads + MFMAs issued
+        if (more && !GEMM_DBG(2)) {
+#ifdef IWAE_DENSE_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GS_STAMP(3)  // wait for the requested quads
+#endif
+            stash(buf ^ 1);
+        }
+        GS_STAMP(4)      // LDS stores
         if (!GEMM_DBG(16)) __syncthreads();
+        GS_STAMP(5)      // barrier
         if (!GEMM_DBG(8)) buf ^= 1;
     }
-    if constexpr (TM == 4 && TN == 4) {
+    if constexpr (TM == 4 && TN == 4 && WGM == 2 && WGN == 2) {
     if (a.epi == GEMM_EPI_BERN) {       // the output layer: log p(x|z) of this half tile's 64 columns per row, no logits in HBM (see gemm_f32_big_kernel)
+        // Transposed tiles (quad_transpose): a lane holds row 4q + p, columns 4c .. 4c + 3 of each of the wave's 4 x 4 tiles -- x, the bias and s = x - sigmoid(l)
+        // go as 16-byte accesses, the 16 logarithms of a lane's row as ONE log of the product of (1 + e^-|l|) <= 2^16, and the row's 64 columns
+        // meet across the four lanes c with two shuffles.
+        if (a.cvec && (a.bern_X & 3) == 0 && (((uintptr_t)a.XB) & 15) == 0) {
+            const int p = lane & 3, cq = 4 * (r16 >> 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * q + p;
+                const int mc = min(m, a.M - 1);
+                const float* xr = a.XB + (size_t)(mc / a.bern_k) * a.bern_X;
+                float sum = 0.0f, prod = 1.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + 64 * wn + 16 * j + cq;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    quad_transpose(v, lane);
+                    if (n < a.N) {
+                        const float4 b = a.bias ? *(const float4*)(a.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 x4 = *(const float4*)(xr + n);
+                        const float l4[4] = {v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+                        float s4[4];
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) {
+                            const float l = l4[e4], e = __expf(-fabsf(l)), ope = 1.0f + e;
+                            sum += xv[e4] * l - fmaxf(l, 0.0f);      // iwae1.py:111: x l - softplus(l) = x l - max(l, 0) - log(1 + e^-|l|)
+                            prod *= ope;
+                            s4[e4] = xv[e4] - (l >= 0.0f ? 1.0f : e) * __builtin_amdgcn_rcpf(ope);
+                        }
+                        if (a.C && m < a.M) *(float4*)(a.C + (size_t)m * a.ldc + n) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                    }
+                }
+                sum -= __logf(prod);
+                sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);      // the row's four column groups c sit on lanes 4c + p
+                if ((r16 >> 2) == 0 && m < a.M) a.part[(size_t)(2 * bx + wn) * a.part_stride + m] = sum;
+            }
+            return;
+        }
         float bias4[4];
         bool nok[4];
 #pragma unroll
@@ -589,12 +677,12 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
                     }
                 }
                 sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
-                if (r16 == 0 && m < a.M) a.part[(size_t)(2 * blockIdx.x + wn) * a.part_stride + m] = sum;
+                if (r16 == 0 && m < a.M) a.part[(size_t)(2 * bx + wn) * a.part_stride + m] = sum;
             }
         return;
     }
     }
-    float* C = a.C + (size_t)blockIdx.z * a.slab_stride;
+    float* C = a.C + (size_t)bz * a.slab_stride;
     if (a.cvec) {      // every row of C (and of ACT, the bias) is 16-byte aligned, N is a multiple of 4: transposed tiles, 16-byte accesses
         const int p = lane & 3, cq = 4 * (r16 >> 2);
 #pragma unroll
@@ -608,7 +696,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
                 quad_transpose(v, lane);
                 if (n >= a.N) continue;
                 if (m >= a.M) {
-                    if (a.Cones && m == a.M) *(float4*)(a.Cones + (size_t)blockIdx.z * a.cones_stride + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.Cones && m == a.M) *(float4*)(a.Cones + (size_t)bz * a.cones_stride + n) = make_float4(v[0], v[1], v[2], v[3]);
                     continue;
                 }
                 if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
@@ -624,6 +712,13 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
                 *dst = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+#ifdef IWAE_DENSE_STAMPS
+        GS_STAMP(6)      // epilogue
+        if (a.stamps && lane == 0) {
+            const size_t w_ = (((size_t)bz * gridDim.y + by) * gridDim.x + bx) * NW + wave;
+            for (int i_ = 0; i_ < 8; ++i_) a.stamps[w_ * 8 + i_] = gs_sum[i_];
+        }
+#endif
         return;
     }
 #pragma unroll
@@ -637,7 +732,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + 16 * TM * wm + 16 * i + 4 * q + r;
                 if (m >= a.M) {
-                    if (a.Cones && m == a.M) a.Cones[(size_t)blockIdx.z * a.cones_stride + n] = acc[i][j][r];
+                    if (a.Cones && m == a.M) a.Cones[(size_t)bz * a.cones_stride + n] = acc[i][j][r];
                     continue;
                 }
                 float v = acc[i][j][r] + bias;
@@ -1028,26 +1123,42 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
 }
 
 int g_gemm_f32_dbg = 0;
-bool g_gemm_f32_v2 = true;      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
-// Tile choice of the big kernel: the candidate with the least padded area (ties: the 128 x 128 tile); returns its workgroup count per K split
-static long gemm_f32_pick(int M, int N, int& bm, int& bn) {
+bool g_gemm_f32_v2 = true;
+bool g_gemm_f32_w8 = true;       // (iwae_set_option f32_gemm_w4 = 1: no 8-wave tiles)      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
+// Tile choice of the big kernels.  4-wave tiles (1 024 workgroup slots on the chip): 128 x 128, 64 x 224, 224 x 64 -- the candidate with the least padded
+// area (ties: 128 x 128).  8-wave tiles (512 slots; 39 % fewer operand bytes per FLOP): 128 x 224 where the 64 x 224 tile won and the rows fill the
+// machine, 224 x 128 where 224 x 64 won and the wider tile pads <= 10 % more (N = 784: 7 x 128 = 896 against 13 x 64 = 832).
+struct GemmF32Tile { int bm, bn, waves; long tm, tn; };
+static GemmF32Tile gemm_f32_pick(int M, int N, bool allow8 = true) {
     const int cand[3][2] = {{128, 128}, {64, 224}, {224, 64}};
-    long best = -1, wgs = 0;
+    long best = -1;
+    GemmF32Tile t = {128, 128, 4, 0, 0};
     for (int c = 0; c < 3; ++c) {
         const long tm = (M + cand[c][0] - 1) / cand[c][0], tn = (N + cand[c][1] - 1) / cand[c][1];
         const long area = tm * cand[c][0] * tn * cand[c][1];
-        if (best < 0 || area < best) { best = area; bm = cand[c][0]; bn = cand[c][1]; wgs = tm * tn; }
+        if (best < 0 || area < best) { best = area; t = {cand[c][0], cand[c][1], 4, tm, tn}; }
     }
-    return wgs;
+    if (allow8 && g_gemm_f32_v2 && g_gemm_f32_w8) {
+        if (t.bm == 64 && t.bn == 224 && M >= 128 * 256) { t.bm = 128; t.waves = 8; t.tm = (M + 127) / 128; }
+        else if (t.bm == 224 && t.bn == 64) {
+            const long tn8 = (N + 127) / 128;
+            if (tn8 * 128 * 10 <= t.tn * 64 * 11) { t.bn = 128; t.waves = 8; t.tn = tn8; }
+        }
+    }
+    return t;
 }
 long gemm_f32_tiles(int M, int N) {      // output tiles of the kernel launch_gemm_f32 would take (f32_dw sizes its row splits from it)
-    if (M > 64 && N > 64) { int bm, bn; return gemm_f32_pick(M, N, bm, bn); }
+    if (M > 64 && N > 64) { const GemmF32Tile t = gemm_f32_pick(M, N); return t.tm * t.tn; }
     return (long)((M + 63) / 64) * ((N + 63) / 64);
+}
+int gemm_f32_slots(int M, int N) {       // workgroups of that kernel the chip holds at once
+    if (M > 64 && N > 64) return gemm_f32_pick(M, N).waves == 8 ? 512 : 1024;
+    return 1024;
 }
 bool gemm_f32_takes_big(int M, int N, int nsplit) {
     if (!(M > 64 && N > 64)) return false;
-    int bm, bn;
-    return gemm_f32_pick(M, N, bm, bn) * nsplit >= 512;      // (448, which lets the 100 x 200 weight gradient in -- 2 tiles x 247 row splits -- measured slower: 79 vs 59 us)
+    const GemmF32Tile t = gemm_f32_pick(M, N, false);
+    return t.tm * t.tn * nsplit >= 512;      // (448, which lets the 100 x 200 weight gradient in -- 2 tiles x 247 row splits -- measured slower: 79 vs 59 us)
 }
 void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     GemmF32Args a = a0;
@@ -1064,27 +1175,35 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     // -- and only where that still fills the machine: a handful of 128-tiles walking K alone is latency-bound (3 us per k-step)
     const int Mg = a.M + (a.Cones ? 1 : 0);      // (the row of ones)
     if (gemm_f32_takes_big(a.M, a.N, nsplit)) {
-        int bm = 128, bn = 128;
-        if (a.epi != GEMM_EPI_BERN) gemm_f32_pick(a.M, a.N, bm, bn);      // (the Bernoulli epilogue's partial sums are per 64-column half of a 128-tile)
-        const dim3 grid((a.N + bn - 1) / bn, (Mg + bm - 1) / bm, nsplit);
-        const bool ak = a.sak == 1, bnf = a.sbn == 1;
         // (the v2 loop wants unit strides on the fast index of each operand -- every caller's are -- and falls back to the old kernel otherwise)
         const bool v2 = g_gemm_f32_v2 && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1);
+        GemmF32Tile t = gemm_f32_pick(a.M, a.N, v2);
+        if (a.epi == GEMM_EPI_BERN) t = {128, 128, 4, 0, 0};      // (the Bernoulli epilogue's partial sums are per 64-column half of a 128-tile)
+        const bool ak = a.sak == 1, bnf = a.sbn == 1;
+        if (t.waves == 8 && !((t.bm == 128 && ak) || (t.bm == 224 && !ak && bnf))) t = gemm_f32_pick(a.M, a.N, false);      // (8-wave kernels exist for the orientations the step has)
+        const dim3 grid((a.N + t.bn - 1) / t.bn, (Mg + t.bm - 1) / t.bm, nsplit);
+        if (t.waves == 8) {
+            if (t.bm == 128) {
+                if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 7, 4, 2, true, true>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 7, 4, 2, true, false>), grid, dim3(512), 0, st, a);
+            } else hipLaunchKernelGGL((gemm_f32_v2_kernel<7, 2, 2, 4, false, true>), grid, dim3(512), 0, st, a);
+            return;
+        }
 #define IWAE_F32_BIG(TM, TN)                                                                                             \
         do {                                                                                                             \
             if (v2) {                                                                                                    \
-                if (ak && bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);  \
-                else if (ak) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, a);   \
-                else if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, a);  \
-                else hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, a);          \
+                if (ak && bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, 2, 2, true, true>), grid, dim3(256), 0, st, a);  \
+                else if (ak) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, 2, 2, true, false>), grid, dim3(256), 0, st, a);   \
+                else if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, 2, 2, false, true>), grid, dim3(256), 0, st, a);  \
+                else hipLaunchKernelGGL((gemm_f32_v2_kernel<TM, TN, 2, 2, false, false>), grid, dim3(256), 0, st, a);          \
             }                                                                                                            \
             else if (ak && bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, true>), grid, dim3(256), 0, st, a);     \
             else if (ak) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, true, false>), grid, dim3(256), 0, st, a);      \
             else if (bnf) hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, true>), grid, dim3(256), 0, st, a);     \
             else hipLaunchKernelGGL((gemm_f32_big_kernel<TM, TN, false, false>), grid, dim3(256), 0, st, a);             \
         } while (0)
-        if (bm == 64) IWAE_F32_BIG(2, 7);
-        else if (bm == 224) IWAE_F32_BIG(7, 2);
+        if (t.bm == 64) IWAE_F32_BIG(2, 7);
+        else if (t.bm == 224) IWAE_F32_BIG(7, 2);
         else IWAE_F32_BIG(4, 4);
 #undef IWAE_F32_BIG
     }

@@ -142,7 +142,7 @@ struct iwae_model {
     // backward_f32 (reduce_slabs_multi_f32_kernel): jobs queued by f32_dw, slab offsets in floats (the buffer may still grow while they queue)
     struct F32Pending { size_t off; size_t stride; size_t n; float* out; int nsplit; int seg; };
     std::vector<F32Pending> f32_pending; size_t f32_slab_used = 0; bool allow_f32_multi_reduce = true;
-    bool allow_f32_side = true, f32_side_active = false, f32_wout_first = false;      // float32 step: the decoder's weight gradients + update on the side stream (options no_f32_side, f32_wout_first)
+    bool allow_f32_side = true, f32_side_active = false, f32_wout_first = true;      // float32 step: the decoder's weight gradients + update on the side stream (options no_f32_side, f32_wout_first)
     bool f32_z_pending = false;
     bool bf16_side_used = false;      // a bf16 call may have left a speculative draw on a side stream (forward_f32 waits for it on the host)
     size_t f32_slab_want = 0, f32_slab_want_step = 0;      // floats of slabs the last whole step asked for (the buffer's target size) / this step so far
@@ -181,6 +181,7 @@ struct iwae_model {
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
     int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
+    bool f32_dec_fused_train = false;
     bool allow_f32_dec_fused = true;                           // float32 mode: the decoder forward as one launch (dec_fwd_f32_kernel; option no_f32_dec_fused)
     bool allow_f32_bern_fused = true, f32_keeps_s = false;      // float32 mode: log p(x|z) (and, in a training step, s) in the output layer's GEMM epilogue (option no_f32_bern_fused)
     bool allow_wg3 = true;                           // few rows: the decoder's three weight gradients as one grouped launch (option no_wg3)
@@ -1776,6 +1777,13 @@ int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, 
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.epi = epi; a.ACT = ACT; a.ldact = ldact; a.accumulate = accumulate ? 1 : 0; a.kchunk = K; a.slab_stride = 0;
     a.brow_scale = brow_scale; a.orow_scale = orow_scale;
+#ifdef IWAE_DENSE_STAMPS
+    if (m->dstamp_epi == 12 && orow_scale && M >= 4096) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 12): phase stamps of the output layer's dX product
+        m->dstamp_waves = ((M + 63) / 64) * ((N + 223) / 224) * 4;
+        CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st ? st : m->stream));
+        a.stamps = ptr<unsigned long long>(m->dstamps);
+    }
+#endif
     launch_gemm_f32(a, 1, st ? st : m->stream);
     HIPCHK(hipGetLastError());
     return IWAE_OK;
@@ -1819,7 +1827,9 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     hipStream_t st = seg == 1 ? m->side : m->stream;
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
     const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout);      // (+ 1: the row of ones whose product row is the bias gradient)
-    const int nsplit = std::max(1, std::min(std::min(256, rows / 64), m->f32_dw_tiles / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
+    const int slots = std::min(m->f32_dw_tiles, gemm_f32_slots(kl.Kin + 1, kl.Nout));
+    int nsplit = std::max(1, std::min(std::min(256, rows / 64), slots / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
+    while (nsplit > 8 && (tiles * nsplit) % 8 != 0) --nsplit;      // (a multiple of 8 workgroups: gemm_f32_v2_kernel then keeps a split's tiles on one XCD)
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     // (round 5: the slabs of every gradient of the step stay until ONE reduction launch at the end of the backward pass; the buffer is sized for a
     // whole step -- a step that outgrows it falls back to the reduction per tensor, and the buffer grows for the next step)
@@ -1845,6 +1855,13 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
         launch_gemm_f32(a, 1, st);
     } else {
         a.C = slabW; a.ldc = kl.Nout; a.slab_stride = nW; a.Cones = slabB; a.cones_stride = (size_t)kl.Nout;
+#ifdef IWAE_DENSE_STAMPS
+        if (m->dstamp_epi == 13 && rowscale) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 13): phase stamps of the output layer's weight gradient
+            m->dstamp_waves = ((kl.Kin + 1 + 223) / 224) * ((kl.Nout + 63) / 64) * ns * 4;
+            CHK(ensure(m->dstamps, (size_t)m->dstamp_waves * 64, st));
+            a.stamps = ptr<unsigned long long>(m->dstamps);
+        }
+#endif
         launch_gemm_f32(a, ns, st);
         if (queue) {
             m->f32_pending.push_back({(size_t)(slabW - ptr<float>(m->f32.slab)), nW, nW, m->grad + kl.offW, ns, seg});
@@ -2015,7 +2032,9 @@ int forward_f32(iwae_model* m, const float* x, int B, int k, float beta, const f
     df.W1 = m->param + d1->offW; df.b1 = m->param + d1->offb; df.W2 = m->param + d2->offW; df.b2 = m->param + d2->offb;
     df.W3 = m->param + d3->offW; df.b3 = m->param + d3->offb;
     df.XB = xd; df.k = k; df.lpxz = lpxz; df.zero = m->d_zero; df.ldg = H; df.ldS = X;
-    const bool fused_dec = m->allow_f32_dec_fused && !(want && want->logits) && M >= 4096 && dec_fwd_f32_ok(df);
+    // (round 5: a TRAINING step takes the three GEMM launches again -- with gemm_f32_v2_kernel they are faster than the fused kernel once g1, g2 and s
+    // have to be stored anyway: 1.280 -> 1.248 ms; option f32_dec_fused_train = 1 for the fused kernel)
+    const bool fused_dec = m->allow_f32_dec_fused && (!bwd || m->f32_dec_fused_train) && !(want && want->logits) && M >= 4096 && dec_fwd_f32_ok(df);
     if (bwd || !fused_dec) {
         CHK(ensure(m->f32.g1, (size_t)M * H * 4, st));
         CHK(ensure(m->f32.g2, (size_t)M * H * 4, st));
@@ -2635,10 +2654,12 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_gemm_w4") g_gemm_f32_w8 = !on;                  // ... without the 8-wave tiles (process-wide, A/B only)
     else if (n == "f32_gemm_v1") g_gemm_f32_v2 = !on;                  // float32 GEMMs with the round-3 k loop (process-wide switch, A/B only)
     else if (n == "no_f32_side") m->allow_f32_side = !on;             // float32 step on one stream (no side-stream weight gradients, no deferred decoder update)
-    else if (n == "f32_wout_first") m->f32_wout_first = on;           // ... with the output layer's gradient first on the side stream instead of last
+    else if (n == "f32_wout_last") m->f32_wout_first = !on;           // ... with the output layer's gradient last on the side stream (beside the encoder's few-row kernels) instead of first (beside the dX chain)
     else if (n == "no_f32_multi_reduce") m->allow_f32_multi_reduce = !on;      // float32 mode: a slab reduction launch per gradient tensor instead of one per step
+    else if (n == "f32_dec_fused_train") m->f32_dec_fused_train = on;   // float32 training step: the decoder forward as dec_fwd_f32_kernel (round 4) instead of three GEMM launches
     else if (n == "no_f32_dec_fused") m->allow_f32_dec_fused = !on;   // float32 mode: the decoder forward as three GEMM launches
     else if (n == "no_f32_bern_fused") m->allow_f32_bern_fused = !on; // float32 mode: logits to memory, bern_f32_kernel / dl_f32_kernel as their own passes
     else if (n == "no_dec_rows") m->allow_dec_rows = !on;             // few data rows: the decoder's weight gradients as the grouped launch on the side stream + deferred reduction
