@@ -398,8 +398,8 @@ __device__ __forceinline__ void quad_transpose(float (&x)[4], int lane) {
 // WGM x WGN = the workgroup's waves (2 x 2: the tiles of gemm_f32_big_kernel; 4 x 2 / 2 x 4: 8 waves on a 128 x 224 / 224 x 128 tile).  The k loop is
 // bound by what a CU can request per clock (ablations, profiles/r05_f32_gemm_ablations.txt: the requests alone take as long as the MFMAs alone,
 // and the two overlap badly): a tile twice as tall moves 39 % fewer operand bytes per FLOP.
-template <int TM, int TN, int WGM, int WGN, bool AK, bool BNF>      // AK: op(A)'s k index is the unit-stride one; BNF: op(B)'s n index is
-__global__ __launch_bounds__(64 * WGM * WGN, 4) void gemm_f32_v2_kernel(GemmF32Args a) {
+template <int TM, int TN, int WGM, int WGN, bool AK, bool BNF, int OCC = 4>      // AK: op(A)'s k index is the unit-stride one; BNF: op(B)'s n index is; OCC: waves per SIMD the registers allow
+__global__ __launch_bounds__(64 * WGM * WGN, OCC) void gemm_f32_v2_kernel(GemmF32Args a) {
     constexpr int NT = 64 * WGM * WGN;
     [[maybe_unused]] constexpr int NW = WGM * WGN;
     constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN;
@@ -1124,6 +1124,7 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
 
 int g_gemm_f32_dbg = 0;
 bool g_gemm_f32_v2 = true;
+bool g_gemm_f32_v2_small = true;      // (option f32_gemm_small_v1 = 1)
 bool g_gemm_f32_w8 = true;       // (iwae_set_option f32_gemm_w4 = 1: no 8-wave tiles)      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
 // Tile choice of the big kernels.  4-wave tiles (1 024 workgroup slots on the chip): 128 x 128, 64 x 224, 224 x 64 -- the candidate with the least padded
 // area (ties: 128 x 128).  8-wave tiles (512 slots; 39 % fewer operand bytes per FLOP): 128 x 224 where the 64 x 224 tile won and the rows fill the
@@ -1147,12 +1148,13 @@ static GemmF32Tile gemm_f32_pick(int M, int N, bool allow8 = true) {
     }
     return t;
 }
-long gemm_f32_tiles(int M, int N) {      // output tiles of the kernel launch_gemm_f32 would take (f32_dw sizes its row splits from it)
-    if (M > 64 && N > 64) { const GemmF32Tile t = gemm_f32_pick(M, N); return t.tm * t.tn; }
+long gemm_f32_tiles(int M, int N, int tile_mode) {      // output tiles of the kernel launch_gemm_f32 would take (f32_dw sizes its row splits from it)
+    if (M > 64 && N > 64) { const GemmF32Tile t = gemm_f32_pick(M, N, tile_mode == 0); return t.tm * t.tn; }
     return (long)((M + 63) / 64) * ((N + 63) / 64);
 }
-int gemm_f32_slots(int M, int N) {       // workgroups of that kernel the chip holds at once
-    if (M > 64 && N > 64) return gemm_f32_pick(M, N).waves == 8 ? 512 : 1024;
+int gemm_f32_slots(int M, int N, int tile_mode) {       // workgroups of that kernel the chip holds at once
+    if (tile_mode == 2) return 768;
+    if (M > 64 && N > 64) return gemm_f32_pick(M, N, tile_mode == 0).waves == 8 ? 512 : 1024;
     return 1024;
 }
 bool gemm_f32_takes_big(int M, int N, int nsplit) {
@@ -1177,9 +1179,14 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     if (gemm_f32_takes_big(a.M, a.N, nsplit)) {
         // (the v2 loop wants unit strides on the fast index of each operand -- every caller's are -- and falls back to the old kernel otherwise)
         const bool v2 = g_gemm_f32_v2 && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1);
-        GemmF32Tile t = gemm_f32_pick(a.M, a.N, v2);
+        GemmF32Tile t = gemm_f32_pick(a.M, a.N, v2 && a.tile_mode == 0);
         if (a.epi == GEMM_EPI_BERN) t = {128, 128, 4, 0, 0};      // (the Bernoulli epilogue's partial sums are per 64-column half of a 128-tile)
         const bool ak = a.sak == 1, bnf = a.sbn == 1;
+        if (v2 && a.tile_mode == 2 && t.bm == 224 && !ak && bnf) {      // a weight gradient that shares the CUs with few-row kernels: 3 waves per SIMD, one slot left to them
+            const dim3 grid((a.N + t.bn - 1) / t.bn, (Mg + t.bm - 1) / t.bm, nsplit);
+            hipLaunchKernelGGL((gemm_f32_v2_kernel<7, 2, 2, 2, false, true, 3>), grid, dim3(256), 0, st, a);
+            return;
+        }
         if (t.waves == 8 && !((t.bm == 128 && ak) || (t.bm == 224 && !ak && bnf))) t = gemm_f32_pick(a.M, a.N, false);      // (8-wave kernels exist for the orientations the step has)
         const dim3 grid((a.N + t.bn - 1) / t.bn, (Mg + t.bm - 1) / t.bm, nsplit);
         if (t.waves == 8) {
@@ -1209,6 +1216,15 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
     }
     else {
         const dim3 grid((a.N + 63) / 64, (Mg + 63) / 64, nsplit);
+        const bool ak = a.sak == 1, bnf = a.sbn == 1;
+        // many 64 x 64 tiles (the 50-wide latent layer on all rows, its weight gradient's row splits): the v2 loop on that tile
+        if (g_gemm_f32_v2 && g_gemm_f32_v2_small && (long)grid.x * grid.y * grid.z >= 256 && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1)) {
+            if (ak && bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, st, a);
+            else if (ak) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, st, a);
+            else if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, false, false>), grid, dim3(256), 0, st, a);
+            return;
+        }
         // few workgroups walking a long K: two k-steps per iteration (half as many exposed round trips)
         if ((long)grid.x * grid.y * grid.z < 512 && a.kchunk >= 64) hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, a);

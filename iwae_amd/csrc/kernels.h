@@ -357,6 +357,7 @@ struct GemmF32Args {
     // goes to Cones[z * cones_stride + n] instead of C (round 3: no separate pass over G for the bias gradients)
     float* Cones; size_t cones_stride;
     unsigned long long* stamps;           // diagnostic build (STAMPS=1) only: [workgroups * 4 waves][8] phase cycle sums of gemm_f32_v2_kernel, else null
+    int tile_mode;                        // 0: launch_gemm_f32 picks the tile; 1: 4-wave tiles only; 2: 4-wave tiles at <= 3 waves per SIMD (a slot per SIMD stays free for few-row kernels beside it)
     int dbg;                              // diagnostic builds (DIAG=1) only: timing ablations of gemm_f32_v2_kernel (option f32_gemm_dbg; results wrong)
 };
 // dec_fwd_f32_kernel: the decoder forward in float32 in ONE launch (z -> tanh -> tanh -> logits -> log p(x|z)), rows stationary
@@ -373,12 +374,12 @@ struct DecFwdF32Args {
 };
 bool dec_fwd_f32_ok(const DecFwdF32Args& a);
 void launch_dec_fwd_f32(const DecFwdF32Args& a, hipStream_t st);
-long gemm_f32_tiles(int M, int N);                       // output tiles of the kernel launch_gemm_f32 takes for an M x N product
+long gemm_f32_tiles(int M, int N, int tile_mode = 0);                       // output tiles of the kernel launch_gemm_f32 takes for an M x N product
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 extern int g_gemm_f32_dbg;
-extern bool g_gemm_f32_w8;
-int gemm_f32_slots(int M, int N);                       // workgroups of launch_gemm_f32's kernel for an M x N product the chip holds at once
+extern bool g_gemm_f32_w8, g_gemm_f32_v2_small;
+int gemm_f32_slots(int M, int N, int tile_mode = 0);                       // workgroups of launch_gemm_f32's kernel for an M x N product the chip holds at once
 extern bool g_gemm_f32_v2;                               // false: gemm_f32_big_kernel (the round-3 k loop) instead of gemm_f32_v2_kernel
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);
 // every slab sum of a float32 step in one launch (round 5): out[i] = sum over the job's slabs, i < n; block_begin is filled by the launcher

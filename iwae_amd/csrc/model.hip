@@ -144,6 +144,7 @@ struct iwae_model {
     std::vector<F32Pending> f32_pending; size_t f32_slab_used = 0; bool allow_f32_multi_reduce = true;
     bool allow_f32_side = true, f32_side_active = false, f32_wout_first = true;      // float32 step: the decoder's weight gradients + update on the side stream (options no_f32_side, f32_wout_first)
     bool f32_z_pending = false;
+    int f32_dw_last = 0;
     bool bf16_side_used = false;      // a bf16 call may have left a speculative draw on a side stream (forward_f32 waits for it on the host)
     size_t f32_slab_want = 0, f32_slab_want_step = 0;      // floats of slabs the last whole step asked for (the buffer's target size) / this step so far
     int eval_tag_kill = -1;
@@ -1823,11 +1824,11 @@ int f32_flush_reductions(iwae_model* m, int seg = -1) {
 }
 // grad W = X^T G, grad b = column sums of G: the row axis is split into fp32 slabs summed in a fixed order (deterministic)
 // (rowscale: G's row r is multiplied by rowscale[r] as it is fetched -- the values the separate g_r s pass used to store)
-int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr, int seg = 0) {
+int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const float* G, long ldg, int rows, const float* rowscale = nullptr, int seg = 0, int tile_mode = 0) {
     hipStream_t st = seg == 1 ? m->side : m->stream;
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
-    const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout);      // (+ 1: the row of ones whose product row is the bias gradient)
-    const int slots = std::min(m->f32_dw_tiles, gemm_f32_slots(kl.Kin + 1, kl.Nout));
+    const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout, tile_mode);      // (+ 1: the row of ones whose product row is the bias gradient)
+    const int slots = std::min(m->f32_dw_tiles, gemm_f32_slots(kl.Kin + 1, kl.Nout, tile_mode));
     int nsplit = std::max(1, std::min(std::min(256, rows / 64), slots / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
     while (nsplit > 8 && (tiles * nsplit) % 8 != 0) --nsplit;      // (a multiple of 8 workgroups: gemm_f32_v2_kernel then keeps a split's tiles on one XCD)
     const size_t nW = (size_t)kl.Kin * kl.Nout;
@@ -1846,7 +1847,7 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     GemmF32Args a;
     memset(&a, 0, sizeof(a));
     a.A = X; a.sam = 1; a.sak = ldx; a.B = G; a.sbk = ldg; a.sbn = 1; a.M = kl.Kin; a.N = kl.Nout; a.K = rows;
-    a.brow_scale = rowscale;
+    a.brow_scale = rowscale; a.tile_mode = tile_mode;
     a.kchunk = (rows + nsplit - 1) / nsplit; a.kchunk = (a.kchunk + 15) / 16 * 16;
     const int ns = (rows + a.kchunk - 1) / a.kchunk;
     // the bias gradient = the column sums of (weighted) G = the product row of a row of ONES appended to X^T (GemmF32Args.Cones): no pass of its own
@@ -2154,22 +2155,35 @@ int backward_f32(iwae_model* m, int objective, float fused_lr = -1.0f) {
     const bool use_side = m->allow_f32_side && m->side && !m->has_prior && M >= 4096 && b_dec1 + 3 == (int)m->klayers.size();
     m->f32_side_active = use_side;
     const int sg = use_side ? 1 : 0;
+    const bool dw_last = use_side && m->f32_dw_last > 0;      // option: every decoder weight gradient behind the dX chain, beside the main stream's few-row tail
     if (use_side) {
         HIPCHK(hipEventRecord(m->ev_fork, st));      // s, g1, g2, z, the row weights
         HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-        if (m->f32_wout_first) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
+        if (m->f32_wout_first && !dw_last) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
     } else {
         CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw));
     }
     CHK(f32_dx(m, *d3, dl, X, M, ptr<float>(m->f32.d2), H, ptr<float>(m->f32.g2), H, false, rw));
-    if (use_side) { HIPCHK(hipEventRecord(m->ev_fork2, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0)); }
-    CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M, nullptr, sg));
+    if (use_side && !dw_last) { HIPCHK(hipEventRecord(m->ev_fork2, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_fork2, 0)); }
+    if (!dw_last) CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M, nullptr, sg));
     CHK(f32_dx(m, *d2, ptr<float>(m->f32.d2), H, M, ptr<float>(m->f32.d1), H, ptr<float>(m->f32.g1), H, false));
-    if (use_side) { HIPCHK(hipEventRecord(m->ev_blk, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0)); }
-    CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M, nullptr, sg));
-    if (use_side) { HIPCHK(hipEventRecord(m->ev_join, m->side)); m->f32_z_pending = true; }      // (z is free for the next step's sampling)
-    if (use_side && !m->f32_wout_first) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
+    if (use_side && !dw_last) { HIPCHK(hipEventRecord(m->ev_blk, st)); HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0)); }
+    if (!dw_last) {
+        CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M, nullptr, sg));
+        if (use_side) { HIPCHK(hipEventRecord(m->ev_join, m->side)); m->f32_z_pending = true; }      // (z is free for the next step's sampling)
+        if (use_side && !m->f32_wout_first) CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1));
+    }
     CHK(f32_dx(m, *d1, ptr<float>(m->f32.d1), H, M, ptr<float>(m->wdec1.dz), Dp0, nullptr, 0, false));
+    if (dw_last) {
+        const int tmode = m->f32_dw_last - 1;      // (1: tiles as picked, 2: 4-wave tiles, 3: 4-wave tiles at 3 waves per SIMD)
+        HIPCHK(hipEventRecord(m->ev_blk, st));
+        HIPCHK(hipStreamWaitEvent(m->side, m->ev_blk, 0));
+        CHK(f32_dw(m, *d1, ptr<float>(m->f32.z[0]), D0 + m->C, ptr<float>(m->f32.d1), H, M, nullptr, 1, tmode));
+        HIPCHK(hipEventRecord(m->ev_join, m->side));
+        m->f32_z_pending = true;
+        CHK(f32_dw(m, *d2, ptr<float>(m->f32.g1), H, ptr<float>(m->f32.d2), H, M, nullptr, 1, tmode));
+        CHK(f32_dw(m, *d3, ptr<float>(m->f32.g2), H, dl, X, M, rw, 1, tmode));
+    }
     const float *dz1_b = nullptr, *dz1_c = nullptr;
     if (two) {
         const int b_enc2 = m->enc2[0].sub[0], b_dec2 = m->dec2[0].sub[0];
@@ -2654,9 +2668,11 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_gemm_small_v1") g_gemm_f32_v2_small = !on;      // ... the round-3 64-tile kernel for every 64 x 64-tiled product
     else if (n == "f32_gemm_w4") g_gemm_f32_w8 = !on;                  // ... without the 8-wave tiles (process-wide, A/B only)
     else if (n == "f32_gemm_v1") g_gemm_f32_v2 = !on;                  // float32 GEMMs with the round-3 k loop (process-wide switch, A/B only)
     else if (n == "no_f32_side") m->allow_f32_side = !on;             // float32 step on one stream (no side-stream weight gradients, no deferred decoder update)
+    else if (n == "f32_dw_last") m->f32_dw_last = iv;                 // float32 step: all decoder weight gradients behind the dX chain (1: tiles as picked, 2: 4-wave tiles, 3: ... at 3 waves per SIMD)
     else if (n == "f32_wout_last") m->f32_wout_first = !on;           // ... with the output layer's gradient last on the side stream (beside the encoder's few-row kernels) instead of first (beside the dX chain)
     else if (n == "no_f32_multi_reduce") m->allow_f32_multi_reduce = !on;      // float32 mode: a slab reduction launch per gradient tensor instead of one per step
     else if (n == "f32_dec_fused_train") m->f32_dec_fused_train = on;   // float32 training step: the decoder forward as dec_fwd_f32_kernel (round 4) instead of three GEMM launches

@@ -8,7 +8,7 @@ import csv, glob, sys
 fn = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(fn)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:70], r["Queue_Id"], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), r.get("Workgroup_Size_X", r.get("Workgroup_Size", ""))) for r in rows)
-idx = [i for i, e in enumerate(ev) if "dec_fwd_f32_kernel" in e[2]]
+idx = [i for i, e in enumerate(ev) if "lse_kernel" in e[2]]
 i0, i1 = idx[len(idx) // 2], idx[len(idx) // 2 + 1]
 t0 = ev[i0][0]; prev = t0
 for s, e, n, q, gx, gy, gz, wg in ev[i0:i1]:
