@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <algorithm>
 #include "kernels.h"
 
 namespace iwae {
@@ -1124,6 +1125,7 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
 
 int g_gemm_f32_dbg = 0;
 bool g_gemm_f32_v2 = true;
+bool g_gemm_f32_ksplit = true;        // (option f32_no_ksplit = 1: few-row products as one 64-tile launch walking K alone)
 bool g_gemm_f32_v2_small = true;      // (option f32_gemm_small_v1 = 1)
 bool g_gemm_f32_w8 = true;       // (iwae_set_option f32_gemm_w4 = 1: no 8-wave tiles)      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
 // Tile choice of the big kernels.  4-wave tiles (1 024 workgroup slots on the chip): 128 x 128, 64 x 224, 224 x 64 -- the candidate with the least padded
@@ -1229,6 +1231,50 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
         if ((long)grid.x * grid.y * grid.z < 512 && a.kchunk >= 64) hipLaunchKernelGGL(gemm_f32_kernel<2>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(gemm_f32_kernel<1>, grid, dim3(256), 0, st, a);
     }
+}
+// C = epi(sum over z of slab[z] + bias) for a K-split product of FEW rows (the encoder's layers on the batch's images: 64 tiles of 64 x 64 walking K alone
+// expose a memory round trip per k-step -- 20 us for K = 200, 55 for K = 784; split four ways they are 256 workgroups of 3-13 k-steps and this pass):
+// the epilogue of the GEMM kernels (bias, row weight, tanh / exp / tanh', accumulate) on the summed slabs, in slab order (deterministic).
+__global__ __launch_bounds__(256) void reduce_epi_f32_kernel(GemmF32Args a, const float* slabs, int nsplit) {
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x, per = (size_t)a.N >> 2;      // quads of 4 columns (N % 4 == 0)
+    if (q >= (size_t)a.M * per) return;
+    const int m = (int)(q / per), n = 4 * (int)(q - (size_t)m * per);
+    const float* p = slabs + (size_t)m * a.N + n;
+    float4 acc = *(const float4*)p;
+    for (int z = 1; z < nsplit; ++z) { const float4 t = *(const float4*)(p + (size_t)z * a.slab_stride); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] + (a.bias ? a.bias[n + e] : 0.0f);
+        if (a.orow_scale) x *= a.orow_scale[m];
+        if (a.epi == GEMM_EPI_TANH) x = tanh_f32(x);
+        else if (a.epi == GEMM_EPI_EXP) x = expf(x) + 1e-6f;
+        else if (a.epi == GEMM_EPI_DTANH) { const float y = a.ACT[(size_t)m * a.ldact + n + e]; x *= 1.0f - y * y; }
+        float* dst = a.C + (size_t)m * a.ldc + n + e;
+        *dst = a.accumulate ? *dst + x : x;
+    }
+}
+// the K split launch_gemm_f32_fewrows would take (1: none)
+int gemm_f32_fewrows_split(int M, int N, int K) {
+    if (!g_gemm_f32_v2 || !g_gemm_f32_ksplit || M > 4096 || (N & 3) || K < 96) return 1;
+    const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 256 || tiles < 8) return 1;
+    int ns = (int)std::min<long>(std::min<long>(8, (256 + tiles - 1) / tiles), K / 48);
+    if (ns < 2) return 1;
+    const int kchunk = ((K + ns - 1) / ns + 15) / 16 * 16;
+    return (K + kchunk - 1) / kchunk;
+}
+// slabs: >= split * M * N floats of scratch (16-byte aligned)
+void launch_gemm_f32_fewrows(const GemmF32Args& a0, float* slabs, hipStream_t st) {
+    const int ns0 = gemm_f32_fewrows_split(a0.M, a0.N, a0.K);
+    GemmF32Args g = a0;
+    g.kchunk = ((a0.K + ns0 - 1) / ns0 + 15) / 16 * 16;
+    const int ns = (a0.K + g.kchunk - 1) / g.kchunk;
+    g.C = slabs; g.ldc = a0.N; g.slab_stride = (size_t)a0.M * a0.N; g.bias = nullptr; g.epi = GEMM_EPI_NONE; g.ACT = nullptr; g.accumulate = 0; g.orow_scale = nullptr;
+    launch_gemm_f32(g, ns, st);
+    GemmF32Args e = a0;
+    e.slab_stride = g.slab_stride;
+    hipLaunchKernelGGL(reduce_epi_f32_kernel, dim3((unsigned)(((size_t)a0.M * (a0.N >> 2) + 255) / 256)), dim3(256), 0, st, e, slabs, ns);
 }
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(reduce_slabs_f32_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slabs, stride, nsplit, n, out);

@@ -378,7 +378,9 @@ long gemm_f32_tiles(int M, int N, int tile_mode = 0);                       // o
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 extern int g_gemm_f32_dbg;
-extern bool g_gemm_f32_w8, g_gemm_f32_v2_small;
+extern bool g_gemm_f32_w8, g_gemm_f32_v2_small, g_gemm_f32_ksplit;
+int gemm_f32_fewrows_split(int M, int N, int K);        // > 1: launch_gemm_f32_fewrows splits K that many ways (scratch: split * M * N floats)
+void launch_gemm_f32_fewrows(const GemmF32Args& a, float* slabs, hipStream_t st);
 int gemm_f32_slots(int M, int N, int tile_mode = 0);                       // workgroups of launch_gemm_f32's kernel for an M x N product the chip holds at once
 extern bool g_gemm_f32_v2;                               // false: gemm_f32_big_kernel (the round-3 k loop) instead of gemm_f32_v2_kernel
 void launch_reduce_slabs_f32(const float* slabs, size_t stride, int nsplit, size_t n, float* out, hipStream_t st);

@@ -137,7 +137,7 @@ struct iwae_model {
     int64_t adam_t = 0;
     // float32 mode (iwae_config.precision / iwae_set_eval_precision): row-major float32 activations, GEMMs on v_mfma_f32_16x16x4_f32
     struct F32Block { DevBuf h1, h2, dhead, d2, d1, dx; };
-    struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat; } f32;
+    struct F32State { F32Block enc1, enc2, dec2, prior; DevBuf z[2], g1, g2, logits, d2, d1, slab, bpart, xcat, kslab; } f32;
     // float32 weight gradients of a step keep their row-split slabs (each in its own region of f32.slab) and are summed by ONE launch at the end of
     // backward_f32 (reduce_slabs_multi_f32_kernel): jobs queued by f32_dw, slab offsets in floats (the buffer may still grow while they queue)
     struct F32Pending { size_t off; size_t stride; size_t n; float* out; int nsplit; int seg; };
@@ -1778,6 +1778,17 @@ int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, 
     a.A = A; a.sam = sam; a.sak = sak; a.B = B; a.sbk = sbk; a.sbn = sbn; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.bias = bias; a.epi = epi; a.ACT = ACT; a.ldact = ldact; a.accumulate = accumulate ? 1 : 0; a.kchunk = K; a.slab_stride = 0;
     a.brow_scale = brow_scale; a.orow_scale = orow_scale;
+    {   // few rows (the encoder on the batch's images): K split + one reduction pass that carries the epilogue
+        hipStream_t s_ = st ? st : m->stream;
+        const int ns = gemm_f32_fewrows_split(M, N, K);
+        if (ns > 1 && !brow_scale) {
+            a.avec = a.bvec = 0;
+            CHK(ensure(m->f32.kslab, (size_t)ns * M * N * 4, s_));
+            launch_gemm_f32_fewrows(a, ptr<float>(m->f32.kslab), s_);
+            HIPCHK(hipGetLastError());
+            return IWAE_OK;
+        }
+    }
 #ifdef IWAE_DENSE_STAMPS
     if (m->dstamp_epi == 12 && orow_scale && M >= 4096) {      // diagnostic (STAMPS=1 build, option dense_stamps_epi = 12): phase stamps of the output layer's dX product
         m->dstamp_waves = ((M + 63) / 64) * ((N + 223) / 224) * 4;
@@ -2454,7 +2465,7 @@ void iwae_destroy(iwae_handle m) {
     {
         iwae_model::F32Block* fb[] = {&m->f32.enc1, &m->f32.enc2, &m->f32.dec2, &m->f32.prior};
         for (auto* w : fb) { DevBuf* bb[] = {&w->h1, &w->h2, &w->dhead, &w->d2, &w->d1, &w->dx}; for (DevBuf* b : bb) free_buf(*b); }
-        DevBuf* bb[] = {&m->f32.z[0], &m->f32.z[1], &m->f32.g1, &m->f32.g2, &m->f32.logits, &m->f32.d2, &m->f32.d1, &m->f32.slab, &m->f32.bpart, &m->f32.xcat};
+        DevBuf* bb[] = {&m->f32.z[0], &m->f32.z[1], &m->f32.g1, &m->f32.g2, &m->f32.logits, &m->f32.d2, &m->f32.d1, &m->f32.slab, &m->f32.bpart, &m->f32.xcat, &m->f32.kslab};
         for (DevBuf* b : bb) free_buf(*b);
     }
     if (m->param) (void)hipFree(m->param);
@@ -2668,6 +2679,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_no_ksplit") g_gemm_f32_ksplit = !on;            // ... few-row products as one 64-tile launch
     else if (n == "f32_gemm_small_v1") g_gemm_f32_v2_small = !on;      // ... the round-3 64-tile kernel for every 64 x 64-tiled product
     else if (n == "f32_gemm_w4") g_gemm_f32_w8 = !on;                  // ... without the 8-wave tiles (process-wide, A/B only)
     else if (n == "f32_gemm_v1") g_gemm_f32_v2 = !on;                  // float32 GEMMs with the round-3 k loop (process-wide switch, A/B only)
