@@ -1178,7 +1178,8 @@ def test_float32_decoder_forward_in_one_launch_matches_exact_oracle(gpu, B, k, n
     res, g = O.loss_grads_1layer(P, x, eps, 1.0, obj)
     keys = ("iwae_elbo",) if obj == "dreg" else ("vae_elbo", "iwae_elbo", "iwae_eq14")
     out = []
-    for opts in ({}, {"no_f32_dec_fused": 1}):
+    # (round 5: a training step takes the three launches by default -- the fused kernel is the forward-only calls' and option f32_dec_fused_train's)
+    for opts in ({"f32_dec_fused_train": 1}, {"no_f32_dec_fused": 1}, {}):
         m = NativeModel(1, nh, nl, x_dim=xd, seed=123, precision="fp32", options=opts)
         m.set_params(O.flatten_params(P))
         r = m.forward_backward(x, k, 1.0, obj, eps=eps, want=("lpxz",))
@@ -1191,9 +1192,73 @@ def test_float32_decoder_forward_in_one_launch_matches_exact_oracle(gpu, B, k, n
         np.testing.assert_allclose(r0["lpxz"], r["lpxz"], rtol=1e-6, atol=1e-4)
         out.append((r, flat.astype(np.float64)))
         m.close()
-    (r1, g1), (r2, g2) = out
+    (r1, g1), (r2, g2), (r3, g3) = out
     np.testing.assert_allclose(r1["lpxz"], r2["lpxz"], rtol=2e-6, atol=2e-4)
     assert np.linalg.norm(g1 - g2) / np.linalg.norm(g2) < 1e-5
+    np.testing.assert_array_equal(r3["lpxz"], r2["lpxz"])
+    np.testing.assert_array_equal(g3, g2)
+
+
+@pytest.mark.parametrize("layers,B,k,obj", [(1, 100, 50, "iwae_elbo"), (1, 1024, 5, "vae_elbo"), (2, 96, 50, "iwae_elbo")])
+def test_float32_step_on_two_streams_is_bitwise_the_one_stream_step(gpu, layers, B, k, obj):
+    """Round 5, float32 mode at >= 4 096 rows: the decoder's three weight gradients, their slab reduction and their Adam update run on the side
+    stream, the update deferred past the next step's encoder forward and sampling (backward_f32; joined in front of the decoder forward, by every
+    call that reads parameters or gradients, and by a forward-only call in between).  Same kernels in the same order per stream: parameters, Adam
+    state and objective values after four steps (device noise, a forward-only call and a gradient read in between) are BITWISE those of the
+    one-stream step (option no_f32_side)."""
+    from iwae_amd.native import NativeModel
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x = O.synthetic_binarized(B, 11)
+    out = []
+    for opts in ({}, {"no_f32_side": 1}, {"f32_wout_last": 1}):
+        m = NativeModel(layers, nh, nl, seed=77, precision="fp32", options=opts)
+        vals = []
+        for step in range(4):
+            r = m.train_step(x, k, 1.0, 1e-3, obj)
+            vals.append([r["vae_elbo"], r["iwae_elbo"]])
+            if step == 1:
+                vals.append([m.forward(x, k, 1.0)["iwae_elbo"], 0.0])          # forward only: joins the deferred update first
+            if step == 2:
+                m.forward_backward(x, k, 1.0, obj)
+                vals.append([float(np.abs(m.get_grads()).sum()), 0.0])         # the gradient of a two-call step, read while the side stream may still hold it
+        out.append((np.array(vals), m.get_params().copy(), [a.copy() for a in m.get_adam_state()[:2]]))
+        m.close()
+    for other in out[1:]:
+        np.testing.assert_array_equal(out[0][0], other[0])
+        np.testing.assert_array_equal(out[0][1], other[1])
+        for a, b in zip(out[0][2], other[2]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("layers,B,k", [(1, 100, 50), (1, 1024, 5), (2, 96, 50)])
+def test_float32_gemm_kernel_variants_agree(gpu, layers, B, k):
+    """Round 5: the float32 GEMMs' k loop was rewritten (gemm_f32_v2_kernel: 16-byte conflict-free LDS stores and reads with lane quad q contracting
+    k = 4q + j, transposed 16-byte epilogues, 8-wave 128 x 224 / 224 x 128 tiles, the v2 loop on 64 x 64 tiles, K-split few-row products with the
+    epilogue in the reduction).  Every variant against the exact float64 oracle at the float32 tolerances, and against each other to 1e-5 -- they
+    differ in the ORDER of float32 sums only.  (The switches are process-wide: each is put back.)"""
+    from iwae_amd.native import NativeModel
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x, P, eps = MG.inputs(layers, nh, nl, 784, B, k, 880 + B + k)
+    res, g = (O.loss_grads_1layer(P, x, eps, 1.0, "iwae_elbo") if layers == 1 else O.loss_grads_2layer(P, x, eps[0], eps[1], 1.0, "iwae_elbo"))
+    grads = {}
+    for name in (None, "f32_gemm_v1", "f32_gemm_w4", "f32_gemm_small_v1", "f32_no_ksplit"):
+        m = NativeModel(layers, nh, nl, seed=123, precision="fp32")
+        if name:
+            m.set_option(name, 1)
+        try:
+            m.set_params(O.flatten_params(P))
+            r = m.forward_backward(x, k, 1.0, "iwae_elbo", eps=eps)
+            for key in ("vae_elbo", "iwae_elbo", "iwae_eq14"):
+                assert abs(r[key] - res[key]) <= F32_SCALAR_REL * abs(res[key]) + 2e-4, (name, key, r[key], res[key])
+            flat = m.get_grads()
+            assert max(_grad_rel_errors(flat, g)) < F32_GRAD_REL, name
+            grads[name] = flat.astype(np.float64)
+        finally:
+            if name:
+                m.set_option(name, 0)
+            m.close()
+    for name, gv in grads.items():
+        assert np.linalg.norm(gv - grads[None]) / np.linalg.norm(grads[None]) < 1e-5, name
 
 
 def test_float32_mode_against_golden_fixtures(gpu):
