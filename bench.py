@@ -395,8 +395,8 @@ def run():
                          "measured_hbm_bytes": step_hbm, "measured_hbm_frac": round(step_hbm / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if step_hbm else None},
             }
         if not dom:      # float32 mode (one generic GEMM kernel, no per-kernel events): the step as a whole against the f32 MFMA peak
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (every product of the step: v_mfma_f32_16x16x4_f32), whole step", "timed_as": "step",
-                               "stream": "main", "achieved": round(flop_step / (ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_v2_kernel (every product of the step: v_mfma_f32_16x16x4_f32), whole step", "timed_as": "step",
+                               "stream": "main + side (the decoder's weight gradients and its deferred update)", "achieved": round(flop_step / (ms * 1e-3) / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": round(flop_step / (ms * 1e-3) / (peak_tf * 1e12), 4), "traffic": None, "traffic_source": None,
                                "avg_launch_us": round(ms * 1e3, 2), "launches": args.steps, "flop_per_launch": flop_step}
         if world == 1 and not args.no_cpu_baseline:
