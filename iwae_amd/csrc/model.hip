@@ -1780,7 +1780,9 @@ int f32_gemm(iwae_model* m, const float* A, long sam, long sak, const float* B, 
     a.brow_scale = brow_scale; a.orow_scale = orow_scale;
     {   // few rows (the encoder on the batch's images): K split + one reduction pass that carries the epilogue
         hipStream_t s_ = st ? st : m->stream;
-        const int ns = gemm_f32_fewrows_split(M, N, K);
+        // (not inside iwae_eval_llh: the split depends on how many images a launch holds, and an image's estimate must not -- the evaluator's
+        // encoder is 419 rows beside 2^21 decoder rows, nothing to gain there: test_eval_llh_images_per_launch_are_invisible)
+        const int ns = m->in_eval_llh ? 1 : gemm_f32_fewrows_split(M, N, K);
         if (ns > 1 && !brow_scale) {
             a.avec = a.bvec = 0;
             CHK(ensure(m->f32.kslab, (size_t)ns * M * N * 4, s_));
