@@ -1,5 +1,6 @@
 #!/bin/bash
 # Developer script (GPU box): kernel timeline of one float32 training step (bench.py --precision fp32), with grid sizes.
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_f32_${1:-x}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --precision fp32 --steps 20 --warmup 5 --settle 0 --no-kernel-times --no-cpu-baseline --no-llh-eval $BENCH_ARGS > $OUT/log.txt 2>&1 || echo failed
