@@ -27,3 +27,4 @@ bash tools/profile_bench.sh ${TAG}_c2 c2 quick > $O/profile_c2.txt 2>&1; tail -2
 bash tools/dev/alone.sh "bern_pipe|dec_bwd|wgradws|wgrad_rows|reduce_grads|block_fwd|block_bwd|latent|eps_gen" wg16=128 > $O/alone_times.txt 2>&1; cat $O/alone_times.txt
 BENCH_ARGS="--config c2" bash tools/dev/alone.sh "chain2|gblock|bern_pipe|dec_bwd|wgradws|wgradp|wgrad_rows|reduce_grads|block_fwd|block_bwd|latent" > $O/alone_times_c2.txt 2>&1; cat $O/alone_times_c2.txt
 for p in fp32 bf16; do python tools/dev/eval_only.py $p 4190 >> $O/eval.txt 2>&1; python tools/dev/eval_only.py $p 10000 >> $O/eval.txt 2>&1; done; cat $O/eval.txt
+bash tools/dev/trace_f32.sh $TAG > $O/f32_step_timeline.txt 2>&1; tail -3 $O/f32_step_timeline.txt
