@@ -1261,6 +1261,39 @@ def test_float32_gemm_kernel_variants_agree(gpu, layers, B, k):
         assert np.linalg.norm(gv - grads[None]) / np.linalg.norm(grads[None]) < 1e-5, name
 
 
+@pytest.mark.parametrize("layers,B,k", [(1, 100, 50), (2, 96, 50), (1, 20, 5)])
+def test_float32_data_parallel_step_world1_is_bitwise_the_single_gpu_step(gpu, layers, B, k):
+    """float32 mode through the in-library data-parallel step with ONE rank (iwae_comm_init + iwae_train_step): the gradient comes off both streams
+    (round 5: the decoder's weight gradients on the side stream), is joined, all-reduced whole and applied by one Adam launch -- against the
+    single-GPU step, which applies the encoder's segment on the main stream and the decoder's, deferred, on the side stream.  Eight steps on device
+    noise: bit-identical parameters, Adam state and last gradient."""
+    from iwae_amd.native import NativeModel
+    nh, nl = (200, 100) if layers == 1 else ([200, 100], [100, 50])
+    x = O.synthetic_binarized(B, 17)
+    P = O.init_params(layers, nh, nl, 23, x_mean=O.synthetic_pixel_means())
+    outs = []
+    for dp in (False, True):
+        m = NativeModel(layers, nh, nl, seed=123, precision="fp32")
+        m.set_params(O.flatten_params(P))
+        if dp:
+            m.comm_init(NativeModel.comm_unique_id(), 1, 0)
+        for t in range(8):
+            m.set_step(t, 0)
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo", scalars=(t % 3 == 0))
+            if t == 4:
+                m.get_params()
+        outs.append((m.get_params().copy(), m.get_adam_state(), m.get_grads().copy()))
+        if dp:
+            m.comm_destroy()
+            m.train_step(x, k, 1.0, 1e-3, "iwae_elbo")
+        m.close()
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1][0], outs[1][1][0])
+    np.testing.assert_array_equal(outs[0][1][1], outs[1][1][1])
+    assert outs[0][1][2] == outs[1][1][2] == 8
+
+
 def test_float32_mode_against_golden_fixtures(gpu):
     """The tiny fixtures' exact (float64) expectations, element by element, at SURVEY 8(c)'s float32 tolerances."""
     from iwae_amd.native import NativeModel
