@@ -1125,6 +1125,7 @@ void launch_concat_f32(const float* a, int na, const float* b, int nb, int rows,
 
 int g_gemm_f32_dbg = 0;
 bool g_gemm_f32_v2 = true;
+int g_gemm_f32_ksplit_min_tiles = 1;    // (option f32_ksplit_min_tiles: 8 = round-5 first version: B >= 100 images only)
 bool g_gemm_f32_ksplit = true;        // (option f32_no_ksplit = 1: few-row products as one 64-tile launch walking K alone)
 bool g_gemm_f32_v2_small = true;      // (option f32_gemm_small_v1 = 1)
 bool g_gemm_f32_w8 = true;       // (iwae_set_option f32_gemm_w4 = 1: no 8-wave tiles)      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
@@ -1258,8 +1259,8 @@ __global__ __launch_bounds__(256) void reduce_epi_f32_kernel(GemmF32Args a, cons
 int gemm_f32_fewrows_split(int M, int N, int K) {
     if (!g_gemm_f32_v2 || !g_gemm_f32_ksplit || M > 4096 || (N & 3) || K < 96) return 1;
     const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-    if (tiles >= 256 || tiles < 8) return 1;
-    int ns = (int)std::min<long>(std::min<long>(8, (256 + tiles - 1) / tiles), K / 48);
+    if (tiles >= 256 || tiles < g_gemm_f32_ksplit_min_tiles) return 1;
+    int ns = (int)std::min<long>(std::min<long>(tiles < 8 ? 16 : 8, (256 + tiles - 1) / tiles), K / 48);
     if (ns < 2) return 1;
     const int kchunk = ((K + ns - 1) / ns + 15) / 16 * 16;
     return (K + kchunk - 1) / kchunk;

@@ -2681,6 +2681,7 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
     else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_ksplit_min_tiles") g_gemm_f32_ksplit_min_tiles = std::max(1, iv);      // ... only from that many 64 x 64 output tiles on
     else if (n == "f32_no_ksplit") g_gemm_f32_ksplit = !on;            // ... few-row products as one 64-tile launch
     else if (n == "f32_gemm_small_v1") g_gemm_f32_v2_small = !on;      // ... the round-3 64-tile kernel for every 64 x 64-tiled product
     else if (n == "f32_gemm_w4") g_gemm_f32_w8 = !on;                  // ... without the 8-wave tiles (process-wide, A/B only)
