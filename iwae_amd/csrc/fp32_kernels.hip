@@ -1127,6 +1127,7 @@ int g_gemm_f32_dbg = 0;
 bool g_gemm_f32_v2 = true;
 int g_gemm_f32_ksplit_min_tiles = 1;    // (option f32_ksplit_min_tiles: 8 = round-5 first version: B >= 100 images only)
 bool g_gemm_f32_ksplit = true;        // (option f32_no_ksplit = 1: few-row products as one 64-tile launch walking K alone)
+int g_gemm_f32_v2_small_min = 1;        // (option f32_gemm_small_min: workgroups from which the 64 x 64 launch takes the v2 loop)
 bool g_gemm_f32_v2_small = true;      // (option f32_gemm_small_v1 = 1)
 bool g_gemm_f32_w8 = true;       // (iwae_set_option f32_gemm_w4 = 1: no 8-wave tiles)      // (iwae_set_option f32_gemm_v1 = 1: the round-3 loop, for A/B measurements; process-wide)
 // Tile choice of the big kernels.  4-wave tiles (1 024 workgroup slots on the chip): 128 x 128, 64 x 224, 224 x 64 -- the candidate with the least padded
@@ -1221,7 +1222,7 @@ void launch_gemm_f32(const GemmF32Args& a0, int nsplit, hipStream_t st) {
         const dim3 grid((a.N + 63) / 64, (Mg + 63) / 64, nsplit);
         const bool ak = a.sak == 1, bnf = a.sbn == 1;
         // many 64 x 64 tiles (the 50-wide latent layer on all rows, its weight gradient's row splits): the v2 loop on that tile
-        if (g_gemm_f32_v2 && g_gemm_f32_v2_small && (long)grid.x * grid.y * grid.z >= 256 && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1)) {
+        if (g_gemm_f32_v2 && g_gemm_f32_v2_small && (long)grid.x * grid.y * grid.z >= g_gemm_f32_v2_small_min && (a.sak == 1 || a.sam == 1) && (a.sbn == 1 || a.sbk == 1)) {
             if (ak && bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, true, true>), grid, dim3(256), 0, st, a);
             else if (ak) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, true, false>), grid, dim3(256), 0, st, a);
             else if (bnf) hipLaunchKernelGGL((gemm_f32_v2_kernel<2, 2, 2, 2, false, true>), grid, dim3(256), 0, st, a);

@@ -378,7 +378,7 @@ long gemm_f32_tiles(int M, int N, int tile_mode = 0);                       // o
 bool gemm_f32_takes_big(int M, int N, int nsplit);      // launch_gemm_f32's kernel choice (GEMM_EPI_BERN needs the 128-tile kernel)
 void launch_gemm_f32(const GemmF32Args& a, int nsplit, hipStream_t st);
 extern int g_gemm_f32_dbg;
-extern int g_gemm_f32_ksplit_min_tiles;
+extern int g_gemm_f32_ksplit_min_tiles, g_gemm_f32_v2_small_min;
 extern bool g_gemm_f32_w8, g_gemm_f32_v2_small, g_gemm_f32_ksplit;
 int gemm_f32_fewrows_split(int M, int N, int K);        // > 1: launch_gemm_f32_fewrows splits K that many ways (scratch: split * M * N floats)
 void launch_gemm_f32_fewrows(const GemmF32Args& a, float* slabs, hipStream_t st);

@@ -181,6 +181,7 @@ struct iwae_model {
     // lse_kernel's outputs once more, written by the copy of it that runs on the side stream (see forward_impl): the output layer's
     // weight gradient takes its row weights from there
     DevBuf logw2, wn2, gx2, cf2, per_b2;
+    int f32_dw_min_rows = 32;   // float32 weight gradients: a row split covers at least this many rows (option f32_dw_min_rows; 64 until round 5)
     int f32_dw_tiles = 1024;    // float32 weight gradients: workgroups aimed at per launch (row splits = this / output tiles; option f32_dw_tiles)
     bool f32_dec_fused_train = false;
     bool allow_f32_dec_fused = true;                           // float32 mode: the decoder forward as one launch (dec_fwd_f32_kernel; option no_f32_dec_fused)
@@ -1842,7 +1843,7 @@ int f32_dw(iwae_model* m, const KerasLayer& kl, const float* X, long ldx, const 
     // row splits: enough workgroups to fill the machine (~1 000 tiles of 64 x 64 or 128 x 128), at least 64 rows per split
     const int tiles = (int)gemm_f32_tiles(kl.Kin + 1, kl.Nout, tile_mode);      // (+ 1: the row of ones whose product row is the bias gradient)
     const int slots = std::min(m->f32_dw_tiles, gemm_f32_slots(kl.Kin + 1, kl.Nout, tile_mode));
-    int nsplit = std::max(1, std::min(std::min(256, rows / 64), slots / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
+    int nsplit = std::max(1, std::min(std::min(256, rows / m->f32_dw_min_rows), slots / tiles));      // (rounded DOWN: 1 027 workgroups on 1 024 slots are a second round of 3)
     while (nsplit > 8 && (tiles * nsplit) % 8 != 0) --nsplit;      // (a multiple of 8 workgroups: gemm_f32_v2_kernel then keeps a split's tiles on one XCD)
     const size_t nW = (size_t)kl.Kin * kl.Nout;
     // (round 5: the slabs of every gradient of the step stay until ONE reduction launch at the end of the backward pass; the buffer is sized for a
@@ -2680,7 +2681,9 @@ int iwae_set_option(iwae_handle m, const char* name, int64_t value) {
     else if (n == "no_defer2_split") m->allow_defer2_split = !on;     // ... one deferred update on `tail` instead of one per side stream
     else if (n == "no_defer2") m->allow_defer2 = !on;                 // 2-layer step: one reduction + update of all layers on the main stream
     else if (n == "f32_dw_tiles") m->f32_dw_tiles = std::max(1, iv);
+    else if (n == "f32_dw_min_rows") m->f32_dw_min_rows = std::max(16, iv);
     else if (n == "f32_gemm_dbg") g_gemm_f32_dbg = (int)value;         // DIAG builds: timing ablations of gemm_f32_v2_kernel (1 no fetch, 2 no stash, 4 no MFMAs, 16 no barrier)
+    else if (n == "f32_gemm_small_min") g_gemm_f32_v2_small_min = std::max(1, iv);
     else if (n == "f32_ksplit_min_tiles") g_gemm_f32_ksplit_min_tiles = std::max(1, iv);      // ... only from that many 64 x 64 output tiles on
     else if (n == "f32_no_ksplit") g_gemm_f32_ksplit = !on;            // ... few-row products as one 64-tile launch
     else if (n == "f32_gemm_small_v1") g_gemm_f32_v2_small = !on;      // ... the round-3 64-tile kernel for every 64 x 64-tiled product
